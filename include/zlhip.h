@@ -1,0 +1,221 @@
+/*
+ * zlhip.h -- C-ABI of the MI355X sampler engine that replaces libzl's audio hot path.
+ *
+ * Drop-in seam (reference, paths under /root/reference/lib):
+ *   SamplerChannel::process            SamplerSynth.cpp:116-148   -> zlhip_render / zlhip_render_batch
+ *   SamplerChannel::handleCommand      SamplerSynth.cpp:187-230   -> zlhip_handle_command
+ *   SamplerSynth::registerClip / SamplerSynthSound::loadSoundData
+ *                                      SamplerSynth.cpp:285-295, SamplerSynthSound.cpp:28-59 -> zlhip_sound_upload
+ *   ClipAudioSource getters read per block by the voice
+ *                                      SamplerSynthVoice.cpp:189-196, ClipAudioSource.cpp:261-277,338-346,362,619,692
+ *                                                                 -> zlhip_clip_set
+ *   SamplerSynthVoice::process         SamplerSynthVoice.cpp:174-270 -> HIP kernels behind zlhip_render*
+ *   positions-model report             SamplerSynthVoice.cpp:265-267 -> zlhip_voice_reports
+ *   AudioLevels::timerCallback         AudioLevels.cpp:347-412    -> zlhip_levels_tick
+ *   JackPassthroughPrivate::process    JackPassthrough.cpp:45-115 -> zlhip_passthrough_*
+ *
+ * Plain C: opaque handle, POD structs, raw pointers and sizes, int status codes.  No torch / Qt /
+ * JUCE types.  All functions are thread-compatible (one caller at a time per engine), mirroring
+ * the reference where each SamplerChannel is driven by one JACK thread.
+ * The library has NO CPU render path: if no HIP device is usable, zlhip_engine_create fails with
+ * ZLHIP_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef ZLHIP_H
+#define ZLHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZLHIP_ABI_VERSION 1
+
+/* status codes */
+#define ZLHIP_OK                 0
+#define ZLHIP_ERR_INVALID       -1   /* bad argument */
+#define ZLHIP_ERR_NO_DEVICE     -2   /* no usable HIP device / kernels not loadable */
+#define ZLHIP_ERR_HIP           -3   /* a HIP runtime call failed (see zlhip_last_error) */
+#define ZLHIP_ERR_CAPACITY      -4   /* arena / table / batch capacity exceeded */
+#define ZLHIP_ERR_STATE         -5   /* call not valid in the current state */
+
+/* render modes: 0 reproduces the reference bit for bit (quirks Q1/Q2 of SURVEY.md section 0) */
+#define ZLHIP_MODE_FAITHFUL      0u
+#define ZLHIP_MODE_FIX_GAIN      1u  /* gain/envelope/volume scale the whole interpolated sample */
+#define ZLHIP_MODE_FIX_DELAY     2u  /* frame f is written to out[f] instead of out[f+1] */
+#define ZLHIP_MODE_HERMITE       4u  /* build-defined extension: 4-tap Catmull-Rom interpolation */
+
+#define ZLHIP_MAX_SLICES         128
+#define ZLHIP_BEAT_SUBDIVISIONS  96  /* SyncTimer.cpp:95 */
+
+typedef struct zlhip_engine zlhip_engine;
+
+typedef struct zlhip_config {
+    uint32_t struct_size;            /* sizeof(zlhip_config), for ABI growth */
+    int32_t  device;                 /* HIP device ordinal */
+    int32_t  num_buses;              /* SamplerChannels (reference: 12, SamplerSynth.cpp:258) */
+    int32_t  voices_per_bus;         /* voices per channel (reference: 8, SamplerSynth.cpp:23) */
+    int32_t  max_frames;             /* largest nframes per block; multiple of 64, <= 4096 */
+    int32_t  max_batch_blocks;       /* largest nblocks per zlhip_render_batch call */
+    int32_t  max_sounds;             /* clip / sound table size */
+    uint32_t mode;                   /* ZLHIP_MODE_* */
+    double   playback_sample_rate;   /* jack_get_sample_rate, SamplerSynth.cpp:271-272 */
+    uint64_t sound_arena_bytes;      /* HBM reserved for decoded sources */
+    int32_t  voices_per_task;        /* 0 = auto; voices summed sequentially by one wavefront (mix group) */
+    int32_t  reserved;
+} zlhip_config;
+
+/* clock inputs of one block: JACK cycle times + SyncTimer playhead getters
+ * (SamplerSynth.cpp:128, SyncTimer.cpp:990-1009) */
+typedef struct zlhip_clock {
+    uint64_t current_usecs;
+    uint64_t next_usecs;
+    uint64_t jack_playhead;
+    uint64_t jack_playhead_usecs;
+    uint64_t jack_subbeat_length_usecs;
+} zlhip_clock;
+
+/* snapshot of the ClipAudioSource fields the voice reads (ClipAudioSource.cpp:63-82) */
+typedef struct zlhip_clip_params {
+    float   start_position_seconds;
+    float   length_seconds;
+    float   length_in_beats;
+    float   volume_absolute;         /* tracktion fader position in [0,1], taken as an input */
+    float   pan;
+    float   duration_seconds;        /* getDuration() */
+    float   adsr_attack, adsr_decay, adsr_sustain, adsr_release;
+    int32_t root_note;
+    int32_t num_slice_positions;
+    double  slice_positions[ZLHIP_MAX_SLICES];
+} zlhip_clip_params;
+
+/* ClipCommand (ClipCommand.h:11-32); `clip` is the id returned by zlhip_sound_upload */
+typedef struct zlhip_clip_command {
+    int32_t clip;
+    int32_t midi_note;
+    int32_t midi_channel;
+    int32_t start_playback, stop_playback;
+    int32_t change_slice, slice;
+    int32_t change_looping, looping;
+    int32_t change_pitch;   float pitch_change;
+    int32_t change_speed;   float speed_ratio;
+    int32_t change_gain_db; float gain_db;
+    int32_t change_volume;  float volume;
+} zlhip_clip_command;
+
+/* what SamplerSynthVoice.cpp:265-267 hands to ClipAudioSourcePositionsModel, per voice slot */
+typedef struct zlhip_voice_report {
+    int32_t playing;                 /* voice->isPlaying after the render */
+    int32_t valid;                   /* 1 if (gain, progress) were reported for the last rendered block */
+    float   gain;                    /* peakGain * 0.5f */
+    float   progress;                /* sourceSamplePosition / sourceSampleLength */
+    int32_t clip;                    /* clip id the voice plays, -1 if none */
+    int32_t reserved;
+    double  source_sample_position;  /* d->sourceSamplePosition after the render (parity checks) */
+} zlhip_voice_report;
+
+/* AudioLevels per-channel meter state + outputs (AudioLevels.cpp:359-398) */
+typedef struct zlhip_levels {
+    int32_t peak_a, peak_b;                          /* integer peaks after decay + scan */
+    float   peak_a_hold_signal, peak_b_hold_signal;  /* 0.9x hold (playback channel) */
+    float   peak_db_a, peak_db_b, combined_db, hold_db_a, hold_db_b;
+    float   rms_a, rms_b;                            /* build-defined extension: RMS of the scanned block */
+} zlhip_levels;
+
+/* JackPassthrough parameters (JackPassthrough.cpp:27-31) */
+typedef struct zlhip_passthrough_params {
+    float   dry_amount, wet_fx1_amount, wet_fx2_amount, pan_amount;
+    int32_t muted;
+} zlhip_passthrough_params;
+
+/* profiling counters of the last zlhip_render_batch (HIP events on the engine's stream) */
+typedef struct zlhip_timings {
+    float plan_ms;        /* control-plan kernel (K1) */
+    float render_ms;      /* gather-interp-mix kernel (K2), the dominant one */
+    float finalize_ms;    /* bus reduce + levels kernel (K3) */
+    float total_ms;       /* first launch to last completion */
+    uint64_t source_bytes;   /* algorithmic source bytes of the batch: sum (ceil(N*ratio)+taps-1)*ch*4 */
+    uint64_t slow_blocks;    /* voice-blocks that needed the per-frame control path */
+    uint64_t active_voice_frames; /* voice-samples rendered */
+} zlhip_timings;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int  zlhip_abi_version(void);
+void zlhip_config_default(zlhip_config *cfg);
+int  zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out);
+void zlhip_engine_destroy(zlhip_engine *e);
+const char *zlhip_last_error(const zlhip_engine *e);          /* borrowed, valid until the next call */
+const char *zlhip_strerror(int status);
+
+/* ---- sounds and clip parameters ----------------------------------------------------------- */
+/* Upload a decoded source (planar fp32, right == NULL for mono) from host memory; returns its id
+ * in *out_id.  The id doubles as the clip id (one SamplerSynthSound per ClipAudioSource). */
+int zlhip_sound_upload(zlhip_engine *e, const float *left, const float *right, int32_t length,
+                       double sample_rate, int32_t *out_id);
+/* Same, but left/right are DEVICE pointers on the engine's device (no PCIe transfer). */
+int zlhip_sound_upload_device(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length,
+                              double sample_rate, int32_t *out_id);
+int zlhip_sound_release(zlhip_engine *e, int32_t id);          /* SamplerSynth::unregisterClip */
+void zlhip_clip_params_default(zlhip_clip_params *p, float duration_seconds);   /* ClipAudioSource ctor defaults */
+int zlhip_clip_set(zlhip_engine *e, int32_t id, const zlhip_clip_params *p);
+
+/* ---- commands ------------------------------------------------------------------------------ */
+void zlhip_clip_command_clear(zlhip_clip_command *c);           /* ClipCommand.h:74-91 */
+/* SamplerChannel::handleCommand for the bus whose midi channel matches (bus b has midi channel
+ * b - 2, SamplerSynth.cpp:270).  Returns 1 if a voice took / merged the command, 0 if it was
+ * dropped (no free voice, as in the reference), < 0 on error. */
+int zlhip_handle_command(zlhip_engine *e, const zlhip_clip_command *cmd, uint64_t current_tick);
+/* Same, addressed to an explicit voice slot of a bus (bypasses first-free allocation; used to
+ * build large synthetic scenes deterministically). */
+int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd, uint64_t current_tick);
+
+/* ---- render -------------------------------------------------------------------------------- */
+/* One real-time block: renders nframes for every bus and copies the mix to host memory.
+ * out_left/out_right: [num_buses][nframes] each (host).  Synchronous. */
+int zlhip_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right);
+/* Throughput mode: nblocks consecutive blocks in one pass.  clocks: host [nblocks].
+ * bus_out_dev: DEVICE buffer laid out [num_buses][2][nblocks*nframes] fp32, or NULL to use the
+ * engine's internal buffer (readable with zlhip_read_bus).  stream: hipStream_t or NULL for the
+ * engine's own stream.  Asynchronous; zlhip_synchronize waits. */
+int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks,
+                       float *bus_out_dev, void *stream);
+int zlhip_synchronize(zlhip_engine *e);
+/* copy the internal bus buffer of the last batch to host: out [num_buses][2][nblocks*nframes] */
+int zlhip_read_bus(zlhip_engine *e, float *out, size_t out_floats);
+/* per-voice reports of the last rendered block: out [num_buses*voices_per_bus] */
+int zlhip_voice_reports(zlhip_engine *e, zlhip_voice_report *out, int32_t count);
+/* debug: per-frame (int)sourceSamplePosition of every voice for the blocks of the NEXT batches,
+ * kept on device and read back with zlhip_debug_read_trace: out [nblocks][voices][nframes] int32 */
+int zlhip_debug_enable_trace(zlhip_engine *e, int enable);
+int zlhip_debug_read_trace(zlhip_engine *e, int32_t *out, size_t out_ints);
+
+/* ---- levels -------------------------------------------------------------------------------- */
+/* One AudioLevels timer tick for every bus over block `block_index` of the last batch
+ * (-1 = the last block; the reference only ever sees the most recent block, AudioLevels.cpp:361-384).
+ * out: [num_buses].  with_hold_bus: index of the bus that keeps the 0.9x hold (reference:
+ * channel index 1, AudioLevels.cpp:391-398), -1 for none. */
+int zlhip_levels_tick(zlhip_engine *e, int32_t block_index, int32_t with_hold_bus, zlhip_levels *out);
+/* raw per-block integer peaks of the last batch: out [nblocks][num_buses][2] */
+int zlhip_block_peaks(zlhip_engine *e, int32_t *out, size_t out_ints);
+/* levels of an arbitrary DEVICE bus buffer [num_buses][2][nblocks*nframes] (e.g. the result of a
+ * multi-GPU reduce): recomputes the per-block peaks the next zlhip_levels_tick will use */
+int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblocks, int32_t nframes, void *stream);
+
+/* ---- JackPassthrough fan-out ---------------------------------------------------------------- */
+void zlhip_passthrough_params_default(zlhip_passthrough_params *p);
+/* in_dev: [num_buses][2][frames]; out_dev: [num_buses][6][frames] = dryL,dryR,fx1L,fx1R,fx2L,fx2R.
+ * params: host [num_buses]. */
+int zlhip_passthrough_process(zlhip_engine *e, const zlhip_passthrough_params *params, const float *in_dev,
+                              float *out_dev, int64_t frames, void *stream);
+
+/* ---- introspection / measurement ------------------------------------------------------------ */
+int zlhip_set_profiling(zlhip_engine *e, int enable);
+int zlhip_last_timings(zlhip_engine *e, zlhip_timings *out);
+float *zlhip_bus_device_ptr(zlhip_engine *e);                   /* internal [B][2][Kmax*Nmax] buffer */
+int zlhip_device_name(zlhip_engine *e, char *buf, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

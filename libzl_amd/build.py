@@ -1,0 +1,97 @@
+"""Builds the in-tree native libraries.
+
+    libzl_amd/lib/libzlhip.so      HIP engine + C-ABI (include/zlhip.h), gfx950 only
+    oracle/_build/libzl_oracle.so  CPU oracle (test infrastructure; never loaded by the product)
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build container.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "libzl_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "libzl_amd", "lib")
+LIB = os.path.join(LIBDIR, "libzlhip.so")
+
+HIP_SOURCES = ["zl_kernels.hip", "zl_engine.cpp", "zl_libzl.cpp"]
+HEADERS = ["zl_types.h", "zl_plan.h", "zl_render.h", "zl_kernels.h", "zl_host.h",
+           os.path.join("..", "..", "include", "zlhip.h"), os.path.join("..", "..", "include", "libzl_hotpath.h")]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (needed to build libzlhip.so for gfx950)")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_engine(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [
+        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        # the oracle defines an un-fused rounding sequence; never contract a*b+c into fma
+        "-ffp-contract=off", "-fno-fast-math",
+        "-x", "hip",
+        "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+        "-Wall", "-Wno-unused-function",
+        "-o", LIB,
+    ] + srcs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed building libzlhip.so")
+    if verbose and res.stderr:
+        sys.stderr.write(res.stderr)
+    return LIB
+
+
+def build_oracle(force: bool = False) -> str:
+    odir = os.path.join(ROOT, "oracle")
+    target = os.path.join(odir, "_build", "libzl_oracle.so")
+    deps = [os.path.join(odir, "zl_oracle.c"), os.path.join(odir, "zl_oracle.h"), os.path.join(odir, "Makefile")]
+    if force or _stale(target, deps):
+        res = subprocess.run(["make", "-C", odir, "_build/libzl_oracle.so"], capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError("building the CPU oracle failed")
+    return target
+
+
+def build_cpu_harness(force: bool = False) -> str:
+    """Host build of the __host__ __device__ planning / per-frame code for CPU-only unit tests."""
+    hdir = os.path.join(ROOT, "tests", "cpu_harness")
+    target = os.path.join(hdir, "_build", "libzl_plan_host.so")
+    src = os.path.join(hdir, "plan_host.cpp")
+    deps = [src] + [os.path.join(CSRC, h) for h in ("zl_types.h", "zl_plan.h", "zl_render.h")]
+    if force or _stale(target, deps):
+        os.makedirs(os.path.dirname(target), exist_ok=True)
+        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+               "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", target, src]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError("building the CPU test harness failed")
+    return target
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    print(build_engine(force=force, verbose=True))
+    print(build_oracle(force=force))

@@ -1,0 +1,649 @@
+// zl_engine.cpp -- host side of the C-ABI in include/zlhip.h.
+//
+// Owns the HBM layout (source arena, clip / sound / voice tables, per-batch plan records, bus and
+// level buffers), mirrors the control-plane half of the reference's SamplerChannel (voice
+// allocation and command merge, SamplerSynth.cpp:187-230; startNote's one-off math,
+// SamplerSynthVoice.cpp:110-144) and launches the kernels of zl_kernels.hip.  There is no CPU
+// render path in this library: every sample is produced by the HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/zlhip.h"
+#include "zl_host.h"
+#include "zl_kernels.h"
+#include "zl_plan.h"
+#include "zl_types.h"
+
+namespace {
+
+struct PassParamsDev { float dry, fx1, fx2, pan; int muted; };
+
+template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)); }
+
+}  // namespace
+
+struct zlhip_engine {
+    zlhip_config cfg{};
+    int V = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    char devname[256] = {0};
+
+    // HBM
+    float *arena = nullptr; size_t arenaFloats = 0, arenaUsed = 0;
+    ZlSound *dSounds = nullptr; ZlClip *dClips = nullptr;
+    ZlVoiceState *dVoices = nullptr; ZlVoiceConst *dVconst = nullptr;
+    ZlBlockPlan *dPlans = nullptr; ZlSegment *dSegs = nullptr;
+    double *dCtlP = nullptr; float *dCtlEnv = nullptr;
+    ZlReport *dReports = nullptr; float *dGain = nullptr;
+    float *dPartials = nullptr; float *dBus = nullptr;
+    ZlBlockLevels *dLevels = nullptr; ZlLevelsState *dLevelState = nullptr;
+    ZlClock *dClocks = nullptr; ZlVoiceOp *dOps = nullptr; ZlOpRange *dOpRanges = nullptr;
+    ZlBatchStats *dStats = nullptr; int32_t *dTrace = nullptr; PassParamsDev *dPass = nullptr;
+    size_t opsCap = 0, rangesCap = 0, traceInts = 0;
+    int maxGroups = 1;
+
+    // pinned host staging
+    ZlClock *hClocks = nullptr; ZlReport *hReports = nullptr; float *hGain = nullptr; float *hBus = nullptr;
+    ZlLevelsState *hLevelState = nullptr; ZlBatchStats *hStats = nullptr;
+
+    // host mirrors
+    ZlHostControl hc;                    // voices / sounds / clip parameters / pending ops (zl_host.h)
+    std::vector<ZlVoiceOp> sortedOps; std::vector<ZlOpRange> ranges;
+
+    // last batch
+    int lastK = 0, lastN = 0; float *lastBus = nullptr; bool outstanding = false; bool reportsFresh = false;
+    bool trace = false; int traceK = 0, traceN = 0;
+    int forceSlow = 0;
+
+    // profiling
+    bool profiling = false; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    zlhip_timings timings{};
+};
+
+#define ZL_HIP(e, call)                                                                        \
+    do {                                                                                       \
+        hipError_t st_ = (call);                                                               \
+        if (st_ != hipSuccess) {                                                               \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(st_);                     \
+            return ZLHIP_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+#define ZL_KERNEL(e, call)                                                                     \
+    do {                                                                                       \
+        int st_ = (call);                                                                      \
+        if (st_ != 0) {                                                                        \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString((hipError_t)st_);         \
+            return ZLHIP_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+static int fail(zlhip_engine *e, int code, const char *msg)
+{
+    if (e) e->err = msg;
+    return code;
+}
+
+extern "C" {
+
+int zlhip_abi_version(void) { return ZLHIP_ABI_VERSION; }
+
+const char *zlhip_strerror(int status)
+{
+    switch (status) {
+    case ZLHIP_OK: return "ok";
+    case ZLHIP_ERR_INVALID: return "invalid argument";
+    case ZLHIP_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU render path)";
+    case ZLHIP_ERR_HIP: return "HIP runtime error";
+    case ZLHIP_ERR_CAPACITY: return "capacity exceeded";
+    case ZLHIP_ERR_STATE: return "invalid state";
+    default: return "unknown status";
+    }
+}
+
+const char *zlhip_last_error(const zlhip_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+void zlhip_config_default(zlhip_config *cfg)
+{
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->device = 0;
+    cfg->num_buses = 12;             // SamplerSynth.cpp:258
+    cfg->voices_per_bus = 8;         // SamplerSynth.cpp:23
+    cfg->max_frames = 1024;
+    cfg->max_batch_blocks = 64;
+    cfg->max_sounds = 1024;
+    cfg->mode = ZLHIP_MODE_FAITHFUL;
+    cfg->playback_sample_rate = 48000.0;
+    cfg->sound_arena_bytes = 256ull << 20;
+    cfg->voices_per_task = 0;
+}
+
+void zlhip_engine_destroy(zlhip_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dVconst, e->dPlans, e->dSegs, e->dCtlP, e->dCtlEnv,
+                    e->dReports, e->dGain, e->dPartials, e->dBus, e->dLevels, e->dLevelState, e->dClocks, e->dOps,
+                    e->dOpRanges, e->dStats, e->dTrace, e->dPass };
+    for (void *p : dev) if (p) (void)hipFree(p);
+    void *host[] = { e->hClocks, e->hReports, e->hGain, e->hBus, e->hLevelState, e->hStats };
+    for (void *p : host) if (p) (void)hipHostFree(p);
+    for (auto &x : e->ev) if (x) (void)hipEventDestroy(x);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
+{
+    if (!cfg || !out) return ZLHIP_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->num_buses < 1 || cfg->voices_per_bus < 1 || cfg->max_frames < 64 || cfg->max_frames > 4096
+        || (cfg->max_frames % 64) != 0 || cfg->max_batch_blocks < 1 || cfg->max_sounds < 1
+        || !(cfg->playback_sample_rate > 0.0) || (cfg->mode & ~7u))
+        return ZLHIP_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return ZLHIP_ERR_NO_DEVICE;
+    if (hipSetDevice(cfg->device) != hipSuccess) return ZLHIP_ERR_NO_DEVICE;
+
+    zlhip_engine *e = new zlhip_engine();
+    e->cfg = *cfg;
+    e->device = cfg->device;
+    e->V = cfg->num_buses * cfg->voices_per_bus;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) std::snprintf(e->devname, sizeof e->devname, "%s (%s)", prop.name, prop.gcnArchName);
+
+    const size_t V = (size_t)e->V, K = (size_t)cfg->max_batch_blocks, N = (size_t)cfg->max_frames, B = (size_t)cfg->num_buses;
+    const int minG = std::min(8, cfg->voices_per_bus);
+    e->maxGroups = cfg->voices_per_task > 0 ? (cfg->voices_per_bus + cfg->voices_per_task - 1) / cfg->voices_per_task
+                                           : (cfg->voices_per_bus + minG - 1) / minG;
+    e->arenaFloats = (size_t)(cfg->sound_arena_bytes / sizeof(float));
+
+    int rc = ZLHIP_OK;
+    auto chk = [&](hipError_t st, const char *what) {
+        if (st != hipSuccess && rc == ZLHIP_OK) { e->err = std::string(what) + ": " + hipGetErrorString(st); rc = ZLHIP_ERR_HIP; }
+    };
+    chk(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
+    chk(dalloc(&e->arena, e->arenaFloats), "arena");
+    chk(dalloc(&e->dSounds, (size_t)cfg->max_sounds), "sounds");
+    chk(dalloc(&e->dClips, (size_t)cfg->max_sounds), "clips");
+    chk(dalloc(&e->dVoices, V), "voices");
+    chk(dalloc(&e->dVconst, V), "vconst");
+    chk(dalloc(&e->dPlans, K * V), "plans");
+    chk(dalloc(&e->dSegs, K * V * (ZL_MAXSEG - 1)), "segments");
+    chk(dalloc(&e->dCtlP, K * V * N), "ctlP");
+    chk(dalloc(&e->dCtlEnv, K * V * N), "ctlEnv");
+    chk(dalloc(&e->dReports, V), "reports");
+    chk(dalloc(&e->dGain, V), "gain");
+    chk(dalloc(&e->dPartials, e->maxGroups > 1 ? K * B * (size_t)e->maxGroups * 2 * N : 1), "partials");
+    chk(dalloc(&e->dBus, B * 2 * K * N), "bus");
+    chk(dalloc(&e->dLevels, K * B), "levels");
+    chk(dalloc(&e->dLevelState, B), "levelState");
+    chk(dalloc(&e->dClocks, K), "clocks");
+    chk(dalloc(&e->dStats, 1), "stats");
+    chk(dalloc(&e->dPass, B), "passthrough params");
+    chk(hipHostMalloc((void **)&e->hClocks, K * sizeof(ZlClock)), "hClocks");
+    chk(hipHostMalloc((void **)&e->hReports, V * sizeof(ZlReport)), "hReports");
+    chk(hipHostMalloc((void **)&e->hGain, V * sizeof(float)), "hGain");
+    chk(hipHostMalloc((void **)&e->hBus, B * 2 * N * sizeof(float)), "hBus");
+    chk(hipHostMalloc((void **)&e->hLevelState, B * sizeof(ZlLevelsState)), "hLevelState");
+    chk(hipHostMalloc((void **)&e->hStats, sizeof(ZlBatchStats)), "hStats");
+    for (auto &x : e->ev) chk(hipEventCreate(&x), "hipEventCreate");
+    if (rc == ZLHIP_OK) {
+        chk(hipMemsetAsync(e->dSounds, 0, (size_t)cfg->max_sounds * sizeof(ZlSound), e->stream), "memset sounds");
+        chk(hipMemsetAsync(e->dClips, 0, (size_t)cfg->max_sounds * sizeof(ZlClip), e->stream), "memset clips");
+        chk(hipMemsetAsync(e->dVoices, 0, V * sizeof(ZlVoiceState), e->stream), "memset voices");
+        chk(hipMemsetAsync(e->dLevelState, 0, B * sizeof(ZlLevelsState), e->stream), "memset levels");
+        chk(hipMemsetAsync(e->dReports, 0, V * sizeof(ZlReport), e->stream), "memset reports");
+        chk(hipMemsetAsync(e->dBus, 0, B * 2 * K * N * sizeof(float), e->stream), "memset bus");
+        chk(hipStreamSynchronize(e->stream), "sync");
+    }
+    if (rc != ZLHIP_OK) {
+        std::fprintf(stderr, "zlhip_engine_create: %s\n", e->err.c_str());
+        zlhip_engine_destroy(e);
+        return rc;
+    }
+    e->hc.init(cfg->num_buses, cfg->voices_per_bus, cfg->max_sounds, cfg->playback_sample_rate);
+    std::memset(e->hReports, 0, V * sizeof(ZlReport));
+    *out = e;
+    return ZLHIP_OK;
+}
+
+int zlhip_device_name(zlhip_engine *e, char *buf, size_t len)
+{
+    if (!e || !buf || !len) return ZLHIP_ERR_INVALID;
+    std::snprintf(buf, len, "%s", e->devname);
+    return ZLHIP_OK;
+}
+
+// ---- sounds / clips ---------------------------------------------------------------------------
+void zlhip_clip_params_default(zlhip_clip_params *p, float duration_seconds)
+{
+    ZlHostControl::default_clip_params(p, duration_seconds);
+}
+
+static int alloc_sound_slot(zlhip_engine *e, int32_t length, int channels, double sample_rate, int32_t *out_id, float **dst)
+{
+    if (length < 1 || !(sample_rate > 0.0) || !out_id) return fail(e, ZLHIP_ERR_INVALID, "bad sound arguments");
+    int id = -1;
+    for (int i = 0; i < e->cfg.max_sounds; ++i) if (!e->hc.soundUsed[i]) { id = i; break; }
+    if (id < 0) return fail(e, ZLHIP_ERR_CAPACITY, "sound table full");
+    const size_t pad = 8;
+    size_t floats = ((size_t)length + pad) * (size_t)channels;
+    floats = (floats + 3) & ~(size_t)3;                           // keep every source 16-byte aligned
+    if (e->arenaUsed + floats > e->arenaFloats) return fail(e, ZLHIP_ERR_CAPACITY, "sound arena full");
+    ZlSound s; s.offset = e->arenaUsed; s.length = length; s.channels = channels; s.sample_rate = sample_rate;
+    *dst = e->arena + e->arenaUsed;
+    e->arenaUsed += floats;
+    e->hc.sounds[id] = s;
+    e->hc.soundUsed[id] = 1;
+    *out_id = id;
+    return ZLHIP_OK;
+}
+
+static int publish_sound(zlhip_engine *e, int id)
+{
+    ZL_HIP(e, hipMemcpyAsync(e->dSounds + id, &e->hc.sounds[id], sizeof(ZlSound), hipMemcpyHostToDevice, e->stream));
+    zlhip_clip_params p;
+    zlhip_clip_params_default(&p, (float)(e->hc.sounds[id].length / e->hc.sounds[id].sample_rate));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    return zlhip_clip_set(e, id, &p);
+}
+
+int zlhip_sound_upload_device(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length,
+                              double sample_rate, int32_t *out_id)
+{
+    if (!e || !left_dev) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    float *dst = nullptr;
+    int rc = alloc_sound_slot(e, length, right_dev ? 2 : 1, sample_rate, out_id, &dst);
+    if (rc != ZLHIP_OK) return rc;
+    ZL_KERNEL(e, zl_launch_interleave(left_dev, right_dev, dst, length, 8, e->stream));
+    return publish_sound(e, *out_id);
+}
+
+int zlhip_sound_upload(zlhip_engine *e, const float *left, const float *right, int32_t length, double sample_rate, int32_t *out_id)
+{
+    if (!e || !left) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    float *dst = nullptr;
+    const int ch = right ? 2 : 1;
+    int rc = alloc_sound_slot(e, length, ch, sample_rate, out_id, &dst);
+    if (rc != ZLHIP_OK) return rc;
+    std::vector<float> tmp(((size_t)length + 8) * ch, 0.0f);
+    if (right) for (int32_t i = 0; i < length; ++i) { tmp[2 * (size_t)i] = left[i]; tmp[2 * (size_t)i + 1] = right[i]; }
+    else std::memcpy(tmp.data(), left, (size_t)length * sizeof(float));
+    ZL_HIP(e, hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    return publish_sound(e, *out_id);
+}
+
+int zlhip_sound_release(zlhip_engine *e, int32_t id)
+{
+    if (!e || id < 0 || id >= e->cfg.max_sounds || !e->hc.soundUsed[id]) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    e->hc.soundUsed[id] = 0;
+    e->hc.sounds[id] = ZlSound{0, 0, 0, 0.0};
+    ZL_HIP(e, hipMemcpyAsync(e->dSounds + id, &e->hc.sounds[id], sizeof(ZlSound), hipMemcpyHostToDevice, e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    return ZLHIP_OK;
+}
+
+int zlhip_clip_set(zlhip_engine *e, int32_t id, const zlhip_clip_params *p)
+{
+    if (!e || !p || id < 0 || id >= e->cfg.max_sounds || !e->hc.soundUsed[id]) return ZLHIP_ERR_INVALID;
+    if (p->num_slice_positions < 0 || p->num_slice_positions > ZLHIP_MAX_SLICES) return fail(e, ZLHIP_ERR_INVALID, "too many slices");
+    ZL_HIP(e, hipSetDevice(e->device));
+    e->hc.clipParams[id] = *p;
+    ZlClip c;
+    ZlHostControl::fill_clip(c, *p);
+    ZL_HIP(e, hipMemcpyAsync(e->dClips + id, &c, sizeof c, hipMemcpyHostToDevice, e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    return ZLHIP_OK;
+}
+
+// ---- commands ----------------------------------------------------------------------------------
+void zlhip_clip_command_clear(zlhip_clip_command *c)
+{
+    std::memset(c, 0, sizeof *c);
+    c->clip = -1; c->midi_note = -1; c->midi_channel = -1; c->slice = -1;
+}
+
+static int refresh_host_voices(zlhip_engine *e)
+{
+    if (e->outstanding) {
+        ZL_HIP(e, hipSetDevice(e->device));
+        ZL_HIP(e, hipStreamSynchronize(e->stream));
+        e->outstanding = false;
+    }
+    if (e->reportsFresh) {
+        e->hc.absorb_reports(e->hReports);
+        e->reportsFresh = false;
+    }
+    return ZLHIP_OK;
+}
+
+int zlhip_handle_command(zlhip_engine *e, const zlhip_clip_command *cmd, uint64_t current_tick)
+{
+    if (!e || !cmd) return ZLHIP_ERR_INVALID;
+    int rc = refresh_host_voices(e);
+    if (rc != ZLHIP_OK) return rc;
+    return e->hc.handle_command(*cmd, current_tick);
+}
+
+int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd, uint64_t current_tick)
+{
+    if (!e || !cmd || bus < 0 || bus >= e->cfg.num_buses || slot < 0 || slot >= e->cfg.voices_per_bus) return ZLHIP_ERR_INVALID;
+    int rc = refresh_host_voices(e);
+    if (rc != ZLHIP_OK) return rc;
+    return e->hc.handle_on_bus(bus, *cmd, current_tick, slot);
+}
+
+// ---- render ------------------------------------------------------------------------------------
+static int pick_group(const zlhip_engine *e, int K, int N)
+{
+    const int VPB = e->cfg.voices_per_bus;
+    if (e->cfg.voices_per_task > 0) return std::min(e->cfg.voices_per_task, VPB);
+    // auto: keep whole buses in one wavefront (the reference's summation order) once there are enough
+    // workgroups to fill 256 CUs; otherwise split into mix groups of >= 8 voices
+    int G = VPB;
+    const long long tiles = (long long)K * e->cfg.num_buses * std::max(1, N / 256);
+    while (G > 8 && tiles * ((VPB + G - 1) / G) < 1024 && (VPB + (G / 2) - 1) / (G / 2) <= e->maxGroups) G /= 2;
+    return std::max(G, 1);
+}
+
+static int upload_ops(zlhip_engine *e, ZlBatch &A, hipStream_t s)
+{
+    A.n_op_ranges = 0; A.ops = nullptr; A.op_ranges = nullptr;
+    if (e->hc.pendingOps.empty()) return ZLHIP_OK;
+    e->hc.drain_ops(e->sortedOps, e->ranges);
+    if (e->sortedOps.size() > e->opsCap) {
+        if (e->dOps) ZL_HIP(e, hipFree(e->dOps));
+        e->opsCap = e->sortedOps.size() * 2;
+        ZL_HIP(e, dalloc(&e->dOps, e->opsCap));
+    }
+    if (e->ranges.size() > e->rangesCap) {
+        if (e->dOpRanges) ZL_HIP(e, hipFree(e->dOpRanges));
+        e->rangesCap = e->ranges.size() * 2;
+        ZL_HIP(e, dalloc(&e->dOpRanges, e->rangesCap));
+    }
+    // pageable -> device copies are staged synchronously by the runtime, so the vectors may be reused
+    ZL_HIP(e, hipMemcpyAsync(e->dOps, e->sortedOps.data(), e->sortedOps.size() * sizeof(ZlVoiceOp), hipMemcpyHostToDevice, s));
+    ZL_HIP(e, hipMemcpyAsync(e->dOpRanges, e->ranges.data(), e->ranges.size() * sizeof(ZlOpRange), hipMemcpyHostToDevice, s));
+    A.n_op_ranges = (int)e->ranges.size(); A.ops = e->dOps; A.op_ranges = e->dOpRanges;
+    return ZLHIP_OK;
+}
+
+int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks, float *bus_out_dev, void *stream)
+{
+    if (!e || !clocks) return ZLHIP_ERR_INVALID;
+    if (nblocks < 1 || nblocks > e->cfg.max_batch_blocks) return fail(e, ZLHIP_ERR_CAPACITY, "nblocks exceeds max_batch_blocks");
+    if (nframes < 64 || nframes > e->cfg.max_frames || (nframes % 64) != 0 || (nframes > 256 && (nframes % 256) != 0))
+        return fail(e, ZLHIP_ERR_INVALID, "nframes must be a multiple of 64 (of 256 above 256) and <= max_frames");
+    ZL_HIP(e, hipSetDevice(e->device));
+    int rc = refresh_host_voices(e);                               // also waits for the previous batch: staging buffers are reused
+    if (rc != ZLHIP_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+
+    for (int k = 0; k < nblocks; ++k) {
+        ZlHostControl::fill_clock(e->hClocks[k], clocks[k], nframes);
+    }
+    ZL_HIP(e, hipMemcpyAsync(e->dClocks, e->hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, s));
+
+    ZlBatch A; std::memset(&A, 0, sizeof A);
+    A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.N = nframes;
+    A.G = pick_group(e, nblocks, nframes);
+    A.groups = (A.VPB + A.G - 1) / A.G;
+    A.mode = e->cfg.mode;
+    A.clocks = e->dClocks; A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
+    A.voices = e->dVoices; A.vconst = e->dVconst; A.plans = e->dPlans; A.segs = e->dSegs;
+    A.ctl_P = e->dCtlP; A.ctl_env = e->dCtlEnv; A.reports = e->dReports; A.partials = e->dPartials;
+    A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.levels = e->dLevels; A.stats = e->dStats;
+    A.trace = 0; A.pos_trace = nullptr;
+    if (e->trace) {
+        const size_t need = (size_t)nblocks * e->V * nframes;
+        if (need > e->traceInts) {
+            if (e->dTrace) ZL_HIP(e, hipFree(e->dTrace));
+            ZL_HIP(e, dalloc(&e->dTrace, need));
+            e->traceInts = need;
+        }
+        ZL_HIP(e, hipMemsetAsync(e->dTrace, 0xff, need * sizeof(int32_t), s));
+        A.trace = 1; A.pos_trace = e->dTrace; e->traceK = nblocks; e->traceN = nframes;
+    }
+    rc = upload_ops(e, A, s);
+    if (rc != ZLHIP_OK) return rc;
+    ZL_HIP(e, hipMemsetAsync(e->dStats, 0, sizeof(ZlBatchStats), s));
+
+    if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[0], s));
+    ZL_KERNEL(e, zl_launch_apply_ops(A, s));
+    ZL_KERNEL(e, zl_launch_plan(A, e->forceSlow, s));
+    if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[1], s));
+    ZL_KERNEL(e, zl_launch_render(A, s));
+    if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[2], s));
+    ZL_KERNEL(e, zl_launch_finalize(A, nullptr, s));
+    ZL_KERNEL(e, zl_launch_reports(e->dReports, e->V, e->dGain, s));
+    if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[3], s));
+    ZL_HIP(e, hipMemcpyAsync(e->hReports, e->dReports, (size_t)e->V * sizeof(ZlReport), hipMemcpyDeviceToHost, s));
+    ZL_HIP(e, hipMemcpyAsync(e->hGain, e->dGain, (size_t)e->V * sizeof(float), hipMemcpyDeviceToHost, s));
+    ZL_HIP(e, hipMemcpyAsync(e->hStats, e->dStats, sizeof(ZlBatchStats), hipMemcpyDeviceToHost, s));
+    if (s != e->stream) {
+        // later engine-stream work (levels, read-back) must see this batch
+        ZL_HIP(e, hipEventRecord(e->ev[4], s));
+        ZL_HIP(e, hipStreamWaitEvent(e->stream, e->ev[4], 0));
+    }
+    e->lastK = nblocks; e->lastN = nframes; e->lastBus = A.bus;
+    e->outstanding = true; e->reportsFresh = true;
+    return ZLHIP_OK;
+}
+
+int zlhip_synchronize(zlhip_engine *e)
+{
+    if (!e) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    e->outstanding = false;
+    return ZLHIP_OK;
+}
+
+int zlhip_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right)
+{
+    if (!e || !clock || !out_left || !out_right) return ZLHIP_ERR_INVALID;
+    int rc = zlhip_render_batch(e, 1, nframes, clock, nullptr, nullptr);
+    if (rc != ZLHIP_OK) return rc;
+    const size_t B = (size_t)e->cfg.num_buses, N = (size_t)nframes;
+    ZL_HIP(e, hipMemcpyAsync(e->hBus, e->dBus, B * 2 * N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    e->outstanding = false;
+    for (size_t b = 0; b < B; ++b) {
+        std::memcpy(out_left + b * N, e->hBus + (b * 2) * N, N * sizeof(float));
+        std::memcpy(out_right + b * N, e->hBus + (b * 2 + 1) * N, N * sizeof(float));
+    }
+    return ZLHIP_OK;
+}
+
+int zlhip_read_bus(zlhip_engine *e, float *out, size_t out_floats)
+{
+    if (!e || !out) return ZLHIP_ERR_INVALID;
+    if (!e->lastBus) return fail(e, ZLHIP_ERR_STATE, "no batch rendered yet");
+    const size_t need = (size_t)e->cfg.num_buses * 2 * (size_t)e->lastK * (size_t)e->lastN;
+    if (out_floats < need) return fail(e, ZLHIP_ERR_INVALID, "output buffer too small");
+    ZL_HIP(e, hipSetDevice(e->device));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    e->outstanding = false;
+    ZL_HIP(e, hipMemcpyAsync(out, e->lastBus, need * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    return ZLHIP_OK;
+}
+
+int zlhip_voice_reports(zlhip_engine *e, zlhip_voice_report *out, int32_t count)
+{
+    if (!e || !out || count < e->V) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    if (e->outstanding) { ZL_HIP(e, hipStreamSynchronize(e->stream)); e->outstanding = false; }
+    for (int v = 0; v < e->V; ++v) {
+        const ZlReport &r = e->hReports[v];
+        zlhip_voice_report &o = out[v];
+        o.playing = r.playing; o.valid = r.valid; o.gain = r.valid ? e->hGain[v] : 0.0f; o.progress = r.progress;
+        o.clip = r.clip; o.reserved = 0; o.source_sample_position = r.P;
+    }
+    return ZLHIP_OK;
+}
+
+int zlhip_debug_enable_trace(zlhip_engine *e, int enable)
+{
+    if (!e) return ZLHIP_ERR_INVALID;
+    e->trace = enable != 0;
+    e->forceSlow = (enable & 2) ? 1 : 0;       // bit 1: route every block through the per-frame control path (test hook)
+    return ZLHIP_OK;
+}
+
+int zlhip_debug_read_trace(zlhip_engine *e, int32_t *out, size_t out_ints)
+{
+    if (!e || !out) return ZLHIP_ERR_INVALID;
+    const size_t need = (size_t)e->traceK * e->V * e->traceN;
+    if (!e->dTrace || need == 0) return fail(e, ZLHIP_ERR_STATE, "no trace recorded");
+    if (out_ints < need) return fail(e, ZLHIP_ERR_INVALID, "trace buffer too small");
+    ZL_HIP(e, hipSetDevice(e->device));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    ZL_HIP(e, hipMemcpyAsync(out, e->dTrace, need * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    return ZLHIP_OK;
+}
+
+// ---- levels -------------------------------------------------------------------------------------
+static float convert_to_dbfs(float raw)                            // AudioLevels.cpp:330-341
+{
+    if (raw <= 0) return -200;
+    const float fValue = 20 * log10f(raw);
+    if (fValue < -200) return -200;
+    return fValue;
+}
+static float add_float_db(float db1, float db2)                    // AudioLevels.cpp:234-236
+{
+    return 10 * log10f((float)(std::pow(10, db1 / 10) + std::pow(10, db2 / 10)));
+}
+
+int zlhip_levels_tick(zlhip_engine *e, int32_t block_index, int32_t with_hold_bus, zlhip_levels *out)
+{
+    if (!e || !out) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    const ZlBlockLevels *lv = nullptr;
+    if (block_index != -2) {
+        if (e->lastK <= 0) return fail(e, ZLHIP_ERR_STATE, "no batch rendered yet");
+        const int k = block_index < 0 ? e->lastK - 1 : block_index;
+        if (k >= e->lastK) return fail(e, ZLHIP_ERR_INVALID, "block index out of range");
+        lv = e->dLevels + (size_t)k * e->cfg.num_buses;
+    }
+    const int B = e->cfg.num_buses;
+    ZL_KERNEL(e, zl_launch_levels_tick(e->dLevelState, lv, B, e->lastN, with_hold_bus, e->stream));
+    ZL_HIP(e, hipMemcpyAsync(e->hLevelState, e->dLevelState, (size_t)B * sizeof(ZlLevelsState), hipMemcpyDeviceToHost, e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    e->outstanding = false;
+    static const float intToFloatMultiplier = 0.00000152587f;     // AudioLevels.cpp:349
+    for (int b = 0; b < B; ++b) {
+        const ZlLevelsState &s = e->hLevelState[b];
+        zlhip_levels &o = out[b];
+        o.peak_a = s.peak_a; o.peak_b = s.peak_b;
+        o.peak_a_hold_signal = s.hold_a; o.peak_b_hold_signal = s.hold_b;
+        const float peakA = s.peak_a * intToFloatMultiplier, peakB = s.peak_b * intToFloatMultiplier;   // :385
+        o.peak_db_a = convert_to_dbfs(peakA); o.peak_db_b = convert_to_dbfs(peakB);                     // :386-387
+        o.combined_db = add_float_db(o.peak_db_a, o.peak_db_b);                                         // :394 / :406
+        o.hold_db_a = convert_to_dbfs(s.hold_a); o.hold_db_b = convert_to_dbfs(s.hold_b);               // :397-398
+        o.rms_a = s.frames > 0 ? sqrtf(s.sumsq_a / (float)s.frames) : 0.0f;
+        o.rms_b = s.frames > 0 ? sqrtf(s.sumsq_b / (float)s.frames) : 0.0f;
+    }
+    return ZLHIP_OK;
+}
+
+int zlhip_block_peaks(zlhip_engine *e, int32_t *out, size_t out_ints)
+{
+    if (!e || !out) return ZLHIP_ERR_INVALID;
+    const size_t n = (size_t)e->lastK * e->cfg.num_buses;
+    if (n == 0) return fail(e, ZLHIP_ERR_STATE, "no batch rendered yet");
+    if (out_ints < n * 2) return fail(e, ZLHIP_ERR_INVALID, "output buffer too small");
+    ZL_HIP(e, hipSetDevice(e->device));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    e->outstanding = false;
+    std::vector<ZlBlockLevels> tmp(n);
+    ZL_HIP(e, hipMemcpyAsync(tmp.data(), e->dLevels, n * sizeof(ZlBlockLevels), hipMemcpyDeviceToHost, e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < n; ++i) { out[2 * i] = tmp[i].peak_l; out[2 * i + 1] = tmp[i].peak_r; }
+    return ZLHIP_OK;
+}
+
+int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblocks, int32_t nframes, void *stream)
+{
+    if (!e || !bus_dev || nblocks < 1 || nblocks > e->cfg.max_batch_blocks || nframes < 64 || nframes > e->cfg.max_frames) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    ZlBatch A; std::memset(&A, 0, sizeof A);
+    A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.N = nframes; A.G = A.VPB; A.groups = 1;
+    A.levels = e->dLevels; A.bus = nullptr;
+    ZL_KERNEL(e, zl_launch_finalize(A, bus_dev, s));
+    if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->ev[4], s)); ZL_HIP(e, hipStreamWaitEvent(e->stream, e->ev[4], 0)); }
+    e->lastK = nblocks; e->lastN = nframes;
+    e->outstanding = true;
+    return ZLHIP_OK;
+}
+
+// ---- JackPassthrough ------------------------------------------------------------------------------
+void zlhip_passthrough_params_default(zlhip_passthrough_params *p)
+{
+    p->dry_amount = 1.0f; p->wet_fx1_amount = 1.0f; p->wet_fx2_amount = 1.0f; p->pan_amount = 0.0f; p->muted = 0;   // JackPassthrough.cpp:27-31
+}
+
+int zlhip_passthrough_process(zlhip_engine *e, const zlhip_passthrough_params *params, const float *in_dev, float *out_dev, int64_t frames, void *stream)
+{
+    if (!e || !params || !in_dev || !out_dev || frames < 1) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    std::vector<PassParamsDev> pp((size_t)e->cfg.num_buses);
+    for (int b = 0; b < e->cfg.num_buses; ++b)
+        pp[(size_t)b] = PassParamsDev{ params[b].dry_amount, params[b].wet_fx1_amount, params[b].wet_fx2_amount, params[b].pan_amount, params[b].muted };
+    ZL_HIP(e, hipMemcpyAsync(e->dPass, pp.data(), pp.size() * sizeof(PassParamsDev), hipMemcpyHostToDevice, s));
+    ZL_KERNEL(e, zl_launch_passthrough(e->dPass, in_dev, out_dev, e->cfg.num_buses, (long long)frames, s));
+    e->outstanding = true;
+    return ZLHIP_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------
+int zlhip_set_profiling(zlhip_engine *e, int enable)
+{
+    if (!e) return ZLHIP_ERR_INVALID;
+    e->profiling = enable != 0;
+    return ZLHIP_OK;
+}
+
+int zlhip_last_timings(zlhip_engine *e, zlhip_timings *out)
+{
+    if (!e || !out) return ZLHIP_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    ZL_HIP(e, hipSetDevice(e->device));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    e->outstanding = false;
+    if (e->profiling && e->lastK > 0) {
+        ZL_HIP(e, hipEventSynchronize(e->ev[3]));
+        ZL_HIP(e, hipEventElapsedTime(&out->plan_ms, e->ev[0], e->ev[1]));
+        ZL_HIP(e, hipEventElapsedTime(&out->render_ms, e->ev[1], e->ev[2]));
+        ZL_HIP(e, hipEventElapsedTime(&out->finalize_ms, e->ev[2], e->ev[3]));
+        ZL_HIP(e, hipEventElapsedTime(&out->total_ms, e->ev[0], e->ev[3]));
+    }
+    out->source_bytes = e->hStats->source_bytes;
+    out->slow_blocks = e->hStats->slow_blocks;
+    out->active_voice_frames = e->hStats->active_frames;
+    return ZLHIP_OK;
+}
+
+float *zlhip_bus_device_ptr(zlhip_engine *e) { return e ? e->dBus : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,386 @@
+// zl_plan.h -- K1 "control plan": the per-voice, per-block control state of
+// SamplerSynthVoice::process (reference lib/SamplerSynthVoice.cpp:174-270) advanced WITHOUT walking
+// every frame, bit-exactly.
+//
+// The reference advances `sourceSamplePosition += pitchRatio` (fp64) once per frame (:223).  While
+// P stays inside one binade and the exact sum P + r does not leave it, every such addition rounds
+// to the same multiple of ulp(P), so the recurrence is an exact arithmetic progression
+// P_n = P_0 + n*s with s = round_to_ulp(r) (ties handled by mantissa parity).  A (voice, block) is
+// therefore described by a handful of "linear segments" {first frame, P at that frame, s}; K2's
+// lanes evaluate fma(f - n0, s, P0), which is exact.  Segment boundaries are binade crossings
+// (performed with one real fp64 addition) and the loop / stop events of :225-257.
+// Blocks whose envelope is not in steady sustain (attack, decay, release tail of quirk Q7, note-off)
+// fall back to the per-frame simulation zl_sim_block(), which records (P, env) per frame for K2.
+//
+// Everything here is __host__ __device__ so the identical code is unit-tested on the CPU
+// (tests/cpu_harness) against the oracle; the product only ever runs it inside HIP kernels.
+#pragma once
+#include "zl_types.h"
+#include <math.h>
+#include <limits.h>
+
+#define ZL_INF_STEPS 0x7fffffff
+#define ZL_RUN_CAP   0x3fffffff
+
+ZL_HD inline uint64_t zl_bits(double d) { return __builtin_bit_cast(uint64_t, d); }
+ZL_HD inline double   zl_from_bits(uint64_t u) { return __builtin_bit_cast(double, u); }
+
+// float -> quint64 as on the reference's aarch64 target (fcvtzu): saturating, NaN -> 0
+ZL_HD inline uint64_t zl_f32_to_u64_sat(float f)
+{
+    if (!(f > 0.0f)) return 0;
+    if (f >= 18446744073709551616.0f) return ~0ull;
+    return (uint64_t)f;
+}
+ZL_HD inline uint64_t zl_f64_to_u64_sat(double f)
+{
+    if (!(f > 0.0)) return 0;
+    if (f >= 18446744073709551616.0) return ~0ull;
+    return (uint64_t)f;
+}
+
+// ---- ClipAudioSource getters (ClipAudioSource.cpp:261-277) -----------------------------------
+ZL_HD inline float zl_clip_start(const ZlClip &c, int slice)
+{
+    if (slice > -1 && slice < c.n_slice_pos)
+        return (float)((double)c.start_sec + ((double)c.length_sec * c.slice_pos[slice]));
+    return c.start_sec;
+}
+ZL_HD inline float zl_clip_stop(const ZlClip &c, int slice)
+{
+    if (slice > -1 && slice + 1 < c.n_slice_pos)
+        return (float)((double)c.start_sec + ((double)c.length_sec * c.slice_pos[slice + 1]));
+    return c.start_sec + c.length_sec;
+}
+
+// ---- juce::ADSR on the voice record ----------------------------------------------------------
+ZL_HD inline void zl_adsr_reset(ZlVoiceState &s) { s.env = 0.0f; s.adsr_state = ZL_ADSR_IDLE; }
+
+ZL_HD inline void zl_adsr_note_off(ZlVoiceState &s)
+{
+    if (s.adsr_state != ZL_ADSR_IDLE) {
+        if (s.release > 0.0f) {
+            s.release_rate = (float)((double)s.env / ((double)s.release * s.adsr_sr));
+            s.adsr_state = ZL_ADSR_RELEASE;
+        } else {
+            zl_adsr_reset(s);
+        }
+    }
+}
+
+ZL_HD inline float zl_adsr_next(ZlVoiceState &s)
+{
+    switch (s.adsr_state) {
+    case ZL_ADSR_IDLE:
+        return 0.0f;
+    case ZL_ADSR_ATTACK:
+        s.env += s.attack_rate;
+        if (s.env >= 1.0f) { s.env = 1.0f; s.adsr_state = (s.decay_rate > 0.0f ? ZL_ADSR_DECAY : ZL_ADSR_SUSTAIN); }
+        break;
+    case ZL_ADSR_DECAY:
+        s.env -= s.decay_rate;
+        if (s.env <= s.sustain) { s.env = s.sustain; s.adsr_state = ZL_ADSR_SUSTAIN; }
+        break;
+    case ZL_ADSR_SUSTAIN:
+        s.env = s.sustain;
+        break;
+    case ZL_ADSR_RELEASE:
+        s.env -= s.release_rate;
+        if (s.env <= 0.0f) zl_adsr_reset(s);
+        break;
+    }
+    return s.env;
+}
+
+// stopNote(velocity, false), SamplerSynthVoice.cpp:153-168
+ZL_HD inline void zl_voice_hard_stop(ZlVoiceState &s)
+{
+    zl_adsr_reset(s);
+    s.clip = -1;
+    s.playing = 0;
+    s.next_loop_tick = 0;
+    s.next_loop_usecs = 0;
+}
+
+// ---- exact linear runs of P += r --------------------------------------------------------------
+// Returns the per-step increment s and the number L >= 0 of consecutive additions starting at P
+// that are guaranteed to equal P + i*s exactly (i = 1..L).  L == 0 means "take one real addition".
+ZL_HD inline void zl_linear_run(double P, double r, double &s, int &L)
+{
+    s = 0.0; L = 0;
+    const uint64_t pb = zl_bits(P);
+    const int ex = (int)((pb >> 52) & 0x7ff);
+    if ((pb >> 63) || ex <= 53 || ex >= 0x7fd) return;           // zero / tiny / huge / negative: step for real
+    const double u   = zl_from_bits((uint64_t)(ex - 52) << 52);  // ulp(P) = 2^(e-52)
+    const double top = zl_from_bits((uint64_t)(ex + 1) << 52);   // 2^(e+1)
+    if (!(r > 0.0)) return;
+    const double rq = r / u;                                     // exact power-of-two scaling (or +inf)
+    const double q  = floor(rq);
+    if (!(q < 9007199254740992.0)) return;                       // r >= 2^53 ulps: leaves the binade at once
+    const double rho  = r - q * u;                               // r mod u, exact
+    const double half = 0.5 * u;
+    double c;
+    if (rho > half) c = 1.0;
+    else if (rho < half) c = 0.0;
+    else {                                                       // tie: round-half-even on the mantissa
+        if (pb & 1ull) return;                                   // odd mantissa: one real step makes it even
+        c = (((long long)q) & 1ll) ? 1.0 : 0.0;                  // even mantissa stays even from here on
+    }
+    const double sq = q + c;                                     // step in ulps
+    s = sq * u;                                                  // exact
+    if (sq <= 0.0) { L = ZL_RUN_CAP; return; }                   // r < ulp/2: P never moves
+    // step i (0-based) starts at mantissa m0 + i*sq and must satisfy m + q + 1 <= 2^53 so the exact
+    // sum stays inside [2^e, 2^(e+1)] where the spacing is u
+    const double a = (top - P) - (q + 1.0) * u;                  // exact
+    if (a < 0.0) { s = 0.0; return; }
+    const double cnt = floor((a / s) * (1.0 - 0x1p-40)) + 1.0;   // conservative count
+    L = cnt > (double)ZL_RUN_CAP ? ZL_RUN_CAP : (int)cnt;
+}
+
+// Smallest i in [1, L] with P + i*s >= X (values are exact), or ZL_INF_STEPS.
+ZL_HD inline int zl_steps_to_reach(double P, double s, int L, double X)
+{
+    if (L < 1) return ZL_INF_STEPS;
+    if (!(fma((double)L, s, P) >= X)) return ZL_INF_STEPS;
+    if (P + s >= X) return 1;
+    double g = ceil((X - P) / s);
+    if (!(g >= 1.0)) g = 1.0;
+    if (g > (double)L) g = (double)L;
+    int i = (int)g;
+    while (i > 1 && fma((double)(i - 1), s, P) >= X) --i;
+    while (i < L && fma((double)i, s, P) < X) ++i;
+    return i;
+}
+
+// First frame f in [n, N) after whose rendering the beat-locked loop test of
+// SamplerSynthVoice.cpp:232 fires: current_usecs + (u64)(f * usecsPerFrame) >= nextLoopUsecs.
+// Returns N if it does not fire in this block.  Requires usecs_per_frame < 2^21 (caller checks).
+ZL_HD inline int zl_clock_event_frame(const ZlClock &ck, uint64_t next_loop_usecs, int n, int N)
+{
+    const uint64_t U = ck.usecs_per_frame;
+    if (ck.current_usecs + (uint64_t)n * U >= next_loop_usecs) return n;
+    if (U == 0) return N;
+    if (ck.current_usecs + (uint64_t)(N - 1) * U < next_loop_usecs) return N;
+    const uint64_t D = next_loop_usecs - ck.current_usecs;
+    const uint64_t f = (D + U - 1) / U;
+    return f < (uint64_t)N ? (int)f : N;
+}
+
+struct ZlVoiceBatchConst {
+    int      start_int;       // (int)(getStartPosition(slice) * sourceSampleRate), :241/:246
+    int      stop_pos;        // SamplerSynthSound::stopPosition(slice), :190
+    double   tail_T;          // stopPosition - release * sourceSampleRate, :253
+    uint64_t length_ticks;    // (quint64)(lengthInBeats * multiplier), :234
+    int      beat_locked;     // trunc(lengthInBeats) == lengthInBeats, :227
+    int      clock_ok;        // usecs-per-frame small enough for the exact integer clock test
+};
+
+ZL_HD inline void zl_loop_restart(ZlVoiceState &st, const ZlVoiceBatchConst &c, const ZlClock &ck, bool clockMode)
+{
+    if (clockMode) {                                             // :234-237
+        st.next_loop_tick = st.next_loop_tick + c.length_ticks;
+        st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
+    }
+    st.P = (double)c.start_int;                                  // :241 / :246
+}
+
+// Per-frame simulation of one block (the reference loop minus the audio arithmetic).  Records
+// (P, env) of every rendered frame; returns the number of frames rendered.
+ZL_HD inline int zl_sim_block(ZlVoiceState &st, const ZlVoiceBatchConst &c, const ZlClock &ck, int N,
+                              double *ctlP, float *ctlEnv)
+{
+    const double upf = (double)ck.usecs_per_frame;               // :183
+    int frame = 0;
+    for (; frame < N; ++frame) {
+        ctlP[frame] = st.P;
+        ctlEnv[frame] = zl_adsr_next(st);                        // :201
+        st.P += st.pitch_ratio;                                  // :223
+        if (st.looping) {
+            if (c.beat_locked) {
+                if (ck.current_usecs + zl_f64_to_u64_sat((double)(uint32_t)frame * upf) >= st.next_loop_usecs)   // :232
+                    zl_loop_restart(st, c, ck, true);
+            } else if (st.P >= (double)c.stop_pos) {             // :243
+                zl_loop_restart(st, c, ck, false);
+            }
+        } else {
+            if (st.P >= (double)c.stop_pos) {                    // :249-252
+                zl_voice_hard_stop(st);
+                return frame + 1;
+            } else if (st.P >= c.tail_T) {                       // :253-256 (Q7: every frame)
+                zl_adsr_note_off(st);
+            }
+        }
+        if (st.adsr_state == ZL_ADSR_IDLE) {                     // :258-261
+            zl_voice_hard_stop(st);
+            return frame + 1;
+        }
+    }
+    return N;
+}
+
+struct ZlPlanStats { unsigned long long source_bytes, slow_blocks, active_frames; };
+
+// Plans every block of the batch for voice v and leaves the voice state as the reference would
+// after rendering them.  force_slow routes every block through zl_sim_block (test hook).
+ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanStats &stats)
+{
+    const int K = A.K, N = A.N, V = A.V;
+    ZlVoiceState st = A.voices[v];
+    ZlReport rep;
+    rep.playing = 0; rep.valid = 0; rep.peak_bits = 0; rep.progress = 0.0f; rep.clip = -1; rep.pad = 0; rep.P = st.P;
+    stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
+
+    int k = 0;
+    if (st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0) {
+        const ZlClip &cl = A.clips[st.clip];
+        const ZlSound sd = A.sounds[st.clip];
+        const double sr = sd.sample_rate;
+        ZlVoiceBatchConst c;
+        c.start_int = (int)(zl_clip_start(cl, st.slice) * sr);
+        c.stop_pos  = (int)(zl_clip_stop(cl, st.slice) * sr);
+        c.tail_T    = (double)c.stop_pos - ((double)st.release * sr);
+        c.length_ticks = zl_f32_to_u64_sat(cl.length_beats * (float)ZL_BEAT_SUBDIV);
+        c.beat_locked = truncf(cl.length_beats) == cl.length_beats;
+
+        ZlVoiceConst vc;
+        vc.src_offset = sd.offset;
+        vc.sample_duration = sd.length - 1;                       // :191
+        vc.channels = sd.channels;
+        vc.lgain = st.lgain; vc.rgain = st.rgain;
+        vc.clip_volume = cl.volume_abs;                           // :189
+        vc.lpan = (float)(0.5 * (1.0 + (double)cl.pan));          // :193
+        vc.rpan = (float)(0.5 * (1.0 - (double)cl.pan));          // :194
+        vc.pad = 0;
+        A.vconst[v] = vc;
+
+        // algorithmic source bytes of one block of this voice
+        const int taps = (A.mode & ZL_MODE_HERMITE) ? 4 : 2;
+        const unsigned long long blockBytes =
+            (unsigned long long)((long long)ceil((double)N * st.pitch_ratio) + taps - 1) * (unsigned long long)sd.channels * 4ull;
+
+        const bool posLoop  = st.looping && !c.beat_locked;
+        const bool clockMode = st.looping && c.beat_locked;
+        const bool oneShot  = !st.looping;
+        // threshold of the position event that can occur in a fast (sustain) block
+        const double X = posLoop ? (double)c.stop_pos
+                       : (oneShot ? ((st.release > 0.0f) ? c.tail_T : (double)c.stop_pos) : INFINITY);
+        const bool posMode = posLoop || oneShot;
+
+        double s = 0.0; int L = 0; int ie = ZL_INF_STEPS; bool haveRun = false;
+
+        for (; k < K && st.playing; ++k) {
+            const ZlClock ck = A.clocks[k];
+            const size_t pidx = (size_t)k * V + v;
+            ZlBlockPlan pl;
+            pl.flags = ZL_PLAN_ACTIVE; pl.n_active = N; pl.nseg = 0; pl.env = st.sustain; pl.P0 = st.P; pl.step = 0.0;
+
+            if (st.next_loop_usecs == 0)                          // :179-182
+                st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
+
+            bool slow = force_slow || st.adsr_state != ZL_ADSR_SUSTAIN
+                        || (clockMode && ck.usecs_per_frame >= (1ull << 21));
+            if (!slow) {
+                // ---- fast block: linear segments ----
+                const ZlVoiceState st0 = st;
+                const double s0 = s; const int L0 = L, ie0 = ie; const bool haveRun0 = haveRun;
+                ZlSegment *segs = A.segs + pidx * (ZL_MAXSEG - 1);
+                int n = 0, nseg = 0;
+                while (n < N) {
+                    if (!haveRun) {
+                        zl_linear_run(st.P, st.pitch_ratio, s, L);
+                        haveRun = true;
+                        ie = posMode ? zl_steps_to_reach(st.P, s, L, X) : ZL_INF_STEPS;
+                    }
+                    if (nseg >= ZL_MAXSEG) { slow = true; break; }
+                    if (nseg == 0) { pl.P0 = st.P; pl.step = s; }
+                    else { ZlSegment sg; sg.P0 = st.P; sg.step = s; sg.n0 = n; sg.pad = 0; segs[nseg - 1] = sg; }
+                    ++nseg;
+                    if (L == 0) {
+                        // one real addition from frame n
+                        const double Pn = st.P + st.pitch_ratio;
+                        const bool ev = posMode ? (Pn >= X)
+                                                : (clockMode ? (zl_clock_event_frame(ck, st.next_loop_usecs, n, N) == n) : false);
+                        n += 1;
+                        haveRun = false;
+                        if (!ev) { st.P = Pn; continue; }
+                    } else {
+                        const int room = N - n;
+                        const int m = L < room ? L : room;
+                        int iclk = ZL_INF_STEPS;
+                        if (clockMode) {
+                            const int fa = zl_clock_event_frame(ck, st.next_loop_usecs, n, N);
+                            if (fa < N) iclk = fa - n + 1;
+                        }
+                        const int iev = ie < iclk ? ie : iclk;
+                        if (iev > m) {
+                            st.P = fma((double)m, s, st.P);
+                            n += m; L -= m;
+                            if (ie != ZL_INF_STEPS) ie -= m;
+                            if (L == 0) haveRun = false;
+                            continue;
+                        }
+                        n += iev;
+                        haveRun = false;
+                    }
+                    // ---- event after rendering frame n-1 ----
+                    if (st.looping) {
+                        zl_loop_restart(st, c, ck, clockMode);
+                    } else if (st.release > 0.0f) {
+                        slow = true;                               // release tail starts inside this block (Q7)
+                        break;
+                    } else {
+                        pl.n_active = n;                           // :249-252, voice ends after frame n-1
+                        zl_voice_hard_stop(st);
+                        break;
+                    }
+                }
+                if (slow) {
+                    st = st0; s = s0; L = L0; ie = ie0; haveRun = haveRun0;
+                } else {
+                    pl.nseg = nseg;
+                    if (st.playing) st.env = st.sustain;           // the sustain branch assigns envelopeVal every frame
+                }
+            }
+            if (slow) {
+                pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW;
+                pl.nseg = 0;
+                pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
+                haveRun = false;
+                stats.slow_blocks += 1;
+            }
+            A.plans[pidx] = pl;
+            stats.source_bytes += blockBytes;
+            stats.active_frames += (unsigned long long)pl.n_active;
+        }
+        // :265-267 -- the report of the last block exists only if the voice still has its clip
+        if (k == K && st.playing) {
+            rep.valid = 1;
+            rep.progress = (float)(st.P / st.src_len);
+        }
+    }
+    for (; k < K; ++k) {
+        ZlBlockPlan pl; pl.flags = 0; pl.n_active = 0; pl.nseg = 0; pl.env = 0.0f; pl.P0 = 0.0; pl.step = 0.0;
+        A.plans[(size_t)k * V + v] = pl;
+    }
+    rep.playing = st.playing;
+    rep.clip = st.clip;
+    rep.P = st.P;
+    A.reports[v] = rep;
+    A.voices[v] = st;
+}
+
+// ---- voice operations (device half of SamplerChannel::handleCommand, SamplerSynth.cpp:187-230) --
+ZL_HD inline void zl_apply_op(ZlVoiceState &st, const ZlVoiceOp &op)
+{
+    if (op.kind == ZL_OP_START) {
+        st = op.start;                                            // startNote :110-144 computed by the host
+    } else if (op.kind == ZL_OP_NOTE_OFF) {
+        if (st.playing) zl_adsr_note_off(st);                     // stopNote(0, true) :148-151
+    } else if (op.kind == ZL_OP_PATCH) {                          // setCurrentCommand merge :58-98
+        if (!st.playing) return;
+        if (op.patch_mask & ZL_PATCH_LOOPING)  st.looping = op.looping;
+        if (op.patch_mask & ZL_PATCH_GAIN)     { st.lgain = op.gain; st.rgain = op.gain; }
+        if (op.patch_mask & ZL_PATCH_SLICE)    st.slice = op.slice;
+        if (op.patch_mask & ZL_PATCH_POSITION) st.P = op.position;
+    }
+}

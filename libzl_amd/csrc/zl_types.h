@@ -1,0 +1,157 @@
+// zl_types.h -- POD records shared by the host engine and the HIP kernels (HBM layout).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ZL_HD __host__ __device__
+#else
+#define ZL_HD
+#endif
+
+#define ZL_MAXSEG        16     // linear position segments per (voice, block) before the per-frame path is used
+#define ZL_MAX_SLICES    128
+#define ZL_BEAT_SUBDIV   96
+
+// juce::ADSR states (restated; see oracle/zl_oracle.h for the JUCE citation)
+enum { ZL_ADSR_IDLE = 0, ZL_ADSR_ATTACK = 1, ZL_ADSR_DECAY = 2, ZL_ADSR_SUSTAIN = 3, ZL_ADSR_RELEASE = 4 };
+
+// mode flags (mirror ZLHIP_MODE_*)
+enum { ZL_MODE_FIX_GAIN = 1u, ZL_MODE_FIX_DELAY = 2u, ZL_MODE_HERMITE = 4u };
+
+// One block's clock (zlhip_clock + the derived integer microseconds-per-frame of
+// SamplerSynthVoice.cpp:183, which is block-constant and computed once on the host).
+struct ZlClock {
+    uint64_t current_usecs, next_usecs;
+    uint64_t playhead, playhead_usecs, subbeat_usecs;
+    uint64_t usecs_per_frame;     // (next_usecs - current_usecs) / nframes, integer division
+};
+
+// Decoded source in the HBM arena.  Stereo sources are stored INTERLEAVED [L0 R0 L1 R1 ...] so
+// the two interpolation taps of both channels are one 16-byte load; mono sources are [x0 x1 ...].
+struct ZlSound {
+    uint64_t offset;              // float index into the arena (16-byte aligned)
+    int32_t  length;              // frames
+    int32_t  channels;            // 1 or 2; 0 = slot free / invalid
+    double   sample_rate;
+};
+
+// ClipAudioSource fields the voice reads (ClipAudioSource.cpp:63-82), device copy.
+struct ZlClip {
+    float   start_sec, length_sec, length_beats, volume_abs, pan, duration;
+    int32_t n_slice_pos;
+    int32_t pad;
+    double  slice_pos[ZL_MAX_SLICES];
+};
+
+// SamplerSynthVoicePrivate + juce::ADSR state (SamplerSynthVoice.cpp:20-39), device resident.
+struct ZlVoiceState {
+    double   P;                   // sourceSamplePosition
+    double   pitch_ratio;
+    double   src_len;             // sourceSampleLength
+    double   adsr_sr;             // ADSR sample rate (= source sample rate, quirk Q8)
+    uint64_t next_loop_tick, next_loop_usecs;
+    float    lgain, rgain;
+    float    env;
+    int32_t  adsr_state;
+    float    attack_rate, decay_rate, release_rate;
+    float    sustain, release;    // ADSR parameters still needed after noteOn
+    int32_t  clip;                // clip == sound id; -1 none
+    int32_t  slice;
+    int32_t  looping;
+    int32_t  playing;             // isPlaying && clipCommand != nullptr
+    int32_t  pad;
+};
+
+// Host -> device voice operations, applied in order before the next block is planned.
+enum { ZL_OP_START = 1, ZL_OP_NOTE_OFF = 2, ZL_OP_PATCH = 3 };
+enum { ZL_PATCH_GAIN = 1, ZL_PATCH_LOOPING = 2, ZL_PATCH_SLICE = 4, ZL_PATCH_POSITION = 8 };
+struct ZlVoiceOp {
+    int32_t  voice;
+    int32_t  kind;
+    int32_t  patch_mask;
+    int32_t  looping;
+    int32_t  slice;
+    float    gain;
+    double   position;
+    ZlVoiceState start;           // full post-startNote state for ZL_OP_START
+};
+struct ZlOpRange { int32_t voice, first, count, pad; };
+
+// ---- K1 -> K2 records -------------------------------------------------------------------------
+struct ZlVoiceConst {             // per voice, constant over a batch
+    uint64_t src_offset;
+    int32_t  sample_duration;     // length - 1 (SamplerSynthVoice.cpp:191)
+    int32_t  channels;
+    float    lgain, rgain, clip_volume, lpan, rpan;
+    int32_t  pad;
+};
+
+enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2 };
+struct ZlBlockPlan {              // per (block, voice); first linear segment inline
+    int32_t flags;
+    int32_t n_active;             // frames rendered in this block (N unless the voice stopped inside it)
+    int32_t nseg;                 // >= 1 for fast blocks; extra segments live in the side array
+    float   env;                  // envelope value of every frame of a fast block (sustain)
+    double  P0;                   // position of frame 0
+    double  step;                 // exact per-frame increment inside the segment
+};
+struct ZlSegment {                // extra segments [block][voice][ZL_MAXSEG-1]
+    double  P0;
+    double  step;
+    int32_t n0;                   // first frame of the segment
+    int32_t pad;
+};
+
+struct ZlReport {                 // device side of zlhip_voice_report
+    int32_t playing, valid;
+    uint32_t peak_bits;           // max over the last block of (l'+r'), as float bits (>= 0)
+    float   progress;
+    int32_t clip, pad;
+    double  P;
+};
+
+struct ZlBlockLevels {            // per (block, bus)
+    int32_t peak_l, peak_r;       // max over the block of (int)|131072*x|
+    float   sumsq_l, sumsq_r;     // sum of squares (RMS extension)
+};
+
+struct ZlLevelsState {            // AudioLevelsChannel meter state per bus
+    int32_t peak_a, peak_b;
+    float   hold_a, hold_b;
+    float   sumsq_a, sumsq_b;
+    int32_t frames, pad;
+};
+
+struct ZlBatchStats {
+    unsigned long long source_bytes;
+    unsigned long long slow_blocks;
+    unsigned long long active_frames;
+};
+
+// Launch-wide arguments (passed by value to the kernels).
+struct ZlBatch {
+    int32_t V, B, VPB, K, N;      // voices, buses, voices per bus, blocks, frames per block
+    int32_t G;                    // voices per render task (mix group); groups per bus = ceil(VPB / G)
+    int32_t groups;
+    uint32_t mode;
+    int32_t n_op_ranges;
+    int32_t trace;                // 1 = write pos trace
+    const ZlClock      *clocks;   // [K]
+    const ZlSound      *sounds;
+    const ZlClip       *clips;
+    const float        *arena;
+    ZlVoiceState       *voices;   // [V]
+    const ZlVoiceOp    *ops;
+    const ZlOpRange    *op_ranges;
+    ZlVoiceConst       *vconst;   // [V]
+    ZlBlockPlan        *plans;    // [K][V]
+    ZlSegment          *segs;     // [K][V][ZL_MAXSEG-1]
+    double             *ctl_P;    // [K][V][N]   per-frame control of slow blocks
+    float              *ctl_env;  // [K][V][N]
+    ZlReport           *reports;  // [V]
+    float              *partials; // [K][B][groups][2][N]  (only when groups > 1)
+    float              *bus;      // [B][2][K*N]
+    ZlBlockLevels      *levels;   // [K][B]
+    int32_t            *pos_trace;// [K][V][N] or null
+    ZlBatchStats       *stats;
+};

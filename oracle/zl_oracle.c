@@ -1,0 +1,769 @@
+/*
+ * zl_oracle.c -- CPU restatement of libzl's sampler hot path.  TEST INFRASTRUCTURE ONLY.
+ * See zl_oracle.h for the parity status ("parity unpinned") and who may use this file.
+ * References are file:line under /root/reference/lib unless stated.
+ */
+#include "zl_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* float -> quint64 as the reference's target (aarch64 fcvtzu) performs it: saturating, NaN -> 0.
+ * On x86-64 a negative float -> unsigned conversion is undefined; the reference only reaches it
+ * with lengthInBeats = -1 (quirk Q10, invalid input). */
+static uint64_t f32_to_u64_sat(float f)
+{
+    if (!(f > 0.0f)) return 0;                       /* negatives, -0, NaN */
+    if (f >= 18446744073709551616.0f) return UINT64_MAX;
+    return (uint64_t)f;
+}
+static uint64_t f64_to_u64_sat(double f)
+{
+    if (!(f > 0.0)) return 0;
+    if (f >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)f;
+}
+
+/* =============================== juce::ADSR ================================================== */
+
+void zlo_adsr_default_params(zlo_adsr_params *p)
+{
+    p->attack = 0.1f; p->decay = 0.1f; p->sustain = 1.0f; p->release = 0.1f;   /* juce::ADSR::Parameters defaults */
+}
+
+static void adsr_go_to_next_state(zlo_adsr *a)
+{
+    if (a->state == ZLO_ADSR_ATTACK) { a->state = (a->decayRate > 0.0f ? ZLO_ADSR_DECAY : ZLO_ADSR_SUSTAIN); return; }
+    if (a->state == ZLO_ADSR_DECAY)  { a->state = ZLO_ADSR_SUSTAIN; return; }
+    if (a->state == ZLO_ADSR_RELEASE) zlo_adsr_reset(a);
+}
+
+static float adsr_get_rate(float distance, float timeInSeconds, double sr)
+{
+    return timeInSeconds > 0.0f ? (float)(distance / (timeInSeconds * sr)) : -1.0f;
+}
+
+static void adsr_recalculate_rates(zlo_adsr *a)
+{
+    a->attackRate  = adsr_get_rate(1.0f, a->p.attack, a->sampleRate);
+    a->decayRate   = adsr_get_rate(1.0f - a->p.sustain, a->p.decay, a->sampleRate);
+    a->releaseRate = adsr_get_rate(a->p.sustain, a->p.release, a->sampleRate);
+    if ((a->state == ZLO_ADSR_ATTACK && a->attackRate <= 0.0f)
+        || (a->state == ZLO_ADSR_DECAY && (a->decayRate <= 0.0f || a->env <= a->p.sustain))
+        || (a->state == ZLO_ADSR_RELEASE && a->releaseRate <= 0.0f))
+        adsr_go_to_next_state(a);
+}
+
+void zlo_adsr_init(zlo_adsr *a)
+{
+    memset(a, 0, sizeof *a);
+    zlo_adsr_default_params(&a->p);
+    a->sampleRate = 44100.0;
+    a->state = ZLO_ADSR_IDLE;
+    a->env = 0.0f;
+    adsr_recalculate_rates(a);
+}
+
+void zlo_adsr_set_sample_rate(zlo_adsr *a, double sr) { a->sampleRate = sr; }
+
+void zlo_adsr_set_parameters(zlo_adsr *a, const zlo_adsr_params *p)
+{
+    a->p = *p;
+    adsr_recalculate_rates(a);
+}
+
+void zlo_adsr_reset(zlo_adsr *a) { a->env = 0.0f; a->state = ZLO_ADSR_IDLE; }
+
+void zlo_adsr_note_on(zlo_adsr *a)
+{
+    if (a->attackRate > 0.0f)      { a->state = ZLO_ADSR_ATTACK; }
+    else if (a->decayRate > 0.0f)  { a->env = 1.0f; a->state = ZLO_ADSR_DECAY; }
+    else                           { a->env = a->p.sustain; a->state = ZLO_ADSR_SUSTAIN; }
+}
+
+void zlo_adsr_note_off(zlo_adsr *a)
+{
+    if (a->state != ZLO_ADSR_IDLE) {
+        if (a->p.release > 0.0f) {
+            a->releaseRate = (float)(a->env / (a->p.release * a->sampleRate));
+            a->state = ZLO_ADSR_RELEASE;
+        } else {
+            zlo_adsr_reset(a);
+        }
+    }
+}
+
+float zlo_adsr_next(zlo_adsr *a)
+{
+    switch (a->state) {
+    case ZLO_ADSR_IDLE:
+        return 0.0f;
+    case ZLO_ADSR_ATTACK:
+        a->env += a->attackRate;
+        if (a->env >= 1.0f) { a->env = 1.0f; adsr_go_to_next_state(a); }
+        break;
+    case ZLO_ADSR_DECAY:
+        a->env -= a->decayRate;
+        if (a->env <= a->p.sustain) { a->env = a->p.sustain; adsr_go_to_next_state(a); }
+        break;
+    case ZLO_ADSR_SUSTAIN:
+        a->env = a->p.sustain;
+        break;
+    case ZLO_ADSR_RELEASE:
+        a->env -= a->releaseRate;
+        if (a->env <= 0.0f) adsr_go_to_next_state(a);
+        break;
+    }
+    return a->env;
+}
+
+int zlo_adsr_is_active(const zlo_adsr *a) { return a->state != ZLO_ADSR_IDLE; }
+
+/* =============================== positions model ============================================= */
+
+void zlo_positions_init(zlo_positions *m)
+{
+    for (int i = 0; i < ZLO_POSITION_COUNT; ++i) {       /* ClipAudioSourcePositionsModel.cpp:7-12,17-21 */
+        m->pos[i].id = -1; m->pos[i].progress = 0.0f; m->pos[i].gain = 0.0f; m->pos[i].lastUpdated = 0;
+    }
+    m->updatePeakGain = 0;
+    m->peakGain = 0.0f;
+}
+
+int zlo_positions_cleanup(zlo_positions *m, int64_t now_ms)      /* :191-209 */
+{
+    const int64_t allowedTime = now_ms - 1000;
+    int removed = 0;
+    for (int i = 0; i < ZLO_POSITION_COUNT; ++i) {
+        zlo_position *p = &m->pos[i];
+        if (p->id > -1 && p->lastUpdated < allowedTime) {
+            p->id = -1; p->gain = 0.0f; p->progress = 0.0f; ++removed;
+        }
+    }
+    return removed;
+}
+
+int64_t zlo_positions_create(zlo_positions *m, float initialProgress, int64_t now_ms)   /* :78-100 */
+{
+    zlo_position *position = NULL;
+    int positionRow = -1;
+    for (int i = 0; i < ZLO_POSITION_COUNT; ++i) {
+        ++positionRow;
+        if (m->pos[i].id == -1) { position = &m->pos[i]; break; }
+    }
+    if (position) {
+        position->id = positionRow;
+        position->progress = initialProgress;
+        position->lastUpdated = now_ms;
+        m->updatePeakGain = 1;
+        zlo_positions_cleanup(m, now_ms);
+    }
+    /* Reference quirk: when all 32 rows are taken the loop ends with positionRow == 31 and no
+     * position; 31 is returned although that row belongs to another voice (:82-99). */
+    return positionRow;
+}
+
+void zlo_positions_set_gain_and_progress(zlo_positions *m, int64_t id, float gain, float progress, int64_t now_ms) /* :126-138 */
+{
+    if (id > -1 && id < ZLO_POSITION_COUNT) {
+        zlo_position *p = &m->pos[id];
+        p->gain = gain; p->progress = progress; p->lastUpdated = now_ms;
+        m->updatePeakGain = 1;
+    }
+}
+
+void zlo_positions_remove(zlo_positions *m, int64_t id, int64_t now_ms)   /* :140-153 */
+{
+    if (id > -1 && id < ZLO_POSITION_COUNT) {
+        zlo_position *p = &m->pos[id];
+        p->id = -1; p->gain = 0.0f; p->progress = 0.0f;
+        m->updatePeakGain = 1;
+    }
+    zlo_positions_cleanup(m, now_ms);
+}
+
+float zlo_positions_peak_gain(zlo_positions *m)                     /* :160-173 */
+{
+    if (m->updatePeakGain) {
+        float peak = 0.0f;
+        for (int i = 0; i < ZLO_POSITION_COUNT; ++i) peak = peak > m->pos[i].gain ? peak : m->pos[i].gain;
+        /* abs(float) > 0.01 : the int abs() overload is not viable for a float argument in C++,
+         * so this is fabs in double against the double literal 0.01 */
+        if (fabs((double)(m->peakGain - peak)) > 0.01) m->peakGain = peak;
+        m->updatePeakGain = 0;
+    }
+    return m->peakGain;
+}
+
+double zlo_positions_first_progress(const zlo_positions *m)         /* :175-185 */
+{
+    double progress = -1.0;
+    for (int i = 0; i < ZLO_POSITION_COUNT; ++i)
+        if (m->pos[i].id > -1) { progress = m->pos[i].progress; break; }
+    return progress;
+}
+
+/* =============================== ClipAudioSource parameters ================================== */
+
+float zlo_subbeat_count_to_seconds(uint64_t bpm, uint64_t subbeats)   /* SyncTimer.cpp:180-183,936-939 */
+{
+    if (bpm < 50) bpm = 50;                 /* qBound(BPM_MINIMUM, bpm, BPM_MAXIMUM), SyncTimer.cpp:28-29 */
+    if (bpm > 200) bpm = 200;
+    const uint64_t ns = (subbeats * 60000000000ULL) / (bpm * (uint64_t)ZLO_BEAT_SUBDIVISIONS);
+    return ns / (float)1000000000;          /* quint64 -> float, float division */
+}
+
+void zlo_clip_init(zlo_clip *c, float durationSeconds, double sourceSampleRate)
+{
+    memset(c, 0, sizeof *c);
+    c->startPositionInSeconds = 0;          /* ClipAudioSource.cpp:63 */
+    c->lengthInSeconds = durationSeconds;   /* :64 then :158 lengthInSeconds = edit->getLength() */
+    c->lengthInBeats = -1;                  /* :65 */
+    c->volumeAbsolute = 1.0f;               /* :66 cached fader position; build input, 1.0 = unity */
+    c->pan = 0.0f;                          /* :69 */
+    c->duration = durationSeconds;          /* :367 */
+    c->rootNote = 60;                       /* :81 */
+    c->sliceBaseMidiNote = 60;              /* :78 */
+    c->keyZoneStart = 0; c->keyZoneEnd = 127;   /* :79-80 */
+    c->slices = 0; c->nSlicePositions = 0;
+    zlo_adsr_init(&c->adsr);
+    {                                       /* :164-168 : default Parameters with attack 0, release .05 */
+        zlo_adsr_params p; zlo_adsr_default_params(&p);
+        p.attack = 0.0f; p.release = 0.05f;
+        zlo_adsr_set_sample_rate(&c->adsr, sourceSampleRate);
+        zlo_adsr_set_parameters(&c->adsr, &p);
+    }
+    zlo_positions_init(&c->positions);
+    zlo_clip_set_slices(c, 16);             /* :204 */
+}
+
+float zlo_clip_get_start_position(const zlo_clip *c, int slice)      /* :261-268 */
+{
+    if (slice > -1 && slice < c->nSlicePositions)
+        return (float)(c->startPositionInSeconds + (c->lengthInSeconds * c->slicePositions[slice]));
+    return c->startPositionInSeconds;
+}
+
+float zlo_clip_get_stop_position(const zlo_clip *c, int slice)       /* :270-277 */
+{
+    if (slice > -1 && slice + 1 < c->nSlicePositions)
+        return (float)(c->startPositionInSeconds + (c->lengthInSeconds * c->slicePositions[slice + 1]));
+    return c->startPositionInSeconds + c->lengthInSeconds;
+}
+
+void zlo_clip_set_start_position(zlo_clip *c, float s)               /* :255-259 */
+{
+    c->startPositionInSeconds = s > 0.0f ? s : 0.0f;   /* jmax(0.0f, s) */
+}
+
+void zlo_clip_set_length(zlo_clip *c, float beat, int bpm)           /* :352-360 */
+{
+    c->lengthInSeconds = zlo_subbeat_count_to_seconds((uint64_t)bpm, f32_to_u64_sat(beat * (float)ZLO_BEAT_SUBDIVISIONS));
+    c->lengthInBeats = beat;
+}
+
+void zlo_clip_set_volume_absolute(zlo_clip *c, float vol)            /* :328-336 (clamp; fader readback taken as identity) */
+{
+    const float lo = vol < 1.0f ? vol : 1.0f;      /* qMin(vol, 1.0f) */
+    c->volumeAbsolute = 0.0f > lo ? 0.0f : lo;     /* qMax(0.0f, ...) */
+}
+
+void zlo_clip_set_pan(zlo_clip *c, float pan) { if (c->pan != pan) c->pan = pan; }   /* :623-629 */
+
+void zlo_clip_set_slices(zlo_clip *c, int slices)                    /* :495-528 */
+{
+    if (slices > ZLO_MAX_SLICES) slices = ZLO_MAX_SLICES;            /* oracle storage bound only */
+    if (c->slices != slices) {
+        if (slices == 0) {
+            c->nSlicePositions = 0;
+        } else if (c->slices > slices) {
+            while (c->nSlicePositions > slices) c->nSlicePositions--;
+        } else if (c->slices < slices) {
+            double lastSlicePosition = 0.0f;
+            if (c->nSlicePositions > 0) lastSlicePosition = c->slicePositions[c->nSlicePositions - 1];
+            double positionIncrement = (1.0f - lastSlicePosition) / (slices - c->slices);
+            double newPosition = lastSlicePosition + positionIncrement;
+            if (c->nSlicePositions == 0) c->slicePositions[c->nSlicePositions++] = 0.0f;
+            while (c->nSlicePositions < slices) {
+                c->slicePositions[c->nSlicePositions++] = newPosition;
+                newPosition += positionIncrement;
+            }
+        }
+        c->slices = slices;
+    }
+}
+
+int zlo_clip_slice_for_midi_note(const zlo_clip *c, int midiNote)    /* :575-578 */
+{
+    return ((c->slices - (c->sliceBaseMidiNote % c->slices)) + midiNote) % c->slices;
+}
+
+/* Q13: each setter builds a fresh default Parameters and sets one field (:636-685) */
+void zlo_clip_set_adsr_attack(zlo_clip *c, float v)
+{
+    if (c->adsr.p.attack != v) { zlo_adsr_params p; zlo_adsr_default_params(&p); p.attack = v; zlo_adsr_set_parameters(&c->adsr, &p); }
+}
+void zlo_clip_set_adsr_decay(zlo_clip *c, float v)
+{
+    if (c->adsr.p.decay != v) { zlo_adsr_params p; zlo_adsr_default_params(&p); p.decay = v; zlo_adsr_set_parameters(&c->adsr, &p); }
+}
+void zlo_clip_set_adsr_sustain(zlo_clip *c, float v)
+{
+    if (c->adsr.p.sustain != v) { zlo_adsr_params p; zlo_adsr_default_params(&p); p.sustain = v; zlo_adsr_set_parameters(&c->adsr, &p); }
+}
+void zlo_clip_set_adsr_release(zlo_clip *c, float v)
+{
+    if (c->adsr.p.release != v) { zlo_adsr_params p; zlo_adsr_default_params(&p); p.release = v; zlo_adsr_set_parameters(&c->adsr, &p); }
+}
+
+/* =============================== ClipCommand ================================================= */
+
+void zlo_clip_command_clear(zlo_clip_command *c)    /* ClipCommand.h:13-32 defaults, :74-91 clear */
+{
+    memset(c, 0, sizeof *c);
+    c->clip = -1; c->midiNote = -1; c->midiChannel = -1; c->slice = -1;
+}
+
+int zlo_clip_command_equivalent(const zlo_clip_command *a, const zlo_clip_command *b)   /* :33-39 */
+{
+    return a->clip == b->clip
+        && ((a->changeSlice && b->changeSlice && a->slice == b->slice)
+            || (!a->changeSlice && !b->changeSlice && a->midiNote == b->midiNote && a->midiChannel == b->midiChannel));
+}
+
+/* =============================== SamplerSynthVoice =========================================== */
+
+static float velocity_to_gain(float velocity) { return velocity; }    /* SamplerSynthVoice.cpp:11-18 */
+
+void zlo_voice_init(zlo_voice *v)
+{
+    memset(v, 0, sizeof *v);
+    zlo_clip_command_clear(&v->cmd);
+    v->clip = -1; v->clipPositionId = -1; v->sound = -1;
+    zlo_adsr_init(&v->adsr);
+}
+
+int zlo_voice_set_current_command(zlo_voice *v, const zlo_clip_command *c,
+                                  const zlo_clip *clips, const zlo_sound *sounds)   /* :58-98 */
+{
+    int merged = 0;
+    if (v->hasCommand) {
+        if (c->changeLooping) { v->cmd.looping = c->looping; v->cmd.changeLooping = 1; }
+        if (c->changePitch)   { v->cmd.pitchChange = c->pitchChange; v->cmd.changePitch = 1; }
+        if (c->changeSpeed)   { v->cmd.speedRatio = c->speedRatio; v->cmd.changeSpeed = 1; }
+        if (c->changeGainDb)  { v->cmd.gainDb = c->gainDb; v->cmd.changeGainDb = 1; }
+        if (c->changeVolume) {
+            v->cmd.volume = c->volume; v->cmd.changeVolume = 1;
+            v->lgain = velocity_to_gain(v->cmd.volume);
+            v->rgain = velocity_to_gain(v->cmd.volume);
+        }
+        if (c->changeSlice)   { v->cmd.slice = c->slice; }
+        if (c->startPlayback) {
+            if (v->sound >= 0 && v->clip >= 0)   /* :89 ; d->clip is dereferenced unchecked at :90 */
+                v->sourceSamplePosition = (int)(zlo_clip_get_start_position(&clips[v->clip], v->cmd.slice) * sounds[v->sound].sampleRate);
+        }
+        merged = 1;
+    } else {
+        v->cmd = *c;
+        v->hasCommand = 1;
+    }
+    v->isPlaying = v->hasCommand;
+    return merged;
+}
+
+void zlo_voice_start_note(zlo_voice *v, int midiNote, float velocity, int soundIndex,
+                          const zlo_sound *sounds, zlo_clip *clips, double playbackSampleRate, int64_t now_ms)   /* :110-144 */
+{
+    const zlo_sound *sound = &sounds[soundIndex];
+    v->sound = soundIndex;                                   /* juce::Synthesiser::startVoice: currentlyPlayingSound = sound */
+    if (sound->valid) {                                      /* :114 (sound->clip() is the identity mapping here) */
+        zlo_clip *clip = &clips[soundIndex];
+        v->pitchRatio = pow(2.0, (midiNote - clip->rootNote) / 12.0) * sound->sampleRate / playbackSampleRate;   /* :115-116 */
+        v->clip = soundIndex;                                                                                   /* :119 */
+        v->sourceSampleLength = clip->duration * sound->sampleRate;                                             /* :120 */
+        v->sourceSamplePosition = (int)(zlo_clip_get_start_position(clip, v->cmd.slice) * sound->sampleRate);   /* :121 */
+        v->nextLoopTick = f32_to_u64_sat(v->startTick + clip->lengthInBeats * ZLO_BEAT_SUBDIVISIONS);           /* :123 (u64 + float -> float) */
+        v->nextLoopUsecs = 0;                                                                                   /* :124 */
+        if (v->clipPositionId > -1) zlo_positions_remove(&clip->positions, v->clipPositionId, now_ms);          /* :126-128 */
+        v->clipPositionId = zlo_positions_create(&clip->positions, 0.0f, now_ms);                               /* :129 */
+        v->lgain = velocity_to_gain(velocity);                                                                  /* :131-132 */
+        v->rgain = velocity_to_gain(velocity);
+        zlo_adsr_reset(&v->adsr);                                                                               /* :134-137 */
+        zlo_adsr_set_sample_rate(&v->adsr, sound->sampleRate);
+        zlo_adsr_set_parameters(&v->adsr, &clip->adsr.p);
+        zlo_adsr_note_on(&v->adsr);
+    }
+}
+
+void zlo_voice_stop_note(zlo_voice *v, int allowTailOff, zlo_clip *clips, int64_t now_ms)    /* :146-169 */
+{
+    if (allowTailOff) {
+        zlo_adsr_note_off(&v->adsr);
+    } else {
+        v->sound = -1;                                         /* clearCurrentNote() */
+        zlo_adsr_reset(&v->adsr);
+        if (v->clip >= 0) {
+            zlo_positions_remove(&clips[v->clip].positions, v->clipPositionId, now_ms);
+            v->clip = -1;
+            v->clipPositionId = -1;
+        }
+        if (v->hasCommand) {
+            v->hasCommand = 0;
+            zlo_clip_command_clear(&v->cmd);
+            v->isPlaying = 0;
+        }
+        v->nextLoopTick = 0;
+        v->nextLoopUsecs = 0;
+    }
+}
+
+/* build-defined Hermite extension: 4-point Catmull-Rom, operation order fixed here */
+static float hermite4(float y0, float y1, float y2, float y3, float a)
+{
+    const float c1 = 0.5f * (y2 - y0);
+    const float c2 = (y0 + 2.0f * y2) - (0.5f * y3 + 2.5f * y1);
+    const float c3 = (0.5f * y3 + 1.5f * y1) - (0.5f * y0 + 1.5f * y2);
+    return y1 + a * (c1 + a * (c2 + a * c3));
+}
+
+void zlo_voice_process(zlo_voice *v, float *leftBuffer, float *rightBuffer, uint32_t nframes, const zlo_clock *clk,
+                       const zlo_sound *sounds, zlo_clip *clips, uint32_t mode, int64_t now_ms,
+                       zlo_report *rep, int32_t *pos_trace)           /* :174-270 */
+{
+    if (rep) { rep->valid = 0; rep->gain = 0.0f; rep->progress = 0.0f; }
+    if (pos_trace) for (uint32_t i = 0; i < nframes; ++i) pos_trace[i] = -1;
+    if (v->sound < 0) return;                                                   /* :176 */
+    const zlo_sound *playingSound = &sounds[v->sound];
+    if (!(playingSound->valid && v->hasCommand)) return;                        /* :178 */
+    zlo_clip *clip = &clips[v->clip];
+
+    if (v->nextLoopUsecs == 0) {                                                /* :179-182 */
+        const uint64_t differenceToPlayhead = v->nextLoopTick - clk->jackPlayhead;
+        v->nextLoopUsecs = clk->jackPlayheadUsecs + (differenceToPlayhead * clk->jackSubbeatLengthInMicroseconds);
+    }
+    const double microsecondsPerFrame = (double)((clk->next_usecs - clk->current_usecs) / nframes);   /* :183 (integer division) */
+    float peakGain = 0.0f;                                                      /* :184 */
+    const float *const inL = playingSound->L;                                   /* :186 */
+    const float *const inR = playingSound->R;                                   /* :187 */
+
+    const float clipVolume = clip->volumeAbsolute;                              /* :189 */
+    const int stopPosition = (int)(zlo_clip_get_stop_position(clip, v->cmd.slice) * playingSound->sampleRate);   /* :190, SamplerSynthSound.cpp:101-104 */
+    const int sampleDuration = playingSound->length - 1;                        /* :191 */
+    const float pan = (float)clip->pan;                                         /* :192 */
+    const float lPan = (float)(0.5 * (1.0 + pan));                              /* :193 */
+    const float rPan = (float)(0.5 * (1.0 - pan));                              /* :194 */
+    const double sourceSampleRate = playingSound->sampleRate;                   /* :195 */
+    const int isLooping = v->cmd.looping;                                       /* :196 */
+    const int fixGain = (mode & ZLO_MODE_FIX_GAIN) != 0, fixDelay = (mode & ZLO_MODE_FIX_DELAY) != 0;
+    const int hermite = (mode & ZLO_MODE_HERMITE) != 0;
+
+    for (uint32_t frame = 0; frame < nframes; ++frame) {                        /* :197 */
+        const int pos = (int)v->sourceSamplePosition;                           /* :198 */
+        const float alpha = (float)(v->sourceSamplePosition - pos);             /* :199 */
+        const float invAlpha = 1.0f - alpha;                                    /* :200 */
+        const float envelopeValue = zlo_adsr_next(&v->adsr);                    /* :201 */
+        if (pos_trace) pos_trace[frame] = pos;
+
+        float l, r;
+        if (hermite && sampleDuration > pos) {
+            /* extension: whole-sample gain; falls back to 2-tap linear at the buffer edges */
+            const int wide = (pos - 1 >= 0) && (pos + 2 <= sampleDuration);
+            const float sl = wide ? hermite4(inL[pos - 1], inL[pos], inL[pos + 1], inL[pos + 2], alpha)
+                                  : (inL[pos] * invAlpha + inL[pos + 1] * alpha);
+            l = sl * v->lgain * envelopeValue * clipVolume;
+            if (inR != NULL) {
+                const float sr_ = wide ? hermite4(inR[pos - 1], inR[pos], inR[pos + 1], inR[pos + 2], alpha)
+                                       : (inR[pos] * invAlpha + inR[pos + 1] * alpha);
+                r = sr_ * v->rgain * envelopeValue * clipVolume;
+            } else {
+                r = l;
+            }
+        } else if (fixGain) {
+            l = sampleDuration > pos ? ((inL[pos] * invAlpha + inL[pos + 1] * alpha) * v->lgain * envelopeValue * clipVolume) : 0;
+            r = (inR != NULL && sampleDuration > pos) ? ((inR[pos] * invAlpha + inR[pos + 1] * alpha) * v->rgain * envelopeValue * clipVolume) : l;
+        } else {
+            /* :204-205 -- Q1: the gain chain multiplies only the second tap */
+            l = sampleDuration > pos ? (inL[pos] * invAlpha + inL[pos + 1] * alpha * v->lgain * envelopeValue * clipVolume) : 0;
+            r = (inR != NULL && sampleDuration > pos) ? (inR[pos] * invAlpha + inR[pos + 1] * alpha * v->rgain * envelopeValue * clipVolume) : l;
+        }
+
+        const float mSignal = (float)(0.5 * (l + r));                           /* :208 */
+        const float sSignal = l - r;                                            /* :209 */
+        l = lPan * mSignal + sSignal;                                           /* :210 */
+        r = rPan * mSignal - sSignal;                                           /* :211 */
+
+        const float newGain = l + r;                                            /* :213-216 */
+        if (newGain > peakGain) peakGain = newGain;
+
+        /* :218-221 -- Q2: pointers are pre-incremented, so frame f lands in out[f+1]; the write for
+         * f = nframes-1 is one past the JACK buffer in the reference and is dropped here. */
+        if (fixDelay) {
+            leftBuffer[frame] += l; rightBuffer[frame] += r;
+        } else if (frame + 1 < nframes) {
+            leftBuffer[frame + 1] += l; rightBuffer[frame + 1] += r;
+        }
+
+        v->sourceSamplePosition += v->pitchRatio;                               /* :223 */
+
+        if (isLooping) {                                                        /* :225 */
+            if (truncf(clip->lengthInBeats) == clip->lengthInBeats) {           /* :227 (trunc on float, compared as double) */
+                if (clk->current_usecs + f64_to_u64_sat(frame * microsecondsPerFrame) >= v->nextLoopUsecs) {   /* :232 */
+                    const uint64_t lengthInTicks = f32_to_u64_sat(clip->lengthInBeats * ZLO_BEAT_SUBDIVISIONS);   /* :234 */
+                    v->nextLoopTick = v->nextLoopTick + lengthInTicks;          /* :235 */
+                    const uint64_t differenceToPlayhead = v->nextLoopTick - clk->jackPlayhead;                 /* :236 */
+                    v->nextLoopUsecs = clk->jackPlayheadUsecs + (differenceToPlayhead * clk->jackSubbeatLengthInMicroseconds);   /* :237 */
+                    v->sourceSamplePosition = (int)(zlo_clip_get_start_position(clip, v->cmd.slice) * sourceSampleRate);     /* :241 */
+                }
+            } else if (v->sourceSamplePosition >= stopPosition) {               /* :243 */
+                v->sourceSamplePosition = (int)(zlo_clip_get_start_position(clip, v->cmd.slice) * sourceSampleRate);         /* :246 */
+            }
+        } else {
+            if (v->sourceSamplePosition >= stopPosition) {                      /* :249 */
+                zlo_voice_stop_note(v, 0, clips, now_ms);                       /* :251 */
+                break;
+            } else if (v->sourceSamplePosition >= (stopPosition - (v->adsr.p.release * sourceSampleRate))) {   /* :253 */
+                zlo_voice_stop_note(v, 1, clips, now_ms);                       /* :255 -- Q7: every frame */
+            }
+        }
+        if (!zlo_adsr_is_active(&v->adsr)) {                                    /* :258-261 */
+            zlo_voice_stop_note(v, 0, clips, now_ms);
+            break;
+        }
+    }
+
+    if (v->clip >= 0 && v->clipPositionId > -1) {                               /* :265-267 */
+        const float gain = peakGain * 0.5f;
+        const float progress = (float)(v->sourceSamplePosition / v->sourceSampleLength);
+        zlo_positions_set_gain_and_progress(&clips[v->clip].positions, v->clipPositionId, gain, progress, now_ms);
+        if (rep) { rep->valid = 1; rep->gain = gain; rep->progress = progress; }
+    }
+}
+
+/* =============================== SamplerChannel ============================================== */
+
+int zlo_channel_handle_command(zlo_channel *ch, const zlo_clip_command *c, uint64_t currentTick,
+                               const zlo_sound *sounds, zlo_clip *clips, double playbackSampleRate, int64_t now_ms)   /* SamplerSynth.cpp:187-230 */
+{
+    const int sound = c->clip;                                  /* d->clipSounds[clipCommand->clip], :189 */
+    int consumed = 0;
+    if (c->stopPlayback || c->startPlayback) {
+        if (c->stopPlayback) {                                  /* :191-203 */
+            if (ch->midiChannel == c->midiChannel) {
+                for (int i = 0; i < ch->nvoices; ++i) {
+                    zlo_voice *voice = &ch->voices[i];
+                    if (voice->sound >= 0 && voice->sound == sound && voice->hasCommand && zlo_clip_command_equivalent(&voice->cmd, c))
+                        zlo_voice_stop_note(voice, 1, clips, now_ms);
+                }
+            }
+        }
+        if (c->startPlayback) {                                 /* :204-215 */
+            if (ch->midiChannel == c->midiChannel) {
+                for (int i = 0; i < ch->nvoices; ++i) {
+                    zlo_voice *voice = &ch->voices[i];
+                    if (!voice->isPlaying) {
+                        zlo_voice_set_current_command(voice, c, clips, sounds);
+                        voice->startTick = currentTick;
+                        /* juce::Synthesiser::startVoice: a voice that still has a sound is hard-stopped first */
+                        if (voice->sound >= 0) zlo_voice_stop_note(voice, 0, clips, now_ms);
+                        zlo_voice_start_note(voice, c->midiNote, c->volume, sound, sounds, clips, playbackSampleRate, now_ms);
+                        consumed = 1;
+                        break;
+                    }
+                }
+            }
+        }
+    } else {                                                    /* :216-229 */
+        if (ch->midiChannel == c->midiChannel) {
+            for (int i = 0; i < ch->nvoices; ++i) {
+                zlo_voice *voice = &ch->voices[i];
+                if (voice->sound >= 0 && voice->sound == sound && voice->hasCommand && zlo_clip_command_equivalent(&voice->cmd, c)) {
+                    zlo_voice_set_current_command(voice, c, clips, sounds);
+                    consumed = 1;
+                }
+            }
+        }
+    }
+    return consumed;
+}
+
+void zlo_channel_process(zlo_channel *ch, float *L, float *R, uint32_t nframes, const zlo_clock *clk,
+                         const zlo_sound *sounds, zlo_clip *clips, uint32_t mode, int64_t now_ms, zlo_report *reports)   /* :123-141 */
+{
+    if (reports) memset(reports, 0, sizeof(zlo_report) * (size_t)ch->nvoices);
+    if (!ch->enabled) return;                                   /* :123 (buffers left untouched) */
+    memset(L, 0, nframes * sizeof(float));                      /* :134-135 */
+    memset(R, 0, nframes * sizeof(float));
+    for (int i = 0; i < ch->nvoices; ++i) {                     /* :136-140 */
+        zlo_voice *voice = &ch->voices[i];
+        if (voice->isPlaying)
+            zlo_voice_process(voice, L, R, nframes, clk, sounds, clips, mode, now_ms, reports ? &reports[i] : NULL, NULL);
+    }
+}
+
+/* =============================== AudioLevels ================================================= */
+
+float zlo_convert_to_dbfs(float raw)                            /* AudioLevels.cpp:330-341 */
+{
+    if (raw <= 0) return -200;
+    const float fValue = 20 * log10f(raw);
+    if (fValue < -200) return -200;
+    return fValue;
+}
+
+float zlo_add_float_db(float db1, float db2)                    /* :234-236 : pow(int, float) -> double pow */
+{
+    return 10 * log10f((float)(pow(10, db1 / 10) + pow(10, db2 / 10)));
+}
+
+int32_t zlo_sample_to_peak_int(float x)                         /* :367 : abs(131072.f * x) -> int */
+{
+    const float v = fabsf(131072.0f * x);
+    /* |v| >= 2^31 and NaN are undefined in the reference (float -> int); the build saturates / maps NaN to 0 */
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    return (int32_t)v;
+}
+
+void zlo_levels_tick(zlo_levels_channel *c, const float *L, const float *R, uint32_t n, int with_hold)   /* :347-398 */
+{
+    static const float intToFloatMultiplier = 0.00000152587;    /* :349 (Q12: 0.2/131072) */
+    c->peakA = c->peakA - 10000 > 0 ? c->peakA - 10000 : 0;     /* :359-360 */
+    c->peakB = c->peakB - 10000 > 0 ? c->peakB - 10000 : 0;
+    if (n > 0) {                                                /* :361-384 */
+        for (uint32_t i = 0; i < n; ++i) { const int32_t s = zlo_sample_to_peak_int(L[i]); if (s > c->peakA) c->peakA = s; }
+        for (uint32_t i = 0; i < n; ++i) { const int32_t s = zlo_sample_to_peak_int(R[i]); if (s > c->peakB) c->peakB = s; }
+    }
+    const float peakA = c->peakA * intToFloatMultiplier, peakB = c->peakB * intToFloatMultiplier;   /* :385 */
+    c->peakDbA = zlo_convert_to_dbfs(peakA);                    /* :386-387 */
+    c->peakDbB = zlo_convert_to_dbfs(peakB);
+    c->combinedDb = zlo_add_float_db(c->peakDbA, c->peakDbB);   /* :394 / :406 */
+    if (with_hold) {                                            /* :395-398 */
+        c->peakAHoldSignal = (peakA >= c->peakAHoldSignal) ? peakA : c->peakAHoldSignal * 0.9f;
+        c->peakBHoldSignal = (peakB >= c->peakBHoldSignal) ? peakB : c->peakBHoldSignal * 0.9f;
+        c->holdDbA = zlo_convert_to_dbfs(c->peakAHoldSignal);
+        c->holdDbB = zlo_convert_to_dbfs(c->peakBHoldSignal);
+    }
+}
+
+float zlo_block_rms(const float *x, uint32_t n)                 /* build-defined extension */
+{
+    float acc = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) acc += x[i] * x[i];
+    return n ? sqrtf(acc / (float)n) : 0.0f;
+}
+
+/* =============================== JackPassthrough ============================================= */
+
+void zlo_passthrough_init(zlo_passthrough *p)                   /* JackPassthrough.cpp:27-31 */
+{
+    p->dryAmount = 1.0f; p->wetFx1Amount = 1.0f; p->wetFx2Amount = 1.0f; p->panAmount = 0.0f; p->muted = 0;
+}
+
+void zlo_passthrough_process(const zlo_passthrough *p, const float *inL, const float *inR, float *const out[6], uint32_t nframes)   /* :45-115 */
+{
+    const size_t bytes = nframes * sizeof(float);
+    if (p->muted) {                                             /* :55-61 */
+        for (int k = 0; k < 6; ++k) memset(out[k], 0, bytes);
+        return;
+    }
+    const float amounts[3] = { p->dryAmount, p->wetFx1Amount, p->wetFx2Amount };
+    int output[3] = { 1, 1, 1 };
+    for (int k = 0; k < 3; ++k) {                               /* :66-92 */
+        if (p->panAmount == 0 && amounts[k] == 0) {
+            output[k] = 0; memset(out[2 * k], 0, bytes); memset(out[2 * k + 1], 0, bytes);
+        } else if (p->panAmount == 0 && amounts[k] == 1) {
+            output[k] = 0; memcpy(out[2 * k], inL, bytes); memcpy(out[2 * k + 1], inR, bytes);
+        }
+    }
+    if (p->panAmount != 0 || output[0] || output[1] || output[2]) {   /* :93-112 */
+        const float lm = (1 - p->panAmount) < 1.0f ? (1 - p->panAmount) : 1.0f;   /* std::min(1 - panAmount, 1.0f) */
+        const float rm = (1 + p->panAmount) < 1.0f ? (1 + p->panAmount) : 1.0f;
+        for (uint32_t f = 0; f < nframes; ++f) {
+            const float sl = inL[f], sr = inR[f];
+            for (int k = 0; k < 3; ++k) {
+                if (p->panAmount != 0 || output[k]) {
+                    out[2 * k][f]     = amounts[k] * sl * lm;
+                    out[2 * k + 1][f] = amounts[k] * sr * rm;
+                }
+            }
+        }
+    }
+}
+
+/* =============================== batch driver ================================================ */
+
+typedef struct batch_job {
+    zlo_channel *channels; int32_t bus_begin, bus_end;
+    const zlo_sound *sounds; zlo_clip *clips; const zlo_clock *clocks;
+    uint32_t nblocks, nframes, mode; int32_t mix_group;
+    float *busL, *busR; zlo_report *reports;
+} batch_job;
+
+static void render_bus_block(zlo_channel *ch, float *L, float *R, uint32_t nframes, const zlo_clock *clk,
+                             const zlo_sound *sounds, zlo_clip *clips, uint32_t mode, int32_t mix_group,
+                             zlo_report *reports, float *tmpL, float *tmpR)
+{
+    if (mix_group <= 0 || mix_group >= ch->nvoices) {
+        zlo_channel_process(ch, L, R, nframes, clk, sounds, clips, mode, 0, reports);
+        return;
+    }
+    /* engine summation order: consecutive groups of mix_group voices are summed sequentially into a
+     * zeroed partial, then the partials of groups that rendered anything are added in group order */
+    if (reports) memset(reports, 0, sizeof(zlo_report) * (size_t)ch->nvoices);
+    if (!ch->enabled) return;
+    memset(L, 0, nframes * sizeof(float));
+    memset(R, 0, nframes * sizeof(float));
+    for (int g0 = 0; g0 < ch->nvoices; g0 += mix_group) {
+        const int g1 = g0 + mix_group < ch->nvoices ? g0 + mix_group : ch->nvoices;
+        memset(tmpL, 0, nframes * sizeof(float));
+        memset(tmpR, 0, nframes * sizeof(float));
+        for (int i = g0; i < g1; ++i)
+            if (ch->voices[i].isPlaying)
+                zlo_voice_process(&ch->voices[i], tmpL, tmpR, nframes, clk, sounds, clips, mode, 0, reports ? &reports[i] : NULL, NULL);
+        for (uint32_t f = 0; f < nframes; ++f) { L[f] += tmpL[f]; R[f] += tmpR[f]; }
+    }
+}
+
+static void *batch_worker(void *arg)
+{
+    batch_job *j = (batch_job *)arg;
+    const size_t total = (size_t)j->nblocks * j->nframes;
+    float *tmpL = (float *)malloc(sizeof(float) * j->nframes * 2), *tmpR = tmpL + j->nframes;
+    for (int32_t b = j->bus_begin; b < j->bus_end; ++b) {
+        zlo_channel *ch = &j->channels[b];
+        zlo_report *rp = NULL;
+        for (uint32_t k = 0; k < j->nblocks; ++k) {
+            if (j->reports && k + 1 == j->nblocks) {
+                /* reports are laid out [bus][voice]; buses may have different voice counts only if the
+                 * caller sized the array by the running sum -- the driver assumes a uniform nvoices */
+                rp = j->reports + (size_t)b * ch->nvoices;
+            }
+            render_bus_block(ch, j->busL + b * total + (size_t)k * j->nframes, j->busR + b * total + (size_t)k * j->nframes,
+                             j->nframes, &j->clocks[k], j->sounds, j->clips, j->mode, j->mix_group, rp, tmpL, tmpR);
+        }
+    }
+    free(tmpL);
+    return NULL;
+}
+
+void zlo_render_batch(zlo_channel *channels, int32_t nbuses, const zlo_sound *sounds, zlo_clip *clips,
+                      const zlo_clock *clocks, uint32_t nblocks, uint32_t nframes, uint32_t mode,
+                      int32_t mix_group, float *busL, float *busR, zlo_report *reports, int32_t threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > nbuses) threads = nbuses;
+    batch_job jobs[256];
+    pthread_t tids[256];
+    if (threads > 256) threads = 256;
+    for (int t = 0; t < threads; ++t) {
+        batch_job *j = &jobs[t];
+        j->channels = channels; j->bus_begin = (int32_t)((int64_t)nbuses * t / threads); j->bus_end = (int32_t)((int64_t)nbuses * (t + 1) / threads);
+        j->sounds = sounds; j->clips = clips; j->clocks = clocks; j->nblocks = nblocks; j->nframes = nframes; j->mode = mode;
+        j->mix_group = mix_group; j->busL = busL; j->busR = busR; j->reports = reports;
+    }
+    if (threads == 1) { batch_worker(&jobs[0]); return; }
+    for (int t = 0; t < threads; ++t) pthread_create(&tids[t], NULL, batch_worker, &jobs[t]);
+    for (int t = 0; t < threads; ++t) pthread_join(tids[t], NULL);
+}

@@ -1,0 +1,222 @@
+"""Python binding of the C-ABI in include/zlhip.h (ctypes; no torch types cross the boundary).
+
+Names follow the reference's domain: a SamplerSynth owns `num_buses` SamplerChannels of
+`voices_per_bus` voices (SamplerSynth.cpp:254-278); clips are registered once
+(SamplerSynth::registerClip, :285-295) and played through ClipCommands (ClipCommand.h:11-32).
+Every sample is produced by the HIP kernels behind libzlhip.so; this module only marshals.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from ._abi import (Clock, ClipCommand, ClipParams, Config, Levels, PassthroughParams, Timings, VoiceReport,
+                   MODE_FAITHFUL, MODE_FIX_DELAY, MODE_FIX_GAIN, MODE_HERMITE, ZlHipError)
+
+__all__ = ["SamplerSynth", "Clock", "ClipCommand", "ClipParams", "Levels", "PassthroughParams", "VoiceReport",
+           "MODE_FAITHFUL", "MODE_FIX_GAIN", "MODE_FIX_DELAY", "MODE_HERMITE", "ZlHipError", "clip_command", "synthetic_clocks"]
+
+
+def clip_command(lib=None, **fields) -> ClipCommand:
+    """ClipCommand with the reference's defaults (ClipCommand.h:13-32) and the given fields set."""
+    c = ClipCommand()
+    c.clip = -1
+    c.midi_note = -1
+    c.midi_channel = -1
+    c.slice = -1
+    for k, v in fields.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def synthetic_clocks(nblocks: int, nframes: int, sample_rate: float, start_block: int = 0, bpm: int = 120) -> "C.Array[Clock]":
+    """Monotone JACK-like cycle times: current_usecs = k * round(1e6 * nframes / fs).
+    The SyncTimer playhead is held at tick 0 / usec 0 with the subbeat length of `bpm`
+    (SyncTimer.cpp:180-183,959)."""
+    period = int(round(1e6 * nframes / sample_rate))
+    subbeat = ((1 * 60000000000) // (bpm * 96)) // 1000
+    arr = (Clock * nblocks)()
+    for k in range(nblocks):
+        kk = start_block + k
+        arr[k].current_usecs = kk * period
+        arr[k].next_usecs = (kk + 1) * period
+        arr[k].jack_playhead = 0
+        arr[k].jack_playhead_usecs = 0
+        arr[k].jack_subbeat_length_usecs = subbeat
+    return arr
+
+
+@dataclass
+class BatchResult:
+    bus: np.ndarray            # [num_buses, 2, nblocks*nframes] float32
+    reports: np.ndarray        # structured array of VoiceReport
+
+
+class SamplerSynth:
+    def __init__(self, num_buses: int = 12, voices_per_bus: int = 8, *, max_frames: int = 1024,
+                 max_batch_blocks: int = 64, max_sounds: int = 1024, mode: int = MODE_FAITHFUL,
+                 playback_sample_rate: float = 48000.0, sound_arena_bytes: int = 256 << 20,
+                 voices_per_task: int = 0, device: int = 0):
+        self._lib = _abi.load()
+        cfg = Config()
+        self._lib.zlhip_config_default(C.byref(cfg))
+        cfg.device = device
+        cfg.num_buses = num_buses
+        cfg.voices_per_bus = voices_per_bus
+        cfg.max_frames = max_frames
+        cfg.max_batch_blocks = max_batch_blocks
+        cfg.max_sounds = max_sounds
+        cfg.mode = mode
+        cfg.playback_sample_rate = playback_sample_rate
+        cfg.sound_arena_bytes = sound_arena_bytes
+        cfg.voices_per_task = voices_per_task
+        self.cfg = cfg
+        self._e = C.c_void_p()
+        rc = self._lib.zlhip_engine_create(C.byref(cfg), C.byref(self._e))
+        if rc != 0:
+            raise ZlHipError(f"zlhip_engine_create: {self._lib.zlhip_strerror(rc).decode()} ({rc})")
+        self.num_buses = num_buses
+        self.voices_per_bus = voices_per_bus
+        self.num_voices = num_buses * voices_per_bus
+        self._last = (0, 0)
+
+    # -- lifecycle --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_e", None) and self._e.value:
+            self._lib.zlhip_engine_destroy(self._e)
+            self._e = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc, what):
+        return _abi.check(self._lib, self._e, rc, what)
+
+    @property
+    def handle(self):
+        return self._e
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._ck(self._lib.zlhip_device_name(self._e, buf, 256), "device_name")
+        return buf.value.decode()
+
+    # -- clips ------------------------------------------------------------------------------
+    def register_clip(self, left: np.ndarray, right: Optional[np.ndarray], sample_rate: float) -> int:
+        """SamplerSynth::registerClip + SamplerSynthSound::loadSoundData: upload planar fp32."""
+        left = np.ascontiguousarray(left, dtype=np.float32)
+        rp = None
+        if right is not None:
+            right = np.ascontiguousarray(right, dtype=np.float32)
+            assert right.shape == left.shape
+            rp = right.ctypes.data
+        out = C.c_int32(-1)
+        self._ck(self._lib.zlhip_sound_upload(self._e, left.ctypes.data, rp, left.shape[0], float(sample_rate), C.byref(out)), "sound_upload")
+        return out.value
+
+    def register_clip_device(self, left_ptr: int, right_ptr: Optional[int], length: int, sample_rate: float) -> int:
+        out = C.c_int32(-1)
+        self._ck(self._lib.zlhip_sound_upload_device(self._e, left_ptr, right_ptr, length, float(sample_rate), C.byref(out)), "sound_upload_device")
+        return out.value
+
+    def unregister_clip(self, clip: int):
+        self._ck(self._lib.zlhip_sound_release(self._e, clip), "sound_release")
+
+    def default_clip_params(self, duration_seconds: float) -> ClipParams:
+        p = ClipParams()
+        self._lib.zlhip_clip_params_default(C.byref(p), float(duration_seconds))
+        return p
+
+    def set_clip_params(self, clip: int, params: ClipParams):
+        self._ck(self._lib.zlhip_clip_set(self._e, clip, C.byref(params)), "clip_set")
+
+    # -- commands ---------------------------------------------------------------------------
+    def handle_clip_command(self, cmd: ClipCommand, current_tick: int = 0) -> int:
+        return self._ck(self._lib.zlhip_handle_command(self._e, C.byref(cmd), current_tick), "handle_command")
+
+    def start_voice(self, bus: int, slot: int, cmd: ClipCommand, current_tick: int = 0) -> int:
+        return self._ck(self._lib.zlhip_start_voice(self._e, bus, slot, C.byref(cmd), current_tick), "start_voice")
+
+    # -- render -----------------------------------------------------------------------------
+    def process(self, nframes: int, clock: Clock):
+        """One real-time cycle of every SamplerChannel; returns (left[B,N], right[B,N])."""
+        L = np.empty((self.num_buses, nframes), dtype=np.float32)
+        R = np.empty((self.num_buses, nframes), dtype=np.float32)
+        self._ck(self._lib.zlhip_render(self._e, nframes, C.byref(clock), L.ctypes.data, R.ctypes.data), "render")
+        self._last = (1, nframes)
+        return L, R
+
+    def render_batch(self, nblocks: int, nframes: int, clocks, bus_out_dev: Optional[int] = None, stream: Optional[int] = None):
+        self._ck(self._lib.zlhip_render_batch(self._e, nblocks, nframes, clocks, bus_out_dev, stream), "render_batch")
+        self._last = (nblocks, nframes)
+
+    def synchronize(self):
+        self._ck(self._lib.zlhip_synchronize(self._e), "synchronize")
+
+    def read_bus(self) -> np.ndarray:
+        K, N = self._last
+        out = np.empty((self.num_buses, 2, K * N), dtype=np.float32)
+        self._ck(self._lib.zlhip_read_bus(self._e, out.ctypes.data, out.size), "read_bus")
+        return out
+
+    def voice_reports(self):
+        arr = (VoiceReport * self.num_voices)()
+        self._ck(self._lib.zlhip_voice_reports(self._e, arr, self.num_voices), "voice_reports")
+        return arr
+
+    def enable_trace(self, enable: bool = True, force_slow: bool = False):
+        self._ck(self._lib.zlhip_debug_enable_trace(self._e, (1 if enable else 0) | (2 if force_slow else 0)), "enable_trace")
+
+    def read_trace(self) -> np.ndarray:
+        K, N = self._last
+        out = np.empty((K, self.num_voices, N), dtype=np.int32)
+        self._ck(self._lib.zlhip_debug_read_trace(self._e, out.ctypes.data, out.size), "read_trace")
+        return out
+
+    # -- levels -----------------------------------------------------------------------------
+    def levels_tick(self, block_index: int = -1, with_hold_bus: int = -1):
+        arr = (Levels * self.num_buses)()
+        self._ck(self._lib.zlhip_levels_tick(self._e, block_index, with_hold_bus, arr), "levels_tick")
+        return arr
+
+    def block_peaks(self) -> np.ndarray:
+        K, _ = self._last
+        out = np.empty((K, self.num_buses, 2), dtype=np.int32)
+        self._ck(self._lib.zlhip_block_peaks(self._e, out.ctypes.data, out.size), "block_peaks")
+        return out
+
+    def levels_scan_device(self, bus_dev_ptr: int, nblocks: int, nframes: int, stream: Optional[int] = None):
+        self._ck(self._lib.zlhip_levels_scan_device(self._e, bus_dev_ptr, nblocks, nframes, stream), "levels_scan_device")
+        self._last = (nblocks, nframes)
+
+    # -- passthrough ------------------------------------------------------------------------
+    def passthrough(self, params: Sequence[PassthroughParams], in_dev_ptr: int, out_dev_ptr: int, frames: int, stream: Optional[int] = None):
+        arr = (PassthroughParams * self.num_buses)(*params)
+        self._ck(self._lib.zlhip_passthrough_process(self._e, arr, in_dev_ptr, out_dev_ptr, frames, stream), "passthrough")
+
+    # -- measurement ------------------------------------------------------------------------
+    def set_profiling(self, on: bool = True):
+        self._ck(self._lib.zlhip_set_profiling(self._e, 1 if on else 0), "set_profiling")
+
+    def last_timings(self) -> Timings:
+        t = Timings()
+        self._ck(self._lib.zlhip_last_timings(self._e, C.byref(t)), "last_timings")
+        return t
+
+    def bus_device_ptr(self) -> int:
+        return self._lib.zlhip_bus_device_ptr(self._e)

@@ -32,6 +32,8 @@ struct ZlSim {
     std::vector<int32_t> nsegOut;
     ZlPlanStats stats{};
     int lastK = 0, lastN = 0;
+    bool reportsFresh = false;
+    void absorb() { if (reportsFresh) { hc.absorb_reports(reports.data()); reportsFresh = false; } }
 };
 
 template <uint32_t MODE>
@@ -133,13 +135,13 @@ int zlsim_sound_upload(ZlSim *S, const float *L, const float *R, int length, dou
 
 int zlsim_handle_command(ZlSim *S, const zlhip_clip_command *c, uint64_t tick)
 {
-    S->hc.absorb_reports(S->reports.data());
+    S->absorb();
     return S->hc.handle_command(*c, tick);
 }
 
 int zlsim_start_voice(ZlSim *S, int bus, int slot, const zlhip_clip_command *c, uint64_t tick)
 {
-    S->hc.absorb_reports(S->reports.data());
+    S->absorb();
     return S->hc.handle_on_bus(bus, *c, tick, slot);
 }
 
@@ -155,7 +157,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     S->trace.assign((size_t)K * V * N, -1);
     S->levels.assign((size_t)K * S->B, ZlBlockLevels{});
     std::vector<ZlVoiceOp> ops; std::vector<ZlOpRange> ranges;
-    S->hc.absorb_reports(S->reports.data());
+    S->absorb();
     S->hc.drain_ops(ops, ranges);
 
     ZlBatch A; std::memset(&A, 0, sizeof A);
@@ -180,7 +182,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
         C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7)
 #undef C
     }
-    S->lastK = K; S->lastN = N;
+    S->lastK = K; S->lastN = N; S->reportsFresh = true;
     return 0;
 }
 

@@ -1,0 +1,115 @@
+"""ctypes wrapper of tests/cpu_harness/plan_host.cpp -- TEST HARNESS ONLY.
+
+Runs the engine's __host__ __device__ planning / per-frame code on the CPU so the CPU-only test
+tier can compare it with the oracle.  Not part of the product and never imported by libzl_amd.
+"""
+import ctypes as C
+
+import numpy as np
+
+from libzl_amd import build
+from libzl_amd._abi import ClipCommand, ClipParams, Clock, VoiceReport
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = C.CDLL(build.build_cpu_harness())
+        l.zlsim_create.restype = C.c_void_p
+        l.zlsim_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint32, C.c_int]
+        l.zlsim_destroy.argtypes = [C.c_void_p]
+        l.zlsim_clip_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(ClipParams)]
+        l.zlsim_sound_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        l.zlsim_handle_command.argtypes = [C.c_void_p, C.POINTER(ClipCommand), C.c_uint64]
+        l.zlsim_start_voice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ClipCommand), C.c_uint64]
+        l.zlsim_render_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Clock), C.c_void_p, C.c_int]
+        l.zlsim_reports.argtypes = [C.c_void_p, C.POINTER(VoiceReport)]
+        l.zlsim_trace.argtypes = [C.c_void_p, C.c_void_p]
+        l.zlsim_block_peaks.argtypes = [C.c_void_p, C.c_void_p]
+        l.zlsim_slow_blocks.restype = C.c_ulonglong
+        l.zlsim_slow_blocks.argtypes = [C.c_void_p]
+        l.zlsim_source_bytes.restype = C.c_ulonglong
+        l.zlsim_source_bytes.argtypes = [C.c_void_p]
+        l.zlsim_nseg.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.zlsim_plan_flags.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.zlsim_check_linear_runs.restype = C.c_longlong
+        l.zlsim_check_linear_runs.argtypes = [C.c_double, C.c_double, C.c_longlong, C.POINTER(C.c_longlong)]
+        l.zlsim_steps_to_reach.argtypes = [C.c_double, C.c_double, C.c_double]
+        _lib = l
+    return _lib
+
+
+class SimSynth:
+    """Same surface as libzl_amd.SamplerSynth, executed by the CPU harness."""
+
+    def __init__(self, num_buses=12, voices_per_bus=8, *, mode=0, playback_sample_rate=48000.0,
+                 max_sounds=1024, voices_per_task=0, **_):
+        self.l = lib()
+        self.num_buses, self.voices_per_bus = num_buses, voices_per_bus
+        self.num_voices = num_buses * voices_per_bus
+        self.s = C.c_void_p(self.l.zlsim_create(num_buses, voices_per_bus, max_sounds, playback_sample_rate, mode, voices_per_task))
+        self._last = (0, 0)
+        self.force_slow = False
+
+    def close(self):
+        if self.s:
+            self.l.zlsim_destroy(self.s)
+            self.s = None
+
+    def register_clip(self, left, right, sample_rate):
+        left = np.ascontiguousarray(left, dtype=np.float32)
+        rp = None
+        if right is not None:
+            right = np.ascontiguousarray(right, dtype=np.float32)
+            rp = right.ctypes.data
+        i = self.l.zlsim_sound_upload(self.s, left.ctypes.data, rp, left.shape[0], float(sample_rate))
+        assert i >= 0
+        return i
+
+    def set_clip_params(self, clip, params):
+        self.l.zlsim_clip_set(self.s, clip, C.byref(params))
+
+    def handle_clip_command(self, cmd, current_tick=0):
+        return self.l.zlsim_handle_command(self.s, C.byref(cmd), current_tick)
+
+    def start_voice(self, bus, slot, cmd, current_tick=0):
+        return self.l.zlsim_start_voice(self.s, bus, slot, C.byref(cmd), current_tick)
+
+    def render_batch(self, nblocks, nframes, clocks, *a, **k):
+        self._bus = np.zeros((self.num_buses, 2, nblocks * nframes), dtype=np.float32)
+        self.l.zlsim_render_batch(self.s, nblocks, nframes, clocks, self._bus.ctypes.data, 1 if self.force_slow else 0)
+        self._last = (nblocks, nframes)
+
+    def read_bus(self):
+        return self._bus
+
+    def voice_reports(self):
+        arr = (VoiceReport * self.num_voices)()
+        self.l.zlsim_reports(self.s, arr)
+        return arr
+
+    def enable_trace(self, enable=True, force_slow=False):
+        self.force_slow = force_slow
+
+    def read_trace(self):
+        K, N = self._last
+        out = np.empty((K, self.num_voices, N), dtype=np.int32)
+        self.l.zlsim_trace(self.s, out.ctypes.data)
+        return out
+
+    def block_peaks(self):
+        K, _ = self._last
+        out = np.empty((K, self.num_buses, 2), dtype=np.int32)
+        self.l.zlsim_block_peaks(self.s, out.ctypes.data)
+        return out
+
+    def slow_blocks(self):
+        return self.l.zlsim_slow_blocks(self.s)
+
+    def source_bytes(self):
+        return self.l.zlsim_source_bytes(self.s)
+
+    def nseg(self, k, v):
+        return self.l.zlsim_nseg(self.s, k, v)

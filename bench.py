@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- voice-samples/sec of the sampler hot path on MI355X.
+
+Workload (BASELINE.json metric: "voice-samples/sec at 1024 voices x 256-frame blocks; % HBM
+roofline"): 1024 looping stereo voices on 8 buses x 128 voices, 48 kHz source and playback
+(ratio 1), linear interpolation, reference-faithful mode, one distinct 2 s uniform(-1,1) source
+per voice (786 MB, larger than the 256 MiB Infinity Cache), fractional-beat loops, per-clip
+volume / pan, bus integer peaks every block.  One "step" = one zlhip_render_batch call of
+--blocks-per-step consecutive 256-frame blocks with every input resident in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own 1024
+voices (weak scaling) into a partial bus and the partial buses are summed onto rank 0 with one
+RCCL reduce per step; rank 0 then scans the reduced bus for levels.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (K2 zl_k2_render):
+algorithmic bytes per launch / its average duration measured with HIP events on the engine's
+stream.  `cpu_baseline` times the CPU oracle (a port: the reference is not compilable here) on a
+bounded sample of the same workload on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+VOICE_STATE_BYTES = 104        # sizeof(ZlVoiceState)
+
+
+def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, seed, bpm=120):
+    """Registers one distinct stereo loop per voice (generated on the device) and starts every voice."""
+    from libzl_amd import clip_command
+    V = voices_per_bus * num_buses
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    for v in range(V):
+        src = torch.rand((2, loop_frames), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0
+        cid = syn.register_clip_device(src[0].data_ptr(), src[1].data_ptr(), loop_frames, fs)
+        assert cid == v
+        del src
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(seed)
+    for v in range(V):
+        p = syn.default_clip_params(loop_frames / fs)
+        # fractional beat length -> deterministic sample-space loop wrap (SamplerSynthVoice.cpp:243-246)
+        p.length_in_beats = 3.5
+        p.length_seconds = float(np.float32((loop_frames - 64 - (v % 17)) / fs))
+        p.volume_absolute = float(np.float32(rng.uniform(0.25, 1.0)))
+        p.pan = float(np.float32(rng.uniform(-1.0, 1.0)))
+        syn.set_clip_params(v, p)
+    for v in range(V):
+        bus, slot = divmod(v, voices_per_bus)
+        cmd = clip_command(clip=v, midi_note=60, midi_channel=bus - 2, start_playback=1, looping=1,
+                           change_volume=1, volume=float(np.float32(rng.uniform(0.1, 1.0))))
+        assert syn.start_voice(bus, slot, cmd, 0) == 1
+
+
+def cpu_baseline(args, seed):
+    """Oracle (-O3 -march=native build) on a bounded sample of the same workload, buses partitioned
+    over host threads (one RT thread per JACK client in the reference)."""
+    from oracle import zl_oracle as zo
+    from libzl_amd.engine import synthetic_clocks
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64, args.cpu_threads if args.cpu_threads > 0 else 16))
+    V = 1024
+    vpb = 8                                  # the reference's own voices per channel; 128 buses so threads can spread
+    B = V // vpb
+    loop = 24000                             # 0.5 s loops keep the sample's memory small (49 MB); arithmetic identical
+    blocks = args.cpu_blocks
+    osyn = zo.OracleSynth(B, vpb, args.fs, 0, max_sounds=V, fast=True)
+    rng = np.random.default_rng(seed)
+    for v in range(V):
+        L = rng.uniform(-1, 1, loop).astype(np.float32)
+        R = rng.uniform(-1, 1, loop).astype(np.float32)
+        cid = osyn.register_clip(L, R, args.fs)
+        clip = osyn.clips[cid]
+        clip.lengthInBeats = 3.5
+        clip.lengthInSeconds = float(np.float32((loop - 64 - (v % 17)) / args.fs))
+        clip.volumeAbsolute = float(np.float32(rng.uniform(0.25, 1.0)))
+        clip.pan = float(np.float32(rng.uniform(-1.0, 1.0)))
+    for v in range(V):
+        bus, slot = divmod(v, vpb)
+        cmd = zo.clip_command(clip=v, midiNote=60, midiChannel=bus - 2, startPlayback=1, looping=1, changeVolume=1,
+                              volume=float(np.float32(rng.uniform(0.1, 1.0))))
+        assert osyn.start_voice(bus, slot, cmd, 0) == 1
+    clocks = synthetic_clocks(blocks, args.frames, args.fs)
+    osyn.render_batch(2, args.frames, clocks, threads=threads, want_reports=False)       # warm-up
+    t0 = time.perf_counter()
+    osyn.render_batch(blocks, args.frames, clocks, threads=threads, want_reports=False)
+    dt = time.perf_counter() - t0
+    return {
+        "value": V * blocks * args.frames / dt, "unit": "voice-samples/s", "cores": threads, "kind": "port",
+        "sample": f"{V} stereo voices (128 buses x 8) x {blocks} blocks x {args.frames} frames, 0.5 s loops, ratio 1, "
+                  f"oracle/zl_oracle.c -O3 -march=native, {dt:.2f} s wall on {cores} visible cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--voices", type=int, default=1024)
+    ap.add_argument("--buses", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--blocks-per-step", type=int, default=512)
+    ap.add_argument("--fs", type=float, default=48000.0)
+    ap.add_argument("--loop-seconds", type=float, default=2.0)
+    ap.add_argument("--voices-per-task", type=int, default=0)
+    ap.add_argument("--cpu-blocks", type=int, default=64)
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU render path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from libzl_amd import SamplerSynth
+    from libzl_amd.engine import synthetic_clocks
+
+    V, B, N, KB = args.voices, args.buses, args.frames, args.blocks_per_step
+    vpb = V // B
+    loop_frames = int(args.loop_seconds * args.fs)
+    arena = (loop_frames + 16) * 8 * V + (1 << 20)
+    syn = SamplerSynth(B, vpb, max_frames=N, max_batch_blocks=KB, max_sounds=V, mode=0, playback_sample_rate=args.fs,
+                       sound_arena_bytes=arena, voices_per_task=args.voices_per_task, device=local_rank)
+    seed = 0x5A17 + 2 + 1000 * rank
+    build_scene(syn, torch, dev, vpb, B, args.fs, loop_frames, seed)
+    syn.set_profiling(True)
+
+    # the engine renders into a torch-owned device buffer so the RCCL reduce needs no copy
+    bus = torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+    clock_sets = [synthetic_clocks(KB, N, args.fs, start_block=i * KB) for i in range(args.warmup + args.steps)]
+
+    render_ms = []
+    plan_ms = []
+    fin_ms = []
+    src_bytes = 0
+
+    def step(i, timed):
+        nonlocal src_bytes
+        syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr)
+        if distributed:
+            dist.reduce(bus, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                syn.levels_scan_device(bus.data_ptr(), KB, N, stream=sptr)
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+        if not distributed or True:
+            # per-kernel HIP-event timings of this step (events were recorded on the launch stream);
+            # reading them waits for the step, which render_batch would do anyway before reusing its staging
+            t = syn.last_timings()
+            render_ms.append(t.render_ms); plan_ms.append(t.plan_ms); fin_ms.append(t.finalize_ms)
+            src_bytes = t.source_bytes
+            slow = t.slow_blocks
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_vs = float(V) * world * KB * N * args.steps
+    value = total_vs / dt
+    # algorithmic bytes of one K2 launch: source window once per voice-block + bus write
+    bus_bytes = B * 2 * N * 4 * KB
+    k2_bytes = src_bytes + bus_bytes
+    state_bytes = V * 2 * VOICE_STATE_BYTES + B * 8 * KB
+    k2_avg_ms = float(np.mean(render_ms)) if render_ms else float("nan")
+    achieved = k2_bytes / (k2_avg_ms * 1e-3) / 1e9 if k2_avg_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "voice-samples/sec at 1024 voices x 256-frame blocks; % HBM roofline",
+            "value": value, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{V} looping stereo voices per GPU on {B} buses x {vpb}, {N}-frame blocks, {KB} blocks per step, "
+                            f"fs=sr={args.fs:.0f} (ratio 1), linear interp, faithful mode, distinct {args.loop_seconds:g} s sources "
+                            f"({arena / 1e6:.0f} MB), bus int peaks per block" + (", RCCL bus reduce to rank 0 per step" if distributed else ""),
+                "voices_per_gpu": V, "buses": B, "frames_per_block": N, "blocks_per_step": KB, "parallelism": f"voices sharded x{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "zl_k2_render", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_avg_ms,
+                "bytes_per_voice_sample": k2_bytes / (V * KB * N),
+                "other_kernels_ms": {"zl_k1_plan+k0": float(np.mean(plan_ms)), "zl_k3_finalize+reports": float(np.mean(fin_ms))},
+                "state_and_levels_bytes_per_step": state_bytes, "slow_blocks": int(slow),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, seed)
+        print(json.dumps(out))
+    syn.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,21 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_engine(force: bool = False, verbose: bool = False) -> str:
+def build_engine(force: bool = False, verbose: bool = False, stamps: bool = False) -> str:
+    """stamps=True builds the diagnostic variant libzlhip_stamps.so (-DZL_STAMPS: per-workgroup
+    timestamps in K2; used only by scripts/k2_stamps.py, never by the package)."""
+    global LIB
+    if stamps:
+        out = os.path.join(LIBDIR, "libzlhip_stamps.so")
+        saved, LIB = LIB, out
+        try:
+            return _build_engine(force, verbose, ["-DZL_STAMPS"])
+        finally:
+            LIB = saved
+    return _build_engine(force, verbose, [])
+
+
+def _build_engine(force: bool, verbose: bool, extra: list) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if not force and not _stale(LIB, deps):
@@ -50,7 +64,7 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
         "-I", os.path.join(ROOT, "include"), "-I", CSRC,
         "-Wall", "-Wno-unused-function",
         "-o", LIB,
-    ] + srcs
+    ] + extra + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

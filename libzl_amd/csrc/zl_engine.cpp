@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@ struct zlhip_engine {
     ZlBlockLevels *dLevels = nullptr; ZlLevelsState *dLevelState = nullptr;
     ZlClock *dClocks = nullptr; ZlVoiceOp *dOps = nullptr; ZlOpRange *dOpRanges = nullptr;
     ZlBatchStats *dStats = nullptr; int32_t *dTrace = nullptr; PassParamsDev *dPass = nullptr;
+    int32_t *dExpandList = nullptr; int32_t *dExpandCount = nullptr;
     size_t opsCap = 0, rangesCap = 0, traceInts = 0;
     int maxGroups = 1;
 
@@ -134,7 +136,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dVconst, e->dPlans, e->dSegs, e->dCtlP, e->dCtlEnv,
                     e->dReports, e->dGain, e->dPartials, e->dBus, e->dLevels, e->dLevelState, e->dClocks, e->dOps,
-                    e->dOpRanges, e->dStats, e->dTrace, e->dPass };
+                    e->dOpRanges, e->dStats, e->dTrace, e->dPass, e->dExpandList, e->dExpandCount };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { e->hClocks, e->hReports, e->hGain, e->hBus, e->hLevelState, e->hStats };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -180,7 +182,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     chk(dalloc(&e->dVoices, V), "voices");
     chk(dalloc(&e->dVconst, V), "vconst");
     chk(dalloc(&e->dPlans, K * V), "plans");
-    chk(dalloc(&e->dSegs, K * V * (ZL_MAXSEG - 1)), "segments");
+    chk(dalloc(&e->dSegs, K * V * (ZL_MAXSEG - 2)), "segments");
     chk(dalloc(&e->dCtlP, K * V * N), "ctlP");
     chk(dalloc(&e->dCtlEnv, K * V * N), "ctlEnv");
     chk(dalloc(&e->dReports, V), "reports");
@@ -191,6 +193,8 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     chk(dalloc(&e->dLevelState, B), "levelState");
     chk(dalloc(&e->dClocks, K), "clocks");
     chk(dalloc(&e->dStats, 1), "stats");
+    chk(dalloc(&e->dExpandList, K * V), "expand list");
+    chk(dalloc(&e->dExpandCount, 1), "expand count");
     chk(dalloc(&e->dPass, B), "passthrough params");
     chk(hipHostMalloc((void **)&e->hClocks, K * sizeof(ZlClock)), "hClocks");
     chk(hipHostMalloc((void **)&e->hReports, V * sizeof(ZlReport)), "hReports");
@@ -419,14 +423,20 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         }
         ZL_HIP(e, hipMemsetAsync(e->dTrace, 0xff, need * sizeof(int32_t), s));
         A.trace = 1; A.pos_trace = e->dTrace; e->traceK = nblocks; e->traceN = nframes;
+#ifdef ZL_STAMPS
+        A.trace = 0;       // diagnostic build: the trace buffer receives per-workgroup timestamps instead
+#endif
     }
     rc = upload_ops(e, A, s);
     if (rc != ZLHIP_OK) return rc;
     ZL_HIP(e, hipMemsetAsync(e->dStats, 0, sizeof(ZlBatchStats), s));
+    ZL_HIP(e, hipMemsetAsync(e->dExpandCount, 0, sizeof(int32_t), s));
+    A.expand_list = e->dExpandList; A.expand_count = e->dExpandCount;
 
     if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[0], s));
     ZL_KERNEL(e, zl_launch_apply_ops(A, s));
     ZL_KERNEL(e, zl_launch_plan(A, e->forceSlow, s));
+    ZL_KERNEL(e, zl_launch_expand(A, s));
     if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[1], s));
     ZL_KERNEL(e, zl_launch_render(A, s));
     if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[2], s));

@@ -30,17 +30,55 @@ __global__ void zl_k0_apply_ops(const ZlBatch A)
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: one lane per voice.  Steady-state cost is O(1) per block (one linear segment); see zl_plan.h.
+// K1: one lane per voice; the block clocks are staged in LDS so the per-block step of the planner
+// makes no dependent global load.  Steady-state cost is O(1) per block (zl_plan.h).
+#define ZL_K1_CLOCKS 256
 __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow)
 {
+    __shared__ ZlClock s_clk[ZL_K1_CLOCKS];
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= A.V) return;
-    ZlPlanStats s;
-    zl_plan_voice(A, v, force_slow, s);
-    if (A.stats) {
-        if (s.source_bytes)  atomicAdd(&A.stats->source_bytes, s.source_bytes);
-        if (s.slow_blocks)   atomicAdd(&A.stats->slow_blocks, s.slow_blocks);
-        if (s.active_frames) atomicAdd(&A.stats->active_frames, s.active_frames);
+    const bool mine = v < A.V;
+    ZlPlanner pl;
+    if (mine) pl.begin(A, v);
+    for (int kb = 0; kb < A.K; kb += ZL_K1_CLOCKS) {
+        const int nk = (A.K - kb < ZL_K1_CLOCKS) ? A.K - kb : ZL_K1_CLOCKS;
+        __syncthreads();
+        {
+            const uint4 *g = reinterpret_cast<const uint4 *>(A.clocks + kb);
+            uint4 *sh = reinterpret_cast<uint4 *>(s_clk);
+            for (int i = threadIdx.x; i < nk * (int)(sizeof(ZlClock) / 16); i += blockDim.x) sh[i] = g[i];
+        }
+        __syncthreads();
+        if (mine)
+            for (int k = 0; k < nk; ++k) pl.plan_block(A, kb + k, s_clk[k], force_slow);
+    }
+    if (mine) {
+        pl.end(A);
+        if (A.stats) {
+            if (pl.stats.source_bytes)  atomicAdd(&A.stats->source_bytes, pl.stats.source_bytes);
+            if (pl.stats.slow_blocks)   atomicAdd(&A.stats->slow_blocks, pl.stats.slow_blocks);
+            if (pl.stats.active_frames) atomicAdd(&A.stats->active_frames, pl.stats.active_frames);
+        }
+    }
+}
+
+// K1b: blocks with more than two position segments (the block after a loop restart at a small
+// position crosses ~log2(N) binades) are expanded, lane-parallel, into per-frame control so that K2
+// keeps a single pipelined code path.  One workgroup per queued block, grid-stride over the queue.
+__global__ void __launch_bounds__(256) zl_k1b_expand(const ZlBatch A)
+{
+    const int n = *A.expand_count;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const size_t pidx = (size_t)A.expand_list[e];
+        const ZlBlockPlan pl = A.plans[pidx];
+        const ZlSegment *extra = A.segs + pidx * (ZL_MAXSEG - 2);
+        for (int f = threadIdx.x; f < A.N; f += blockDim.x) {
+            A.ctl_P[pidx * (size_t)A.N + f] = zl_expand_position(pl, extra, f < pl.n_active ? f : 0);
+            A.ctl_env[pidx * (size_t)A.N + f] = pl.env;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) A.plans[pidx].flags = pl.flags | ZL_PLAN_SLOW;
+        __syncthreads();
     }
 }
 
@@ -57,9 +95,114 @@ static __device__ __forceinline__ float zl_wave_max(float x)
     return x;
 }
 
+// 16-byte gather of the two interpolation taps of both channels (interleaved stereo), 8-byte aligned
+typedef float zl_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float zl_f2a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+#define ZL_K2_CHUNK 128      // voice records staged in LDS per pass
+#define ZL_K2_U     8        // gathers in flight per wavefront
+
+// 16-byte gather of the interpolation taps: interleaved stereo [L0 R0 L1 R1] or mono [x0 x1 . .]
+typedef float zl_f4a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float zl_f2a4b __attribute__((ext_vector_type(2), aligned(4)));
+
+struct ZlK2Tap { ZlTaps t; float alpha; int flags; };   // flags: 1 act, 2 inb, 4 stereo, 16 wide
+
+// One chunk of U consecutive voices for one lane (= one output frame).  Branch-free per voice so the
+// U gathers (and, for CTL chunks, the U per-frame control loads before them) are issued back to back
+// and stay in flight together; the voices are then mixed and accumulated in voice order.
+// CTL = the chunk contains a block with per-frame control (envelope not in steady sustain, or a
+// block expanded by K1b); regular voices of such a chunk read a dummy control word.
+template <uint32_t MODE, bool CTL, int U>
+static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
+                                                    const int *s_cls, int c0, size_t pbase, int vfirst, int f, bool wantPeak,
+                                                    float &accL, float &accR)
+{
+    const int N = A.N;
+    ZlK2Tap tap[U];
+    double Pc[U];
+    float  Ec[U];
+    if (CTL) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = c0 + u;
+            const bool ctl = s_cls[i] & 2;
+            const bool act = (s_cls[i] & 1) && f < s_plan[i].n_active;
+            const size_t off = ctl ? (pbase + i) * (size_t)N + (act ? f : 0) : 0;    // regular voices: word 0 (always valid)
+            Pc[u] = A.ctl_P[off];
+            Ec[u] = A.ctl_env[off];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = c0 + u;
+        const int cls = s_cls[i];
+        const bool on = cls & 1;
+        const bool act = on && f < s_plan[i].n_active;
+        const int fe = act ? f : 0;                               // lanes past the voice's end gather a safe address
+        const bool seg1 = fe >= s_plan[i].n1;                     // second linear segment of the block
+        const double P0 = seg1 ? s_plan[i].P1 : s_plan[i].P0;
+        const double st = seg1 ? s_plan[i].step1 : s_plan[i].step;
+        double P = fma((double)(fe - (seg1 ? s_plan[i].n1 : 0)), st, P0);            // exact, see zl_plan.h
+        if (CTL) { if (cls & 2) P = Pc[u]; }
+        int pos;
+        zl_split_position(P, pos, tap[u].alpha);                  // :198-199
+        const int dur = s_vc[i].sample_duration;
+        const bool stereo = s_vc[i].channels > 1;
+        const bool inb = on && (dur > pos) && (pos >= 0);         // :204 guard (Q5)
+        const bool wide = (MODE & ZL_MODE_HERMITE) && inb && (pos - 1 >= 0) && (pos + 2 <= dur);
+        const int p = inb ? pos : 0;
+        const uint64_t so = on ? s_vc[i].src_offset : 0;
+        const float *src = A.arena + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(so >> 32)) << 32)
+                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)so));
+        const size_t e0 = stereo ? 2 * (size_t)p : (size_t)p;
+        const zl_f4a4 d = *reinterpret_cast<const zl_f4a4 *>(src + e0);
+        tap[u].t.x0l = d.x;
+        tap[u].t.x0r = stereo ? d.y : 0.0f;
+        tap[u].t.x1l = stereo ? d.z : d.y;
+        tap[u].t.x1r = stereo ? d.w : 0.0f;
+        if (MODE & ZL_MODE_HERMITE) {
+            const size_t em = stereo ? 2 * (size_t)(wide ? p - 1 : p) : (size_t)(wide ? p - 1 : p);
+            const size_t e2 = stereo ? 2 * (size_t)(wide ? p + 2 : p) : (size_t)(wide ? p + 2 : p);
+            const zl_f2a4b m = *reinterpret_cast<const zl_f2a4b *>(src + em);
+            const zl_f2a4b n = *reinterpret_cast<const zl_f2a4b *>(src + e2);
+            tap[u].t.xml = m.x; tap[u].t.xmr = stereo ? m.y : 0.0f;
+            tap[u].t.x2l = n.x; tap[u].t.x2r = stereo ? n.y : 0.0f;
+        } else {
+            tap[u].t.xml = tap[u].t.xmr = tap[u].t.x2l = tap[u].t.x2r = 0.0f;
+        }
+        tap[u].flags = (act ? 1 : 0) | (inb ? 2 : 0) | (stereo ? 4 : 0) | (wide ? 16 : 0);
+        if (A.trace && on) A.pos_trace[(pbase + i) * (size_t)N + f] = act ? pos : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = c0 + u;
+        const int tf = tap[u].flags;
+        const bool act = tf & 1;
+        float env = s_plan[i].env;
+        if (CTL) { if (s_cls[i] & 2) env = Ec[u]; }
+        float l, r;
+        zl_mix_frame<MODE>(tap[u].t, tap[u].alpha, tf & 2, tf & 16, tf & 4, s_vc[i].lgain, s_vc[i].rgain, env,
+                           s_vc[i].clip_volume, s_vc[i].lpan, s_vc[i].rpan, l, r);
+        if (act) { accL += l; accR += r; }                        // :218-221 (index shift applied at the store)
+        if (wantPeak) {                                           // :213-216, signed peak from 0 (Q6)
+            const float ng = l + r;
+            float pk = (act && ng > 0.0f) ? ng : 0.0f;
+            pk = zl_wave_max(pk);
+            if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[vfirst + i].peak_bits, __float_as_uint(pk));
+        }
+    }
+}
+
 template <uint32_t MODE>
 __global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
 {
+    constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U / 2 : ZL_K2_U;
+    __shared__ ZlBlockPlan  s_plan[ZL_K2_CHUNK];
+    __shared__ ZlVoiceConst s_vc[ZL_K2_CHUNK];
+    __shared__ int s_cls[ZL_K2_CHUNK];            // per voice: 1 = plays this block, 2 = per-frame control
+    __shared__ int s_chunk[ZL_K2_CHUNK / U];      // OR of s_cls over each chunk of U voices
+
     const int N = A.N, V = A.V;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;          // frame inside the block
     const int k = blockIdx.y;
@@ -69,29 +212,64 @@ __global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
     const int vend = (bus + 1) * A.VPB;
     const int v1 = (v0 + A.G < vend) ? v0 + A.G : vend;
     const bool wantPeak = (k == A.K - 1);
+#ifdef ZL_STAMPS
+    unsigned long long zl_t0 = __builtin_amdgcn_s_memrealtime(), zl_t1 = 0;
+#endif
 
     float accL = 0.0f, accR = 0.0f;
-    for (int v = v0; v < v1; ++v) {
-        const size_t pidx = (size_t)k * V + v;
-        const ZlBlockPlan pl = A.plans[pidx];
-        if (!(pl.flags & ZL_PLAN_ACTIVE)) continue;               // !voice->isPlaying, SamplerSynth.cpp:137
-        const ZlVoiceConst vc = A.vconst[v];
-        const bool act = f < pl.n_active;
-        double P; float env;
-        zl_eval_control(pl, A.segs + pidx * (ZL_MAXSEG - 1), A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N,
-                        act ? f : 0, P, env);
-        float l, r; int pos;
-        zl_render_frame<MODE>(vc, A.arena + vc.src_offset, P, env, l, r, pos);
-        if (act) { accL += l; accR += r; }                        // :218-221 (index shift applied at the store)
-        if (A.trace) A.pos_trace[pidx * (size_t)N + f] = act ? pos : -1;
-        if (wantPeak) {                                           // :213-216, signed peak from 0 (Q6)
-            const float ng = l + r;
-            float pk = (act && ng > 0.0f) ? ng : 0.0f;
-            pk = zl_wave_max(pk);
-            if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[v].peak_bits, __float_as_uint(pk));
+    for (int vb = v0; vb < v1; vb += ZL_K2_CHUNK) {
+        const int nv = (v1 - vb < ZL_K2_CHUNK) ? v1 - vb : ZL_K2_CHUNK;
+        // ---- stage the per-voice records of this pass in LDS (one coalesced round trip per workgroup)
+        __syncthreads();
+        {
+            const uint4 *gp = reinterpret_cast<const uint4 *>(A.plans + (size_t)k * V + vb);
+            uint4 *sp = reinterpret_cast<uint4 *>(s_plan);
+            for (int i = threadIdx.x; i < nv * (int)(sizeof(ZlBlockPlan) / 16); i += blockDim.x) sp[i] = gp[i];
+            const uint4 *gc = reinterpret_cast<const uint4 *>(A.vconst + vb);
+            uint4 *sc = reinterpret_cast<uint4 *>(s_vc);
+            for (int i = threadIdx.x; i < nv * (int)(sizeof(ZlVoiceConst) / 16); i += blockDim.x) sc[i] = gc[i];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < ZL_K2_CHUNK; i += blockDim.x) {
+            int cls = 0;
+            if (i < nv && (s_plan[i].flags & ZL_PLAN_ACTIVE)) {
+                cls = 1 | ((s_plan[i].flags & ZL_PLAN_SLOW) ? 2 : 0);
+            } else {
+                // idle slot: a harmless voice with no active frame for the branch-free chunk code
+                s_plan[i].flags = 0; s_plan[i].nseg = 1; s_plan[i].env = 0.0f;
+                s_plan[i].n_active = 0; s_plan[i].P0 = 0.0; s_plan[i].step = 0.0; s_plan[i].n1 = 0x7fffffff;
+                s_plan[i].P1 = 0.0; s_plan[i].step1 = 0.0;
+                s_vc[i].src_offset = 0; s_vc[i].sample_duration = 0; s_vc[i].channels = 2;
+                s_vc[i].lgain = s_vc[i].rgain = s_vc[i].clip_volume = s_vc[i].lpan = s_vc[i].rpan = 0.0f;
+            }
+            s_cls[i] = cls;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < ZL_K2_CHUNK / U; c += blockDim.x) {
+            int cc = 0;
+            for (int u = 0; u < U; ++u) cc |= s_cls[c * U + u];
+            s_chunk[c] = cc;
+        }
+        __syncthreads();
+#ifdef ZL_STAMPS
+        zl_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+        const size_t pbase = (size_t)k * V + vb;
+        for (int c0 = 0; c0 < nv; c0 += U) {
+            const int cc = __builtin_amdgcn_readfirstlane(s_chunk[c0 / U]);
+            if (cc == 0) continue;                                // nobody in this chunk plays (SamplerSynth.cpp:137)
+            if (cc & 2) zl_k2_chunk<MODE, true, U>(A, s_plan, s_vc, s_cls, c0, pbase, vb, f, wantPeak, accL, accR);
+            else        zl_k2_chunk<MODE, false, U>(A, s_plan, s_vc, s_cls, c0, pbase, vb, f, wantPeak, accL, accR);
         }
     }
 
+#ifdef ZL_STAMPS
+    if (threadIdx.x == 0 && A.pos_trace) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(A.pos_trace) + 4 * ((size_t)blockIdx.z * gridDim.y + blockIdx.y);
+        st[0] = zl_t0; st[1] = zl_t1; st[2] = __builtin_amdgcn_s_memrealtime();
+        st[3] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /*XCC_ID*/ | ((unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4) /*HW_ID*/ << 8);
+    }
+#endif
     float *outL, *outR;
     if (A.groups == 1) {
         const size_t KN = (size_t)A.K * N;
@@ -253,6 +431,13 @@ int zl_launch_apply_ops(const ZlBatch &A, hipStream_t s)
 int zl_launch_plan(const ZlBatch &A, int force_slow, hipStream_t s)
 {
     hipLaunchKernelGGL(zl_k1_plan, dim3((A.V + 63) / 64), dim3(64), 0, s, A, force_slow);
+    ZL_LAUNCH_CHECK();
+    return 0;
+}
+
+int zl_launch_expand(const ZlBatch &A, hipStream_t s)
+{
+    hipLaunchKernelGGL(zl_k1b_expand, dim3(512), dim3(A.N < 256 ? A.N : 256), 0, s, A);
     ZL_LAUNCH_CHECK();
     return 0;
 }

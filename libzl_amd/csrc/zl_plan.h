@@ -105,7 +105,8 @@ ZL_HD inline void zl_voice_hard_stop(ZlVoiceState &s)
 // ---- exact linear runs of P += r --------------------------------------------------------------
 // Returns the per-step increment s and the number L >= 0 of consecutive additions starting at P
 // that are guaranteed to equal P + i*s exactly (i = 1..L).  L == 0 means "take one real addition".
-ZL_HD inline void zl_linear_run(double P, double r, double &s, int &L)
+// inv_r = 1 / r (computed once per voice and batch); it only shortens runs conservatively.
+ZL_HD inline void zl_linear_run(double P, double r, double inv_r, double &s, int &L)
 {
     s = 0.0; L = 0;
     const uint64_t pb = zl_bits(P);
@@ -114,7 +115,8 @@ ZL_HD inline void zl_linear_run(double P, double r, double &s, int &L)
     const double u   = zl_from_bits((uint64_t)(ex - 52) << 52);  // ulp(P) = 2^(e-52)
     const double top = zl_from_bits((uint64_t)(ex + 1) << 52);   // 2^(e+1)
     if (!(r > 0.0)) return;
-    const double rq = r / u;                                     // exact power-of-two scaling (or +inf)
+    const double inv_u = zl_from_bits((uint64_t)(2046 - (ex - 52)) << 52);   // 1 / ulp(P), a power of two
+    const double rq = r * inv_u;                                 // exact power-of-two scaling (or +inf)
     const double q  = floor(rq);
     if (!(q < 9007199254740992.0)) return;                       // r >= 2^53 ulps: leaves the binade at once
     const double rho  = r - q * u;                               // r mod u, exact
@@ -133,17 +135,29 @@ ZL_HD inline void zl_linear_run(double P, double r, double &s, int &L)
     // sum stays inside [2^e, 2^(e+1)] where the spacing is u
     const double a = (top - P) - (q + 1.0) * u;                  // exact
     if (a < 0.0) { s = 0.0; return; }
-    const double cnt = floor((a / s) * (1.0 - 0x1p-40)) + 1.0;   // conservative count
+    // count = floor(a / s) + 1, estimated without a division (inv_r ~ 1 / s) and then corrected downwards
+    // exactly: fma(c, s, -a) has the sign of the exact c*s - a
+    double c0 = floor((a * inv_r) * (1.0 - 0x1p-30));
+    if (!(c0 >= 0.0)) c0 = 0.0;
+    for (int it = 0; c0 > 0.0 && fma(c0, s, -a) > 0.0; ++it) {
+        if (it >= 4) {                                           // estimate far off (r tiny against P): divide once
+            c0 = floor(a / s);
+            while (c0 > 0.0 && fma(c0, s, -a) > 0.0) c0 -= 1.0;
+            break;
+        }
+        c0 -= 1.0;
+    }
+    const double cnt = c0 + 1.0;
     L = cnt > (double)ZL_RUN_CAP ? ZL_RUN_CAP : (int)cnt;
 }
 
 // Smallest i in [1, L] with P + i*s >= X (values are exact), or ZL_INF_STEPS.
-ZL_HD inline int zl_steps_to_reach(double P, double s, int L, double X)
+ZL_HD inline int zl_steps_to_reach(double P, double s, double inv_r, int L, double X)
 {
     if (L < 1) return ZL_INF_STEPS;
     if (!(fma((double)L, s, P) >= X)) return ZL_INF_STEPS;
     if (P + s >= X) return 1;
-    double g = ceil((X - P) / s);
+    double g = ceil((X - P) * inv_r);                          // estimate; the exact search below corrects it
     if (!(g >= 1.0)) g = 1.0;
     if (g > (double)L) g = (double)L;
     int i = (int)g;
@@ -220,27 +234,46 @@ ZL_HD inline int zl_sim_block(ZlVoiceState &st, const ZlVoiceBatchConst &c, cons
 
 struct ZlPlanStats { unsigned long long source_bytes, slow_blocks, active_frames; };
 
-// Plans every block of the batch for voice v and leaves the voice state as the reference would
-// after rendering them.  force_slow routes every block through zl_sim_block (test hook).
-ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanStats &stats)
+ZL_HD inline void zl_plan_clear(ZlBlockPlan &pl)
 {
-    const int K = A.K, N = A.N, V = A.V;
-    ZlVoiceState st = A.voices[v];
-    ZlReport rep;
-    rep.playing = 0; rep.valid = 0; rep.peak_bits = 0; rep.progress = 0.0f; rep.clip = -1; rep.pad = 0; rep.P = st.P;
-    stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
+    pl.flags = 0; pl.n_active = 0; pl.nseg = 0; pl.env = 0.0f; pl.P0 = 0.0; pl.step = 0.0;
+    pl.n1 = INT_MAX; pl.pad = 0; pl.P1 = 0.0; pl.step1 = 0.0; pl.pad2 = 0.0;
+}
 
-    int k = 0;
-    if (st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0) {
+// Plans the blocks of a batch for one voice, one block per call (so the caller can feed the clocks
+// from LDS), and leaves the voice state as the reference would after rendering them.
+struct ZlPlanner {
+    ZlVoiceState st;
+    ZlVoiceBatchConst c;
+    ZlPlanStats stats;
+    unsigned long long blockBytes;
+    double X;                    // threshold of the position event that can occur in a fast (sustain) block
+    double inv_r;                // 1 / pitch_ratio
+    double s;                    // current linear run: step, steps left, steps to the position event
+    int L, ie;
+    int v, blocks_done;
+    bool valid, posMode, clockMode, haveRun;
+
+    ZL_HD void begin(const ZlBatch &A, int voice)
+    {
+        v = voice;
+        st = A.voices[v];
+        stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
+        blocks_done = 0;
+        s = 0.0; L = 0; ie = ZL_INF_STEPS; haveRun = false;
+        valid = st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0;
+        posMode = false; clockMode = false; X = INFINITY; blockBytes = 0; inv_r = 0.0;
+        if (!valid) return;
+        inv_r = 1.0 / st.pitch_ratio;
         const ZlClip &cl = A.clips[st.clip];
         const ZlSound sd = A.sounds[st.clip];
         const double sr = sd.sample_rate;
-        ZlVoiceBatchConst c;
         c.start_int = (int)(zl_clip_start(cl, st.slice) * sr);
         c.stop_pos  = (int)(zl_clip_stop(cl, st.slice) * sr);
         c.tail_T    = (double)c.stop_pos - ((double)st.release * sr);
         c.length_ticks = zl_f32_to_u64_sat(cl.length_beats * (float)ZL_BEAT_SUBDIV);
         c.beat_locked = truncf(cl.length_beats) == cl.length_beats;
+        c.clock_ok = 1;
 
         ZlVoiceConst vc;
         vc.src_offset = sd.offset;
@@ -250,123 +283,167 @@ ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanS
         vc.clip_volume = cl.volume_abs;                           // :189
         vc.lpan = (float)(0.5 * (1.0 + (double)cl.pan));          // :193
         vc.rpan = (float)(0.5 * (1.0 - (double)cl.pan));          // :194
-        vc.pad = 0;
+        vc.pad[0] = 0; vc.pad[1] = 0; vc.pad[2] = 0;
         A.vconst[v] = vc;
 
         // algorithmic source bytes of one block of this voice
         const int taps = (A.mode & ZL_MODE_HERMITE) ? 4 : 2;
-        const unsigned long long blockBytes =
-            (unsigned long long)((long long)ceil((double)N * st.pitch_ratio) + taps - 1) * (unsigned long long)sd.channels * 4ull;
+        blockBytes = (unsigned long long)((long long)ceil((double)A.N * st.pitch_ratio) + taps - 1) * (unsigned long long)sd.channels * 4ull;
 
-        const bool posLoop  = st.looping && !c.beat_locked;
-        const bool clockMode = st.looping && c.beat_locked;
-        const bool oneShot  = !st.looping;
-        // threshold of the position event that can occur in a fast (sustain) block
-        const double X = posLoop ? (double)c.stop_pos
-                       : (oneShot ? ((st.release > 0.0f) ? c.tail_T : (double)c.stop_pos) : INFINITY);
-        const bool posMode = posLoop || oneShot;
+        const bool posLoop = st.looping && !c.beat_locked;
+        const bool oneShot = !st.looping;
+        clockMode = st.looping && c.beat_locked;
+        X = posLoop ? (double)c.stop_pos : (oneShot ? ((st.release > 0.0f) ? c.tail_T : (double)c.stop_pos) : INFINITY);
+        posMode = posLoop || oneShot;
+    }
 
-        double s = 0.0; int L = 0; int ie = ZL_INF_STEPS; bool haveRun = false;
+    // Plans block k (clock ck).  Must be called for k = 0, 1, ... in order.
+    ZL_HD void plan_block(const ZlBatch &A, int k, const ZlClock &ck, int force_slow)
+    {
+        const int N = A.N;
+        const size_t pidx = (size_t)k * A.V + v;
+        ZlBlockPlan pl;
+        zl_plan_clear(pl);
+        if (!(valid && st.playing)) { A.plans[pidx] = pl; return; }
+        blocks_done = k + 1;
+        pl.flags = ZL_PLAN_ACTIVE; pl.n_active = N; pl.env = st.sustain; pl.P0 = st.P;
 
-        for (; k < K && st.playing; ++k) {
-            const ZlClock ck = A.clocks[k];
-            const size_t pidx = (size_t)k * V + v;
-            ZlBlockPlan pl;
-            pl.flags = ZL_PLAN_ACTIVE; pl.n_active = N; pl.nseg = 0; pl.env = st.sustain; pl.P0 = st.P; pl.step = 0.0;
+        if (st.next_loop_usecs == 0)                              // :179-182
+            st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
 
-            if (st.next_loop_usecs == 0)                          // :179-182
-                st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
-
-            bool slow = force_slow || st.adsr_state != ZL_ADSR_SUSTAIN
-                        || (clockMode && ck.usecs_per_frame >= (1ull << 21));
-            if (!slow) {
-                // ---- fast block: linear segments ----
-                const ZlVoiceState st0 = st;
-                const double s0 = s; const int L0 = L, ie0 = ie; const bool haveRun0 = haveRun;
-                ZlSegment *segs = A.segs + pidx * (ZL_MAXSEG - 1);
-                int n = 0, nseg = 0;
-                while (n < N) {
-                    if (!haveRun) {
-                        zl_linear_run(st.P, st.pitch_ratio, s, L);
-                        haveRun = true;
-                        ie = posMode ? zl_steps_to_reach(st.P, s, L, X) : ZL_INF_STEPS;
-                    }
-                    if (nseg >= ZL_MAXSEG) { slow = true; break; }
-                    if (nseg == 0) { pl.P0 = st.P; pl.step = s; }
-                    else { ZlSegment sg; sg.P0 = st.P; sg.step = s; sg.n0 = n; sg.pad = 0; segs[nseg - 1] = sg; }
-                    ++nseg;
-                    if (L == 0) {
-                        // one real addition from frame n
-                        const double Pn = st.P + st.pitch_ratio;
-                        const bool ev = posMode ? (Pn >= X)
-                                                : (clockMode ? (zl_clock_event_frame(ck, st.next_loop_usecs, n, N) == n) : false);
-                        n += 1;
-                        haveRun = false;
-                        if (!ev) { st.P = Pn; continue; }
-                    } else {
-                        const int room = N - n;
-                        const int m = L < room ? L : room;
-                        int iclk = ZL_INF_STEPS;
-                        if (clockMode) {
-                            const int fa = zl_clock_event_frame(ck, st.next_loop_usecs, n, N);
-                            if (fa < N) iclk = fa - n + 1;
-                        }
-                        const int iev = ie < iclk ? ie : iclk;
-                        if (iev > m) {
-                            st.P = fma((double)m, s, st.P);
-                            n += m; L -= m;
-                            if (ie != ZL_INF_STEPS) ie -= m;
-                            if (L == 0) haveRun = false;
-                            continue;
-                        }
-                        n += iev;
-                        haveRun = false;
-                    }
-                    // ---- event after rendering frame n-1 ----
-                    if (st.looping) {
-                        zl_loop_restart(st, c, ck, clockMode);
-                    } else if (st.release > 0.0f) {
-                        slow = true;                               // release tail starts inside this block (Q7)
-                        break;
-                    } else {
-                        pl.n_active = n;                           // :249-252, voice ends after frame n-1
-                        zl_voice_hard_stop(st);
-                        break;
-                    }
+        bool slow = force_slow || st.adsr_state != ZL_ADSR_SUSTAIN || (clockMode && ck.usecs_per_frame >= (1ull << 21));
+        // steady state: the current linear run covers the whole block and no loop / stop event falls in it
+        if (!slow && haveRun && L >= N && ie > N
+            && (!clockMode || ck.current_usecs + (uint64_t)(N - 1) * ck.usecs_per_frame < st.next_loop_usecs)) {
+            pl.nseg = 1; pl.step = s;
+            st.P = fma((double)N, s, st.P);
+            L -= N;
+            if (ie != ZL_INF_STEPS) ie -= N;
+            st.env = st.sustain;
+            A.plans[pidx] = pl;
+            stats.source_bytes += blockBytes;
+            stats.active_frames += (unsigned long long)N;
+            return;
+        }
+        if (!slow) {
+            // ---- fast block: linear segments ----
+            const ZlVoiceState st0 = st;
+            const double s0 = s; const int L0 = L, ie0 = ie; const bool haveRun0 = haveRun;
+            ZlSegment *segs = A.segs + pidx * (ZL_MAXSEG - 2);
+            int n = 0, nseg = 0;
+            while (n < N) {
+                if (!haveRun) {
+                    zl_linear_run(st.P, st.pitch_ratio, inv_r, s, L);
+                    haveRun = true;
+                    ie = posMode ? zl_steps_to_reach(st.P, s, inv_r, L, X) : ZL_INF_STEPS;
                 }
-                if (slow) {
-                    st = st0; s = s0; L = L0; ie = ie0; haveRun = haveRun0;
+                if (nseg >= ZL_MAXSEG) { slow = true; break; }
+                if (nseg == 0) { pl.P0 = st.P; pl.step = s; }
+                else if (nseg == 1) { pl.n1 = n; pl.P1 = st.P; pl.step1 = s; }
+                else { ZlSegment sg; sg.P0 = st.P; sg.step = s; sg.n0 = n; sg.pad = 0; segs[nseg - 2] = sg; }
+                ++nseg;
+                if (L == 0) {
+                    // one real addition from frame n
+                    const double Pn = st.P + st.pitch_ratio;
+                    const bool ev = posMode ? (Pn >= X)
+                                            : (clockMode ? (zl_clock_event_frame(ck, st.next_loop_usecs, n, N) == n) : false);
+                    n += 1;
+                    haveRun = false;
+                    if (!ev) { st.P = Pn; continue; }
                 } else {
-                    pl.nseg = nseg;
-                    if (st.playing) st.env = st.sustain;           // the sustain branch assigns envelopeVal every frame
+                    const int room = N - n;
+                    const int m = L < room ? L : room;
+                    int iclk = ZL_INF_STEPS;
+                    if (clockMode) {
+                        const int fa = zl_clock_event_frame(ck, st.next_loop_usecs, n, N);
+                        if (fa < N) iclk = fa - n + 1;
+                    }
+                    const int iev = ie < iclk ? ie : iclk;
+                    if (iev > m) {
+                        st.P = fma((double)m, s, st.P);
+                        n += m; L -= m;
+                        if (ie != ZL_INF_STEPS) ie -= m;
+                        if (L == 0) haveRun = false;
+                        continue;
+                    }
+                    n += iev;
+                    haveRun = false;
+                }
+                // ---- event after rendering frame n-1 ----
+                if (st.looping) {
+                    zl_loop_restart(st, c, ck, clockMode);
+                } else if (st.release > 0.0f) {
+                    slow = true;                                   // release tail starts inside this block (Q7)
+                    break;
+                } else {
+                    pl.n_active = n;                               // :249-252, voice ends after frame n-1
+                    zl_voice_hard_stop(st);
+                    break;
                 }
             }
             if (slow) {
-                pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW;
-                pl.nseg = 0;
-                pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
-                haveRun = false;
-                stats.slow_blocks += 1;
+                st = st0; s = s0; L = L0; ie = ie0; haveRun = haveRun0;
+                pl.n1 = INT_MAX;
+            } else {
+                pl.nseg = nseg;
+                if (st.playing) st.env = st.sustain;               // the sustain branch assigns envelopeVal every frame
+                if (nseg > 2 && A.expand_list) {
+                    // K2 evaluates at most two segments per block: queue this one for K1b, which turns its
+                    // segments into per-frame control (lane-parallel) and marks the block ZL_PLAN_SLOW
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const int slot = atomicAdd(A.expand_count, 1);
+#else
+                    const int slot = (*A.expand_count)++;
+#endif
+                    A.expand_list[slot] = (int32_t)pidx;
+                }
             }
-            A.plans[pidx] = pl;
-            stats.source_bytes += blockBytes;
-            stats.active_frames += (unsigned long long)pl.n_active;
         }
+        if (slow) {
+            pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW;
+            pl.nseg = 0;
+            pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
+            haveRun = false;
+            stats.slow_blocks += 1;
+        }
+        A.plans[pidx] = pl;
+        stats.source_bytes += blockBytes;
+        stats.active_frames += (unsigned long long)pl.n_active;
+    }
+
+    ZL_HD void end(const ZlBatch &A)
+    {
+        ZlReport rep;
+        rep.playing = st.playing; rep.valid = 0; rep.peak_bits = 0; rep.progress = 0.0f; rep.clip = st.clip; rep.pad = 0; rep.P = st.P;
         // :265-267 -- the report of the last block exists only if the voice still has its clip
-        if (k == K && st.playing) {
+        if (valid && st.playing && blocks_done == A.K) {
             rep.valid = 1;
             rep.progress = (float)(st.P / st.src_len);
         }
+        A.reports[v] = rep;
+        A.voices[v] = st;
     }
-    for (; k < K; ++k) {
-        ZlBlockPlan pl; pl.flags = 0; pl.n_active = 0; pl.nseg = 0; pl.env = 0.0f; pl.P0 = 0.0; pl.step = 0.0;
-        A.plans[(size_t)k * V + v] = pl;
-    }
-    rep.playing = st.playing;
-    rep.clip = st.clip;
-    rep.P = st.P;
-    A.reports[v] = rep;
-    A.voices[v] = st;
+};
+
+// K1b body for one frame of one queued block: the position of frame f from the block's segments.
+ZL_HD inline double zl_expand_position(const ZlBlockPlan &pl, const ZlSegment *extra, int f)
+{
+    double P0 = pl.P0, step = pl.step;
+    int n0 = 0;
+    if (f >= pl.n1) { P0 = pl.P1; step = pl.step1; n0 = pl.n1; }
+    for (int i = 0; i + 2 < pl.nseg; ++i)
+        if (f >= extra[i].n0) { P0 = extra[i].P0; step = extra[i].step; n0 = extra[i].n0; }
+    return fma((double)(f - n0), step, P0);                       // exact
+}
+
+// Whole batch of one voice with the clocks read from A.clocks (host harness; the kernel stages them in LDS).
+ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanStats &stats)
+{
+    ZlPlanner pl;
+    pl.begin(A, v);
+    for (int k = 0; k < A.K; ++k) pl.plan_block(A, k, A.clocks[k], force_slow);
+    pl.end(A);
+    stats = pl.stats;
 }
 
 // ---- voice operations (device half of SamplerChannel::handleCommand, SamplerSynth.cpp:187-230) --

@@ -9,9 +9,9 @@
 #include "zl_types.h"
 #include <math.h>
 
-// Position and envelope of frame f of a planned block.
-ZL_HD inline void zl_eval_control(const ZlBlockPlan &pl, const ZlSegment *extra, const double *ctlP,
-                                  const float *ctlEnv, int f, double &P, float &env)
+// Position and envelope of frame f of a planned block (after K1b: at most two inline segments, or
+// per-frame control).
+ZL_HD inline void zl_eval_control(const ZlBlockPlan &pl, const double *ctlP, const float *ctlEnv, int f, double &P, float &env)
 {
     if (pl.flags & ZL_PLAN_SLOW) {
         P = ctlP[f];
@@ -19,12 +19,8 @@ ZL_HD inline void zl_eval_control(const ZlBlockPlan &pl, const ZlSegment *extra,
         return;
     }
     env = pl.env;
-    double P0 = pl.P0, step = pl.step;
-    int n0 = 0;
-    for (int i = 0; i + 1 < pl.nseg; ++i) {          // later segments override earlier ones
-        if (f >= extra[i].n0) { P0 = extra[i].P0; step = extra[i].step; n0 = extra[i].n0; }
-    }
-    P = fma((double)(f - n0), step, P0);             // exact (see zl_plan.h)
+    const bool seg1 = f >= pl.n1;
+    P = fma((double)(f - (seg1 ? pl.n1 : 0)), seg1 ? pl.step1 : pl.step, seg1 ? pl.P1 : pl.P0);   // exact (see zl_plan.h)
 }
 
 ZL_HD inline float zl_hermite4(float y0, float y1, float y2, float y3, float a)
@@ -35,61 +31,71 @@ ZL_HD inline float zl_hermite4(float y0, float y1, float y2, float y3, float a)
     return y1 + a * (c1 + a * (c2 + a * c3));
 }
 
+// The gathered samples of one frame: taps pos, pos+1 (and pos-1, pos+2 for Hermite) of both channels.
+struct ZlTaps {
+    float x0l, x0r, x1l, x1r;       // pos, pos+1
+    float xml, xmr, x2l, x2r;       // pos-1, pos+2 (Hermite only)
+};
+
+// :198-199 -- integer position and fractional part
+ZL_HD inline void zl_split_position(double P, int &pos, float &alpha)
+{
+    pos = (int)P;
+    alpha = (float)(P - (double)pos);
+}
+
+// :204-211 on gathered taps.  inb = guard of :204 (Q5); wide = all four Hermite taps are inside the
+// source; stereo = the source has a second channel.  Returns the panned (l', r') of :210-211.
+template <uint32_t MODE>
+ZL_HD inline void zl_mix_frame(const ZlTaps &t, float alpha, bool inb, bool wide, bool stereo,
+                               float lgain, float rgain, float env, float vol, float lpan, float rpan,
+                               float &lout, float &rout)
+{
+    const float invAlpha = 1.0f - alpha;                         // :200
+    float l, r;
+    if (MODE & ZL_MODE_HERMITE) {
+        // build-defined extension: Catmull-Rom with whole-sample gain, linear at the source edges
+        const float sl = wide ? zl_hermite4(t.xml, t.x0l, t.x1l, t.x2l, alpha) : (t.x0l * invAlpha + t.x1l * alpha);
+        const float sr = wide ? zl_hermite4(t.xmr, t.x0r, t.x1r, t.x2r, alpha) : (t.x0r * invAlpha + t.x1r * alpha);
+        l = sl * lgain * env * vol;
+        r = sr * rgain * env * vol;
+    } else if (MODE & ZL_MODE_FIX_GAIN) {
+        l = (t.x0l * invAlpha + t.x1l * alpha) * lgain * env * vol;
+        r = (t.x0r * invAlpha + t.x1r * alpha) * rgain * env * vol;
+    } else {
+        // :204-205 -- quirk Q1: the gain chain multiplies only the second tap
+        l = t.x0l * invAlpha + t.x1l * alpha * lgain * env * vol;
+        r = t.x0r * invAlpha + t.x1r * alpha * rgain * env * vol;
+    }
+    if (!inb) l = 0.0f;
+    if (!(stereo && inb)) r = l;                                 // :205 mono source / out of range: r = l
+    const float mSignal = 0.5f * (l + r);                        // :208 (0.5 * float in double, exact)
+    const float sSignal = l - r;                                 // :209
+    lout = lpan * mSignal + sSignal;                             // :210
+    rout = rpan * mSignal - sSignal;                             // :211
+}
+
+// Host-side convenience used by tests/cpu_harness: gather + mix for one (voice, frame).
 // src points at the voice's source in the arena (interleaved stereo or mono).
-// Returns the panned (l', r') of :210-211 and pos of :198.
 template <uint32_t MODE>
 ZL_HD inline void zl_render_frame(const ZlVoiceConst &vc, const float *src, double P, float env,
                                   float &lout, float &rout, int &pos_out)
 {
-    const int pos = (int)P;                                      // :198
-    const float alpha = (float)(P - (double)pos);                // :199
-    const float invAlpha = 1.0f - alpha;                         // :200
-    const bool inb = vc.sample_duration > pos && pos >= 0;       // :204 guard (Q5); pos < 0 cannot occur for P >= 0
-    const int p = inb ? pos : 0;
+    int pos; float alpha;
+    zl_split_position(P, pos, alpha);
+    const bool inb = vc.sample_duration > pos && pos >= 0;       // :204 guard; pos < 0 cannot occur for P >= 0
     const bool stereo = vc.channels > 1;
-    float l, r;
-    if (MODE & ZL_MODE_HERMITE) {
-        const bool wide = inb && (pos - 1 >= 0) && (pos + 2 <= vc.sample_duration);
-        float sl, sr;
-        if (stereo) {
-            const float x0l = src[2 * p], x0r = src[2 * p + 1], x1l = src[2 * p + 2], x1r = src[2 * p + 3];
-            if (wide) {
-                sl = zl_hermite4(src[2 * p - 2], x0l, x1l, src[2 * p + 4], alpha);
-                sr = zl_hermite4(src[2 * p - 1], x0r, x1r, src[2 * p + 5], alpha);
-            } else {
-                sl = x0l * invAlpha + x1l * alpha;
-                sr = x0r * invAlpha + x1r * alpha;
-            }
-        } else {
-            const float x0 = src[p], x1 = src[p + 1];
-            sl = wide ? zl_hermite4(src[p - 1], x0, x1, src[p + 2], alpha) : (x0 * invAlpha + x1 * alpha);
-            sr = 0.0f;
-        }
-        l = sl * vc.lgain * env * vc.clip_volume;
-        r = stereo ? (sr * vc.rgain * env * vc.clip_volume) : l;
-        if (!inb) { l = 0.0f; r = 0.0f; }
+    const bool wide = (MODE & ZL_MODE_HERMITE) && inb && (pos - 1 >= 0) && (pos + 2 <= vc.sample_duration);
+    const int p = inb ? pos : 0;
+    ZlTaps t;
+    t.xml = t.xmr = t.x2l = t.x2r = 0.0f;
+    if (stereo) {
+        t.x0l = src[2 * p]; t.x0r = src[2 * p + 1]; t.x1l = src[2 * p + 2]; t.x1r = src[2 * p + 3];
+        if (wide) { t.xml = src[2 * p - 2]; t.xmr = src[2 * p - 1]; t.x2l = src[2 * p + 4]; t.x2r = src[2 * p + 5]; }
     } else {
-        float x0l, x0r, x1l, x1r;
-        if (stereo) {
-            // taps of both channels are 16 contiguous bytes in the interleaved arena
-            x0l = src[2 * p]; x0r = src[2 * p + 1]; x1l = src[2 * p + 2]; x1r = src[2 * p + 3];
-        } else {
-            x0l = src[p]; x1l = src[p + 1]; x0r = 0.0f; x1r = 0.0f;
-        }
-        if (MODE & ZL_MODE_FIX_GAIN) {
-            l = (x0l * invAlpha + x1l * alpha) * vc.lgain * env * vc.clip_volume;
-            r = (x0r * invAlpha + x1r * alpha) * vc.rgain * env * vc.clip_volume;
-        } else {
-            // :204-205 -- quirk Q1: the gain chain multiplies only the second tap
-            l = x0l * invAlpha + x1l * alpha * vc.lgain * env * vc.clip_volume;
-            r = x0r * invAlpha + x1r * alpha * vc.rgain * env * vc.clip_volume;
-        }
-        if (!inb) l = 0.0f;
-        if (!(stereo && inb)) r = l;                             // :205 mono / out-of-range: r = l
+        t.x0l = src[p]; t.x1l = src[p + 1]; t.x0r = 0.0f; t.x1r = 0.0f;
+        if (wide) { t.xml = src[p - 1]; t.x2l = src[p + 2]; }
     }
-    const float mSignal = 0.5f * (l + r);                        // :208 (0.5 * float in double, exact)
-    const float sSignal = l - r;                                 // :209
-    lout = vc.lpan * mSignal + sSignal;                          // :210
-    rout = vc.rpan * mSignal - sSignal;                          // :211
+    zl_mix_frame<MODE>(t, alpha, inb, wide, stereo, vc.lgain, vc.rgain, env, vc.clip_volume, vc.lpan, vc.rpan, lout, rout);
     pos_out = pos;
 }

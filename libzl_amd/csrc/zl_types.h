@@ -78,24 +78,30 @@ struct ZlVoiceOp {
 struct ZlOpRange { int32_t voice, first, count, pad; };
 
 // ---- K1 -> K2 records -------------------------------------------------------------------------
-struct ZlVoiceConst {             // per voice, constant over a batch
+struct ZlVoiceConst {             // per voice, constant over a batch; 48 bytes (3 x 16 for LDS staging)
     uint64_t src_offset;
     int32_t  sample_duration;     // length - 1 (SamplerSynthVoice.cpp:191)
     int32_t  channels;
-    float    lgain, rgain, clip_volume, lpan, rpan;
-    int32_t  pad;
+    float    lgain, rgain, clip_volume, lpan;
+    float    rpan;
+    int32_t  pad[3];
 };
 
 enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2 };
-struct ZlBlockPlan {              // per (block, voice); first linear segment inline
+struct ZlBlockPlan {              // per (block, voice); 64 bytes, the first two linear segments inline
     int32_t flags;
     int32_t n_active;             // frames rendered in this block (N unless the voice stopped inside it)
-    int32_t nseg;                 // >= 1 for fast blocks; extra segments live in the side array
+    int32_t nseg;                 // >= 1 for fast blocks; segments beyond the second live in the side array
     float   env;                  // envelope value of every frame of a fast block (sustain)
     double  P0;                   // position of frame 0
-    double  step;                 // exact per-frame increment inside the segment
+    double  step;                 // exact per-frame increment inside the first segment
+    int32_t n1;                   // first frame of the second segment (INT_MAX when there is none)
+    int32_t pad;
+    double  P1;                   // position of frame n1
+    double  step1;
+    double  pad2;
 };
-struct ZlSegment {                // extra segments [block][voice][ZL_MAXSEG-1]
+struct ZlSegment {                // segments 3.. of a block: [block][voice][ZL_MAXSEG-2]
     double  P0;
     double  step;
     int32_t n0;                   // first frame of the segment
@@ -145,7 +151,7 @@ struct ZlBatch {
     const ZlOpRange    *op_ranges;
     ZlVoiceConst       *vconst;   // [V]
     ZlBlockPlan        *plans;    // [K][V]
-    ZlSegment          *segs;     // [K][V][ZL_MAXSEG-1]
+    ZlSegment          *segs;     // [K][V][ZL_MAXSEG-2]
     double             *ctl_P;    // [K][V][N]   per-frame control of slow blocks
     float              *ctl_env;  // [K][V][N]
     ZlReport           *reports;  // [V]
@@ -154,4 +160,6 @@ struct ZlBatch {
     ZlBlockLevels      *levels;   // [K][B]
     int32_t            *pos_trace;// [K][V][N] or null
     ZlBatchStats       *stats;
+    int32_t            *expand_list;  // [K*V] plan indices whose segments K1b expands into per-frame control
+    int32_t            *expand_count; // [1]
 };

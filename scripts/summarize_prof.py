@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel trace / stats / PMC) into a small per-kernel summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main(root, out):
+    lines = []
+    for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True)):
+        lines.append(f"## kernel stats ({os.path.relpath(f, root)})")
+        with open(f) as fh:
+            for i, row in enumerate(csv.reader(fh)):
+                if i < 12:
+                    lines.append(",".join(row))
+    for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+        dur = defaultdict(list)
+        meta = {}
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("Kernel_Name", "?")
+                dur[name].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                meta[name] = {k: row.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                                                      "Workgroup_Size_X", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")}
+        lines.append(f"## kernel trace ({os.path.relpath(f, root)}): name, calls, avg_ns, min_ns, max_ns, meta")
+        for name, d in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+            lines.append(f"{name[:90]}, {len(d)}, {sum(d) / len(d):.0f}, {min(d)}, {max(d)}, {meta[name]}")
+    for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+        acc = defaultdict(lambda: defaultdict(list))
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                acc[row.get("Kernel_Name", "?")][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", 0)))
+        lines.append(f"## counters ({os.path.relpath(f, root)}): kernel, counter, dispatches, mean per dispatch")
+        for name, cs in acc.items():
+            if "zl_k" not in name:
+                continue
+            for c, vals in sorted(cs.items()):
+                lines.append(f"{name[:60]}, {c}, {len(vals)}, {sum(vals) / len(vals):.1f}")
+    with open(out, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

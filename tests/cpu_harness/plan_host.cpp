@@ -31,7 +31,7 @@ struct ZlSim {
     std::vector<ZlBlockLevels> levels;
     std::vector<int32_t> nsegOut;
     ZlPlanStats stats{};
-    int lastK = 0, lastN = 0;
+    int lastK = 0, lastN = 0; int expanded = 0;
     bool reportsFresh = false;
     void absorb() { if (reportsFresh) { hc.absorb_reports(reports.data()); reportsFresh = false; } }
 };
@@ -58,7 +58,7 @@ static void render_all(ZlSim &S, const ZlBatch &A, float *bus)
                         const ZlVoiceConst &vc = A.vconst[v];
                         const bool act = f < pl.n_active;
                         double P; float env;
-                        zl_eval_control(pl, A.segs + pidx * (ZL_MAXSEG - 1), A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N, act ? f : 0, P, env);
+                        zl_eval_control(pl, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N, act ? f : 0, P, env);
                         float l, r; int pos;
                         zl_render_frame<MODE>(vc, A.arena + vc.src_offset, P, env, l, r, pos);
                         if (act) { accL += l; accR += r; }
@@ -152,7 +152,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     std::vector<ZlClock> ck((size_t)K);
     for (int k = 0; k < K; ++k) ZlHostControl::fill_clock(ck[(size_t)k], clocks[k], N);
     S->plans.assign((size_t)K * V, ZlBlockPlan{});
-    S->segs.assign((size_t)K * V * (ZL_MAXSEG - 1), ZlSegment{});
+    S->segs.assign((size_t)K * V * (ZL_MAXSEG - 2), ZlSegment{});
     S->ctlP.assign((size_t)K * V * N, 0.0); S->ctlEnv.assign((size_t)K * V * N, 0.0f);
     S->trace.assign((size_t)K * V * N, -1);
     S->levels.assign((size_t)K * S->B, ZlBlockLevels{});
@@ -171,11 +171,23 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
         for (int j = 0; j < rg.count; ++j) zl_apply_op(st, ops[(size_t)(rg.first + j)]);
         S->voices[(size_t)rg.voice] = st;
     }
+    std::vector<int32_t> expandList((size_t)K * V); int32_t expandCount = 0;
+    A.expand_list = expandList.data(); A.expand_count = &expandCount;
     S->stats = ZlPlanStats{0, 0, 0};
     for (int v = 0; v < S->V; ++v) {                              // K1
         ZlPlanStats st;
         zl_plan_voice(A, v, force_slow, st);
         S->stats.source_bytes += st.source_bytes; S->stats.slow_blocks += st.slow_blocks; S->stats.active_frames += st.active_frames;
+    }
+    S->expanded = expandCount;
+    for (int e = 0; e < expandCount; ++e) {                       // K1b
+        const size_t pidx = (size_t)expandList[(size_t)e];
+        ZlBlockPlan &pl = S->plans[pidx];
+        for (int f = 0; f < N; ++f) {
+            S->ctlP[pidx * (size_t)N + f] = zl_expand_position(pl, S->segs.data() + pidx * (ZL_MAXSEG - 2), f < pl.n_active ? f : 0);
+            S->ctlEnv[pidx * (size_t)N + f] = pl.env;
+        }
+        pl.flags |= ZL_PLAN_SLOW;
     }
     switch (S->mode & 7u) {                                       // K2 + K3
 #define C(M) case M: render_all<M>(*S, A, bus); break;
@@ -203,6 +215,7 @@ int zlsim_block_peaks(ZlSim *S, int32_t *out)
     for (size_t i = 0; i < S->levels.size(); ++i) { out[2 * i] = S->levels[i].peak_l; out[2 * i + 1] = S->levels[i].peak_r; }
     return 0;
 }
+int zlsim_expanded_blocks(ZlSim *S) { return S->expanded; }
 unsigned long long zlsim_slow_blocks(ZlSim *S) { return S->stats.slow_blocks; }
 unsigned long long zlsim_source_bytes(ZlSim *S) { return S->stats.source_bytes; }
 // segments used by (block, voice) of the last batch (0 for slow / inactive blocks)
@@ -218,7 +231,7 @@ long long zlsim_check_linear_runs(double P0, double r, long long steps, long lon
     long long done = 0, runs = 0;
     while (done < steps) {
         double s; int L;
-        zl_linear_run(P, r, s, L);
+        zl_linear_run(P, r, 1.0 / r, s, L);
         ++runs;
         if (L == 0) {
             P = P + r; Pn = Pn + r; ++done;
@@ -243,8 +256,8 @@ long long zlsim_check_linear_runs(double P0, double r, long long steps, long lon
 int zlsim_steps_to_reach(double P, double r, double X)
 {
     double s; int L;
-    zl_linear_run(P, r, s, L);
-    return zl_steps_to_reach(P, s, L, X);
+    zl_linear_run(P, r, 1.0 / r, s, L);
+    return zl_steps_to_reach(P, s, 1.0 / r, L, X);
 }
 
 }  // extern "C"

@@ -62,7 +62,8 @@ typedef struct zlhip_config {
     uint32_t mode;                   /* ZLHIP_MODE_* */
     double   playback_sample_rate;   /* jack_get_sample_rate, SamplerSynth.cpp:271-272 */
     uint64_t sound_arena_bytes;      /* HBM reserved for decoded sources */
-    int32_t  voices_per_task;        /* 0 = auto; voices summed sequentially by one wavefront (mix group) */
+    int32_t  voices_per_task;        /* voices summed sequentially by one wavefront (mix group); 0 = the whole bus,
+                                        i.e. the reference's order.  Smaller groups = two-level order, more parallelism */
     int32_t  reserved;
 } zlhip_config;
 

@@ -40,8 +40,8 @@ struct zlhip_engine {
     // HBM
     float *arena = nullptr; size_t arenaFloats = 0, arenaUsed = 0;
     ZlSound *dSounds = nullptr; ZlClip *dClips = nullptr;
-    ZlVoiceState *dVoices = nullptr; ZlVoiceConst *dVconst = nullptr;
-    ZlBlockPlan *dPlans = nullptr; ZlSegment *dSegs = nullptr;
+    ZlVoiceState *dVoices = nullptr; ZlVoiceConst *dVconst = nullptr; ZlRunList *dRuns = nullptr;
+    ZlPlanHdr *dPlanHdr = nullptr; ZlPlanSeg0 *dPlanSeg0 = nullptr; ZlPlanSeg1 *dPlanSeg1 = nullptr; ZlSegment *dSegs = nullptr;
     double *dCtlP = nullptr; float *dCtlEnv = nullptr;
     ZlReport *dReports = nullptr; float *dGain = nullptr;
     float *dPartials = nullptr; float *dBus = nullptr;
@@ -134,7 +134,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dVconst, e->dPlans, e->dSegs, e->dCtlP, e->dCtlEnv,
+    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dVconst, e->dRuns, e->dPlanHdr, e->dPlanSeg0, e->dPlanSeg1, e->dSegs, e->dCtlP, e->dCtlEnv,
                     e->dReports, e->dGain, e->dPartials, e->dBus, e->dLevels, e->dLevelState, e->dClocks, e->dOps,
                     e->dOpRanges, e->dStats, e->dTrace, e->dPass, e->dExpandList, e->dExpandCount };
     for (void *p : dev) if (p) (void)hipFree(p);
@@ -166,9 +166,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) std::snprintf(e->devname, sizeof e->devname, "%s (%s)", prop.name, prop.gcnArchName);
 
     const size_t V = (size_t)e->V, K = (size_t)cfg->max_batch_blocks, N = (size_t)cfg->max_frames, B = (size_t)cfg->num_buses;
-    const int minG = std::min(8, cfg->voices_per_bus);
-    e->maxGroups = cfg->voices_per_task > 0 ? (cfg->voices_per_bus + cfg->voices_per_task - 1) / cfg->voices_per_task
-                                           : (cfg->voices_per_bus + minG - 1) / minG;
+    e->maxGroups = cfg->voices_per_task > 0 ? (cfg->voices_per_bus + cfg->voices_per_task - 1) / cfg->voices_per_task : 1;
     e->arenaFloats = (size_t)(cfg->sound_arena_bytes / sizeof(float));
 
     int rc = ZLHIP_OK;
@@ -181,7 +179,10 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     chk(dalloc(&e->dClips, (size_t)cfg->max_sounds), "clips");
     chk(dalloc(&e->dVoices, V), "voices");
     chk(dalloc(&e->dVconst, V), "vconst");
-    chk(dalloc(&e->dPlans, K * V), "plans");
+    chk(dalloc(&e->dRuns, V), "run lists");
+    chk(dalloc(&e->dPlanHdr, K * V), "plan headers");
+    chk(dalloc(&e->dPlanSeg0, K * V), "plan segment 0");
+    chk(dalloc(&e->dPlanSeg1, K * V), "plan segment 1");
     chk(dalloc(&e->dSegs, K * V * (ZL_MAXSEG - 2)), "segments");
     chk(dalloc(&e->dCtlP, K * V * N), "ctlP");
     chk(dalloc(&e->dCtlEnv, K * V * N), "ctlEnv");
@@ -356,14 +357,13 @@ int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_cl
 // ---- render ------------------------------------------------------------------------------------
 static int pick_group(const zlhip_engine *e, int K, int N)
 {
+    // voices summed sequentially by one wavefront.  0 = the whole bus, i.e. the reference's summation order
+    // (SamplerSynth.cpp:136-140) whatever the batch shape; smaller groups add parallelism for short batches
+    // of wide buses at the price of a (documented, deterministic) two-level order.
+    (void)K; (void)N;
     const int VPB = e->cfg.voices_per_bus;
     if (e->cfg.voices_per_task > 0) return std::min(e->cfg.voices_per_task, VPB);
-    // auto: keep whole buses in one wavefront (the reference's summation order) once there are enough
-    // workgroups to fill 256 CUs; otherwise split into mix groups of >= 8 voices
-    int G = VPB;
-    const long long tiles = (long long)K * e->cfg.num_buses * std::max(1, N / 256);
-    while (G > 8 && tiles * ((VPB + G - 1) / G) < 1024 && (VPB + (G / 2) - 1) / (G / 2) <= e->maxGroups) G /= 2;
-    return std::max(G, 1);
+    return VPB;
 }
 
 static int upload_ops(zlhip_engine *e, ZlBatch &A, hipStream_t s)
@@ -410,7 +410,7 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     A.groups = (A.VPB + A.G - 1) / A.G;
     A.mode = e->cfg.mode;
     A.clocks = e->dClocks; A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
-    A.voices = e->dVoices; A.vconst = e->dVconst; A.plans = e->dPlans; A.segs = e->dSegs;
+    A.voices = e->dVoices; A.vconst = e->dVconst; A.runs = e->dRuns; A.plan_hdr = e->dPlanHdr; A.plan_seg0 = e->dPlanSeg0; A.plan_seg1 = e->dPlanSeg1; A.segs = e->dSegs;
     A.ctl_P = e->dCtlP; A.ctl_env = e->dCtlEnv; A.reports = e->dReports; A.partials = e->dPartials;
     A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.levels = e->dLevels; A.stats = e->dStats;
     A.trace = 0; A.pos_trace = nullptr;

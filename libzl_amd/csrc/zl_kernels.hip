@@ -49,8 +49,14 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
             for (int i = threadIdx.x; i < nk * (int)(sizeof(ZlClock) / 16); i += blockDim.x) sh[i] = g[i];
         }
         __syncthreads();
-        if (mine)
-            for (int k = 0; k < nk; ++k) pl.plan_block(A, kb + k, s_clk[k], force_slow);
+        if (mine) {
+            for (int k = 0; k < nk;) {
+                const int m = pl.fast_forward(A, kb + k, kb + nk, s_clk + k, force_slow);
+                if (m) { k += m; continue; }
+                pl.plan_block(A, kb + k, s_clk[k], force_slow);
+                ++k;
+            }
+        }
     }
     if (mine) {
         pl.end(A);
@@ -70,14 +76,14 @@ __global__ void __launch_bounds__(256) zl_k1b_expand(const ZlBatch A)
     const int n = *A.expand_count;
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
         const size_t pidx = (size_t)A.expand_list[e];
-        const ZlBlockPlan pl = A.plans[pidx];
+        const ZlBlockPlan pl = zl_plan_load(A, pidx);
         const ZlSegment *extra = A.segs + pidx * (ZL_MAXSEG - 2);
         for (int f = threadIdx.x; f < A.N; f += blockDim.x) {
             A.ctl_P[pidx * (size_t)A.N + f] = zl_expand_position(pl, extra, f < pl.n_active ? f : 0);
             A.ctl_env[pidx * (size_t)A.N + f] = pl.env;
         }
         __syncthreads();
-        if (threadIdx.x == 0) A.plans[pidx].flags = pl.flags | ZL_PLAN_SLOW;
+        if (threadIdx.x == 0) A.plan_hdr[pidx].flags = pl.flags | ZL_PLAN_SLOW;
         __syncthreads();
     }
 }
@@ -219,32 +225,29 @@ __global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
     float accL = 0.0f, accR = 0.0f;
     for (int vb = v0; vb < v1; vb += ZL_K2_CHUNK) {
         const int nv = (v1 - vb < ZL_K2_CHUNK) ? v1 - vb : ZL_K2_CHUNK;
-        // ---- stage the per-voice records of this pass in LDS (one coalesced round trip per workgroup)
+        // ---- stage the per-voice records of this pass in LDS (coalesced; one round trip per workgroup,
+        //      a second one only for voices whose block has a second position segment)
         __syncthreads();
         {
-            const uint4 *gp = reinterpret_cast<const uint4 *>(A.plans + (size_t)k * V + vb);
-            uint4 *sp = reinterpret_cast<uint4 *>(s_plan);
-            for (int i = threadIdx.x; i < nv * (int)(sizeof(ZlBlockPlan) / 16); i += blockDim.x) sp[i] = gp[i];
             const uint4 *gc = reinterpret_cast<const uint4 *>(A.vconst + vb);
             uint4 *sc = reinterpret_cast<uint4 *>(s_vc);
             for (int i = threadIdx.x; i < nv * (int)(sizeof(ZlVoiceConst) / 16); i += blockDim.x) sc[i] = gc[i];
         }
         __syncthreads();
         for (int i = threadIdx.x; i < ZL_K2_CHUNK; i += blockDim.x) {
-            int cls = 0;
-            if (i < nv && (s_plan[i].flags & ZL_PLAN_ACTIVE)) {
-                cls = 1 | ((s_plan[i].flags & ZL_PLAN_SLOW) ? 2 : 0);
-            } else {
-                // idle slot: a harmless voice with no active frame for the branch-free chunk code
-                s_plan[i].flags = 0; s_plan[i].nseg = 1; s_plan[i].env = 0.0f;
-                s_plan[i].n_active = 0; s_plan[i].P0 = 0.0; s_plan[i].step = 0.0; s_plan[i].n1 = 0x7fffffff;
-                s_plan[i].P1 = 0.0; s_plan[i].step1 = 0.0;
+            ZlBlockPlan pl;
+            zl_plan_clear(pl);
+            if (i < nv) pl = zl_plan_lookup(A, k, vb + i, s_vc[i].env);    // implied by a run, explicit, or idle
+            s_plan[i] = pl;                       // idle slots: a harmless record with no active frame
+            s_cls[i] = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < ZL_K2_CHUNK; i += blockDim.x) {
+            if (!(s_cls[i] & 1)) {                // idle slot: neutral voice constants for the branch-free chunk code
                 s_vc[i].src_offset = 0; s_vc[i].sample_duration = 0; s_vc[i].channels = 2;
                 s_vc[i].lgain = s_vc[i].rgain = s_vc[i].clip_volume = s_vc[i].lpan = s_vc[i].rpan = 0.0f;
             }
-            s_cls[i] = cls;
         }
-        __syncthreads();
         for (int c = threadIdx.x; c < ZL_K2_CHUNK / U; c += blockDim.x) {
             int cc = 0;
             for (int u = 0; u < U; ++u) cc |= s_cls[c * U + u];

@@ -240,6 +240,33 @@ ZL_HD inline void zl_plan_clear(ZlBlockPlan &pl)
     pl.n1 = INT_MAX; pl.pad = 0; pl.P1 = 0.0; pl.step1 = 0.0; pl.pad2 = 0.0;
 }
 
+ZL_HD inline void zl_plan_store(const ZlBatch &A, size_t pidx, const ZlBlockPlan &pl)
+{
+    ZlPlanHdr h; h.flags = pl.flags; h.n_active = pl.n_active; h.nseg = pl.nseg; h.env = pl.env;
+    A.plan_hdr[pidx] = h;
+    ZlPlanSeg0 s0; s0.P0 = pl.P0; s0.step = pl.step;
+    A.plan_seg0[pidx] = s0;
+    if (pl.nseg >= 2) {
+        ZlPlanSeg1 s1; s1.P1 = pl.P1; s1.step1 = pl.step1; s1.n1 = pl.n1; s1.pad = 0; s1.pad2 = 0.0;
+        A.plan_seg1[pidx] = s1;
+    }
+}
+
+ZL_HD inline ZlBlockPlan zl_plan_load(const ZlBatch &A, size_t pidx)
+{
+    ZlBlockPlan pl;
+    zl_plan_clear(pl);
+    const ZlPlanHdr h = A.plan_hdr[pidx];
+    pl.flags = h.flags; pl.n_active = h.n_active; pl.nseg = h.nseg; pl.env = h.env;
+    const ZlPlanSeg0 s0 = A.plan_seg0[pidx];
+    pl.P0 = s0.P0; pl.step = s0.step;
+    if (h.nseg >= 2 && !(h.flags & ZL_PLAN_SLOW)) {
+        const ZlPlanSeg1 s1 = A.plan_seg1[pidx];
+        pl.P1 = s1.P1; pl.step1 = s1.step1; pl.n1 = s1.n1;
+    }
+    return pl;
+}
+
 // Plans the blocks of a batch for one voice, one block per call (so the caller can feed the clocks
 // from LDS), and leaves the voice state as the reference would after rendering them.
 struct ZlPlanner {
@@ -253,6 +280,7 @@ struct ZlPlanner {
     int L, ie;
     int v, blocks_done;
     bool valid, posMode, clockMode, haveRun;
+    ZlRunList rl;
 
     ZL_HD void begin(const ZlBatch &A, int voice)
     {
@@ -260,6 +288,7 @@ struct ZlPlanner {
         st = A.voices[v];
         stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
         blocks_done = 0;
+        rl.n = 0; rl.dead_from = 0;
         s = 0.0; L = 0; ie = ZL_INF_STEPS; haveRun = false;
         valid = st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0;
         posMode = false; clockMode = false; X = INFINITY; blockBytes = 0; inv_r = 0.0;
@@ -283,7 +312,8 @@ struct ZlPlanner {
         vc.clip_volume = cl.volume_abs;                           // :189
         vc.lpan = (float)(0.5 * (1.0 + (double)cl.pan));          // :193
         vc.rpan = (float)(0.5 * (1.0 - (double)cl.pan));          // :194
-        vc.pad[0] = 0; vc.pad[1] = 0; vc.pad[2] = 0;
+        vc.env = st.sustain;
+        vc.pad[0] = 0; vc.pad[1] = 0;
         A.vconst[v] = vc;
 
         // algorithmic source bytes of one block of this voice
@@ -297,6 +327,61 @@ struct ZlPlanner {
         posMode = posLoop || oneShot;
     }
 
+    // Steady-state shortcut: while the current linear run covers whole blocks and no loop / stop event
+    // falls in them, consecutive blocks differ only in P0 and are recorded as ONE run (ZlRunList) instead
+    // of per-block plans.  clk points at the clock of block k (beat-locked loops test every block's clock,
+    // SamplerSynthVoice.cpp:232).  Covers blocks k .. k+m-1 (m <= kmax - k) and returns m; 0 = use plan_block.
+    ZL_HD int fast_forward(const ZlBatch &A, int k, int kmax, const ZlClock *clk, int force_slow)
+    {
+        if (!(valid && st.playing) || force_slow || !haveRun || st.adsr_state != ZL_ADSR_SUSTAIN || st.next_loop_usecs == 0)
+            return 0;
+        const int N = A.N;
+        int m = L / N;
+        if (ie != ZL_INF_STEPS) { const int me = (ie - 1) / N; m = me < m ? me : m; }
+        if (m > kmax - k) m = kmax - k;
+        if (m <= 0) return 0;
+        if (clockMode) {
+            int j = 0;
+            for (; j < m; ++j) {
+                const ZlClock &c = clk[j];
+                if (c.usecs_per_frame >= (1ull << 21)) break;
+                if (!(c.current_usecs + (uint64_t)(N - 1) * c.usecs_per_frame < st.next_loop_usecs)) break;   // restart inside block
+            }
+            m = j;
+            if (m <= 0) return 0;
+        }
+        // record: extend the previous run when this one continues it exactly
+        bool recorded = false;
+        if (rl.n > 0) {
+            ZlRun &last = rl.r[rl.n - 1];
+            if (last.k1 == k && last.step == s && fma((double)((k - last.k0) * N), s, last.P) == st.P) { last.k1 = k + m; recorded = true; }
+        }
+        if (!recorded && rl.n < ZL_MAXRUNS) {
+            ZlRun &r = rl.r[rl.n++];
+            r.P = st.P; r.step = s; r.k0 = k; r.k1 = k + m;
+            recorded = true;
+        }
+        if (!recorded) {
+            // run table full: fall back to explicit per-block plans
+            ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE; h.n_active = N; h.nseg = 1; h.env = st.sustain;
+            for (int j = 0; j < m; ++j) {
+                const size_t pidx = (size_t)(k + j) * A.V + v;
+                ZlPlanSeg0 s0; s0.P0 = fma((double)(j * N), s, st.P); s0.step = s;   // exact: inside the linear run
+                A.plan_hdr[pidx] = h;
+                A.plan_seg0[pidx] = s0;
+            }
+        }
+        const int steps = m * N;
+        st.P = fma((double)steps, s, st.P);
+        L -= steps;
+        if (ie != ZL_INF_STEPS) ie -= steps;
+        st.env = st.sustain;
+        blocks_done = k + m;
+        stats.source_bytes += blockBytes * (unsigned long long)m;
+        stats.active_frames += (unsigned long long)steps;
+        return m;
+    }
+
     // Plans block k (clock ck).  Must be called for k = 0, 1, ... in order.
     ZL_HD void plan_block(const ZlBatch &A, int k, const ZlClock &ck, int force_slow)
     {
@@ -304,7 +389,7 @@ struct ZlPlanner {
         const size_t pidx = (size_t)k * A.V + v;
         ZlBlockPlan pl;
         zl_plan_clear(pl);
-        if (!(valid && st.playing)) { A.plans[pidx] = pl; return; }
+        if (!(valid && st.playing)) return;                        // idle blocks are implied by ZlRunList::dead_from
         blocks_done = k + 1;
         pl.flags = ZL_PLAN_ACTIVE; pl.n_active = N; pl.env = st.sustain; pl.P0 = st.P;
 
@@ -320,7 +405,7 @@ struct ZlPlanner {
             L -= N;
             if (ie != ZL_INF_STEPS) ie -= N;
             st.env = st.sustain;
-            A.plans[pidx] = pl;
+            zl_plan_store(A, pidx, pl);
             stats.source_bytes += blockBytes;
             stats.active_frames += (unsigned long long)N;
             return;
@@ -406,7 +491,7 @@ struct ZlPlanner {
             haveRun = false;
             stats.slow_blocks += 1;
         }
-        A.plans[pidx] = pl;
+        zl_plan_store(A, pidx, pl);
         stats.source_bytes += blockBytes;
         stats.active_frames += (unsigned long long)pl.n_active;
     }
@@ -422,8 +507,30 @@ struct ZlPlanner {
         }
         A.reports[v] = rep;
         A.voices[v] = st;
+        rl.dead_from = valid ? blocks_done : 0;                    // blocks >= dead_from are idle (voice ended or never played)
+        A.runs[v] = rl;
     }
 };
+
+// The plan of block k of voice v: implied by a run, explicit, or idle.  Used by K2's staging and by K1b.
+ZL_HD inline ZlBlockPlan zl_plan_lookup(const ZlBatch &A, int k, int v, float run_env)
+{
+    ZlBlockPlan pl;
+    zl_plan_clear(pl);
+    const ZlRunList *rl = A.runs + v;
+    if (k >= rl->dead_from) return pl;                            // idle
+    const int n = rl->n;
+    for (int j = 0; j < n; ++j) {
+        const ZlRun r = rl->r[j];
+        if (k >= r.k0 && k < r.k1) {
+            pl.flags = ZL_PLAN_ACTIVE; pl.n_active = A.N; pl.nseg = 1; pl.env = run_env;
+            pl.P0 = fma((double)((k - r.k0) * A.N), r.step, r.P);  // exact: inside the linear run
+            pl.step = r.step;
+            return pl;
+        }
+    }
+    return zl_plan_load(A, (size_t)k * A.V + v);
+}
 
 // K1b body for one frame of one queued block: the position of frame f from the block's segments.
 ZL_HD inline double zl_expand_position(const ZlBlockPlan &pl, const ZlSegment *extra, int f)
@@ -441,7 +548,12 @@ ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanS
 {
     ZlPlanner pl;
     pl.begin(A, v);
-    for (int k = 0; k < A.K; ++k) pl.plan_block(A, k, A.clocks[k], force_slow);
+    for (int k = 0; k < A.K;) {
+        const int m = pl.fast_forward(A, k, A.K, A.clocks + k, force_slow);
+        if (m) { k += m; continue; }
+        pl.plan_block(A, k, A.clocks[k], force_slow);
+        ++k;
+    }
     pl.end(A);
     stats = pl.stats;
 }

@@ -84,10 +84,29 @@ struct ZlVoiceConst {             // per voice, constant over a batch; 48 bytes 
     int32_t  channels;
     float    lgain, rgain, clip_volume, lpan;
     float    rpan;
-    int32_t  pad[3];
+    float    env;                 // envelope of the implied (run) blocks: the sustain level
+    int32_t  pad[2];
 };
 
 enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2 };
+// Steady-state stretches of a voice inside a batch: blocks [k0, k1) are rendered whole, in sustain, from
+// one linear position run, so their plan is implied: P0(k) = P + (k - k0) * N * step (exact).  K1 records
+// a handful of these per voice instead of K per-block plans; only the blocks around loop restarts,
+// binade crossings and envelope transients get explicit plan records.
+#define ZL_MAXRUNS 6
+struct ZlRun { double P, step; int32_t k0, k1; };
+struct ZlRunList {
+    int32_t n;                    // runs used
+    int32_t dead_from;            // first block in which the voice no longer plays (K if it plays to the end; 0 = idle)
+    ZlRun   r[ZL_MAXRUNS];
+};
+
+// The plan of one (block, voice).  In HBM it is split into three arrays so that K1 (one lane per voice)
+// writes fully coalesced 16-byte lanes: ZlPlanHdr[K][V], ZlPlanSeg0[K][V] and, only for blocks with a
+// second segment, ZlPlanSeg1[K][V].  K2 reassembles this 64-byte record in LDS.
+struct ZlPlanHdr  { int32_t flags, n_active, nseg; float env; };
+struct ZlPlanSeg0 { double P0, step; };
+struct ZlPlanSeg1 { double P1, step1; int32_t n1, pad; double pad2; };
 struct ZlBlockPlan {              // per (block, voice); 64 bytes, the first two linear segments inline
     int32_t flags;
     int32_t n_active;             // frames rendered in this block (N unless the voice stopped inside it)
@@ -150,7 +169,10 @@ struct ZlBatch {
     const ZlVoiceOp    *ops;
     const ZlOpRange    *op_ranges;
     ZlVoiceConst       *vconst;   // [V]
-    ZlBlockPlan        *plans;    // [K][V]
+    ZlRunList          *runs;     // [V]
+    ZlPlanHdr          *plan_hdr; // [K][V] explicit plans (blocks not covered by a run)
+    ZlPlanSeg0         *plan_seg0;// [K][V]
+    ZlPlanSeg1         *plan_seg1;// [K][V] valid where nseg >= 2
     ZlSegment          *segs;     // [K][V][ZL_MAXSEG-2]
     double             *ctl_P;    // [K][V][N]   per-frame control of slow blocks
     float              *ctl_env;  // [K][V][N]

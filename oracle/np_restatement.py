@@ -1,0 +1,438 @@
+"""Independent restatement of libzl's sampler hot path in numpy scalar arithmetic.  TEST INFRASTRUCTURE.
+
+Written from the reference text (paths under /root/reference/lib), not from oracle/zl_oracle.c, so the
+two can be cross-checked: every float operation is an explicit np.float32 / np.float64 scalar
+operation in the order the reference's C++ expressions associate.  Slow (pure Python loops): used on
+small cases only and to generate tests/golden/*.npz.  Parity status: "parity unpinned" (the
+reference has no golden vectors and cannot be built here; see oracle/zl_oracle.h).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+f32 = np.float32
+f64 = np.float64
+
+IDLE, ATTACK, DECAY, SUSTAIN, RELEASE = range(5)
+BEAT_SUBDIVISIONS = 96            # SyncTimer.cpp:95
+MODE_FIX_GAIN, MODE_FIX_DELAY, MODE_HERMITE = 1, 2, 4
+
+
+def _u64(x: int) -> int:
+    return x & 0xFFFFFFFFFFFFFFFF
+
+
+def _f_to_u64(x) -> int:
+    """float -> quint64 as aarch64 fcvtzu (the reference's target): saturating, NaN -> 0."""
+    x = float(x)
+    if not (x > 0.0):
+        return 0
+    if x >= 18446744073709551616.0:
+        return 0xFFFFFFFFFFFFFFFF
+    return int(x)
+
+
+# ---------------------------------------------------------------- juce::ADSR (JUCE 6/7 juce_ADSR.h)
+class ADSR:
+    def __init__(self):
+        self.attack, self.decay, self.sustain, self.release = f32(0.1), f32(0.1), f32(1.0), f32(0.1)
+        self.sr = f64(44100.0)
+        self.env = f32(0.0)
+        self.state = IDLE
+        self._recalc()
+
+    @staticmethod
+    def _rate(distance, t, sr):
+        return f32(f64(distance) / (f64(t) * sr)) if t > f32(0.0) else f32(-1.0)
+
+    def _next_state(self):
+        if self.state == ATTACK:
+            self.state = DECAY if self.decay_rate > f32(0.0) else SUSTAIN
+        elif self.state == DECAY:
+            self.state = SUSTAIN
+        elif self.state == RELEASE:
+            self.reset()
+
+    def _recalc(self):
+        self.attack_rate = self._rate(f32(1.0), self.attack, self.sr)
+        self.decay_rate = self._rate(f32(1.0) - self.sustain, self.decay, self.sr)
+        self.release_rate = self._rate(self.sustain, self.release, self.sr)
+        if ((self.state == ATTACK and self.attack_rate <= f32(0.0))
+                or (self.state == DECAY and (self.decay_rate <= f32(0.0) or self.env <= self.sustain))
+                or (self.state == RELEASE and self.release_rate <= f32(0.0))):
+            self._next_state()
+
+    def set_sample_rate(self, sr):
+        self.sr = f64(sr)
+
+    def set_parameters(self, a, d, s, r):
+        self.attack, self.decay, self.sustain, self.release = f32(a), f32(d), f32(s), f32(r)
+        self._recalc()
+
+    def reset(self):
+        self.env = f32(0.0)
+        self.state = IDLE
+
+    def note_on(self):
+        if self.attack_rate > f32(0.0):
+            self.state = ATTACK
+        elif self.decay_rate > f32(0.0):
+            self.env = f32(1.0)
+            self.state = DECAY
+        else:
+            self.env = self.sustain
+            self.state = SUSTAIN
+
+    def note_off(self):
+        if self.state != IDLE:
+            if self.release > f32(0.0):
+                self.release_rate = f32(f64(self.env) / (f64(self.release) * self.sr))
+                self.state = RELEASE
+            else:
+                self.reset()
+
+    def next(self):
+        if self.state == IDLE:
+            return f32(0.0)
+        if self.state == ATTACK:
+            self.env = f32(self.env + self.attack_rate)
+            if self.env >= f32(1.0):
+                self.env = f32(1.0)
+                self._next_state()
+        elif self.state == DECAY:
+            self.env = f32(self.env - self.decay_rate)
+            if self.env <= self.sustain:
+                self.env = self.sustain
+                self._next_state()
+        elif self.state == SUSTAIN:
+            self.env = self.sustain
+        elif self.state == RELEASE:
+            self.env = f32(self.env - self.release_rate)
+            if self.env <= f32(0.0):
+                self._next_state()
+        return self.env
+
+    def active(self):
+        return self.state != IDLE
+
+
+# ---------------------------------------------------------------- clip / sound / command
+@dataclass
+class Sound:
+    L: np.ndarray
+    R: Optional[np.ndarray]
+    sample_rate: float
+
+    @property
+    def length(self):
+        return int(self.L.shape[0])
+
+
+@dataclass
+class Clip:
+    """Fields of ClipAudioSource::Private the voice reads (ClipAudioSource.cpp:63-82)."""
+    start_sec: np.float32 = f32(0.0)
+    length_sec: np.float32 = f32(-1.0)
+    length_beats: np.float32 = f32(-1.0)
+    volume_abs: np.float32 = f32(1.0)
+    pan: np.float32 = f32(0.0)
+    duration: np.float32 = f32(0.0)
+    root_note: int = 60
+    slice_pos: List[float] = field(default_factory=list)
+    adsr: tuple = (f32(0.0), f32(0.1), f32(1.0), f32(0.05))      # ctor :164-168
+
+    def get_start(self, slice_):                                  # :261-268
+        if -1 < slice_ < len(self.slice_pos):
+            return f32(f64(self.start_sec) + (f64(self.length_sec) * f64(self.slice_pos[slice_])))
+        return self.start_sec
+
+    def get_stop(self, slice_):                                   # :270-277
+        if slice_ > -1 and slice_ + 1 < len(self.slice_pos):
+            return f32(f64(self.start_sec) + (f64(self.length_sec) * f64(self.slice_pos[slice_ + 1])))
+        return f32(self.start_sec + self.length_sec)
+
+    def set_length(self, beat, bpm):                              # :352-360, SyncTimer.cpp:180-183,936-939
+        sub = _f_to_u64(f32(f32(beat) * f32(BEAT_SUBDIVISIONS)))
+        b = min(max(int(bpm), 50), 200)
+        ns = (sub * 60000000000) // (b * BEAT_SUBDIVISIONS)
+        self.length_sec = f32(f32(ns) / f32(1000000000))
+        self.length_beats = f32(beat)
+
+    def set_slices(self, n):                                      # :495-528 from an empty list
+        inc = f64(1.0) / f64(n)
+        pos = f64(0.0)
+        self.slice_pos = []
+        for _ in range(n):
+            self.slice_pos.append(float(pos))
+            pos = f64(pos + inc)
+
+
+@dataclass
+class Command:
+    clip: int = -1
+    midi_note: int = -1
+    midi_channel: int = -1
+    start: bool = False
+    stop: bool = False
+    change_slice: bool = False
+    slice: int = -1
+    looping: bool = False
+    change_looping: bool = False
+    change_volume: bool = False
+    volume: np.float32 = f32(0.0)
+
+    def equivalent(self, o):                                      # ClipCommand.h:33-39
+        return self.clip == o.clip and (
+            (self.change_slice and o.change_slice and self.slice == o.slice)
+            or (not self.change_slice and not o.change_slice and self.midi_note == o.midi_note and self.midi_channel == o.midi_channel))
+
+
+@dataclass
+class Clock:
+    current_usecs: int
+    next_usecs: int
+    playhead: int = 0
+    playhead_usecs: int = 0
+    subbeat_usecs: int = 0
+
+
+# ---------------------------------------------------------------- SamplerSynthVoice
+class Voice:
+    def __init__(self):
+        self.cmd: Optional[Command] = None
+        self.clip: Optional[Clip] = None
+        self.sound: Optional[Sound] = None
+        self.is_playing = False
+        self.start_tick = 0
+        self.next_loop_tick = 0
+        self.next_loop_usecs = 0
+        self.pitch_ratio = f64(0.0)
+        self.P = f64(0.0)
+        self.src_len = f64(0.0)
+        self.lgain = f32(0.0)
+        self.rgain = f32(0.0)
+        self.adsr = ADSR()
+
+    def start_note(self, note, velocity, sound: Sound, clip: Clip, fs):     # SamplerSynthVoice.cpp:110-144
+        self.sound = sound
+        self.pitch_ratio = f64(math.pow(2.0, (note - clip.root_note) / 12.0)) * f64(sound.sample_rate) / f64(fs)
+        self.clip = clip
+        self.src_len = f64(clip.duration) * f64(sound.sample_rate)
+        self.P = f64(int(f64(clip.get_start(self.cmd.slice)) * f64(sound.sample_rate)))
+        self.next_loop_tick = _f_to_u64(f32(f32(self.start_tick) + f32(clip.length_beats * f32(BEAT_SUBDIVISIONS))))
+        self.next_loop_usecs = 0
+        self.lgain = f32(velocity)
+        self.rgain = f32(velocity)
+        self.adsr.reset()
+        self.adsr.set_sample_rate(sound.sample_rate)
+        self.adsr.set_parameters(*clip.adsr)
+        self.adsr.note_on()
+
+    def stop_note(self, tail):                                            # :146-169
+        if tail:
+            self.adsr.note_off()
+        else:
+            self.sound = None
+            self.adsr.reset()
+            self.clip = None
+            if self.cmd is not None:
+                self.cmd = None
+                self.is_playing = False
+            self.next_loop_tick = 0
+            self.next_loop_usecs = 0
+
+    def process(self, L, R, nframes, clk: Clock, mode=0):                  # :174-270
+        """Accumulates into L/R (np.float32 arrays of nframes).  Returns (valid, gain, progress, pos_trace)."""
+        trace = [-1] * nframes
+        if self.sound is None or self.cmd is None:
+            return False, f32(0), f32(0), trace
+        snd, clip = self.sound, self.clip
+        if self.next_loop_usecs == 0:
+            diff = _u64(self.next_loop_tick - clk.playhead)
+            self.next_loop_usecs = _u64(clk.playhead_usecs + _u64(diff * clk.subbeat_usecs))
+        upf = f64((clk.next_usecs - clk.current_usecs) // nframes)
+        peak = f32(0.0)
+        inL, inR = snd.L, snd.R
+        vol = f32(clip.volume_abs)
+        sr = f64(snd.sample_rate)
+        stop_pos = int(f64(clip.get_stop(self.cmd.slice)) * sr)
+        dur = snd.length - 1
+        pan = f32(clip.pan)
+        lpan = f32(f64(0.5) * (f64(1.0) + f64(pan)))
+        rpan = f32(f64(0.5) * (f64(1.0) - f64(pan)))
+        looping = self.cmd.looping
+        fix_gain, fix_delay, hermite = bool(mode & 1), bool(mode & 2), bool(mode & 4)
+        for frame in range(nframes):
+            pos = int(self.P)
+            alpha = f32(self.P - f64(pos))
+            inv = f32(f32(1.0) - alpha)
+            env = self.adsr.next()
+            trace[frame] = pos
+            inb = dur > pos
+            if hermite and inb:
+                wide = pos - 1 >= 0 and pos + 2 <= dur
+
+                def interp(x):
+                    if wide:
+                        y0, y1, y2, y3 = x[pos - 1], x[pos], x[pos + 1], x[pos + 2]
+                        c1 = f32(f32(0.5) * f32(y2 - y0))
+                        c2 = f32(f32(y0 + f32(f32(2.0) * y2)) - f32(f32(f32(0.5) * y3) + f32(f32(2.5) * y1)))
+                        c3 = f32(f32(f32(f32(0.5) * y3) + f32(f32(1.5) * y1)) - f32(f32(f32(0.5) * y0) + f32(f32(1.5) * y2)))
+                        return f32(y1 + f32(alpha * f32(c1 + f32(alpha * f32(c2 + f32(alpha * c3))))))
+                    return f32(f32(x[pos] * inv) + f32(x[pos + 1] * alpha))
+                l = f32(f32(f32(interp(inL) * self.lgain) * env) * vol)
+                r = f32(f32(f32(interp(inR) * self.rgain) * env) * vol) if inR is not None else l
+            elif fix_gain:
+                l = f32(f32(f32(f32(f32(inL[pos] * inv) + f32(inL[pos + 1] * alpha)) * self.lgain) * env) * vol) if inb else f32(0)
+                r = (f32(f32(f32(f32(f32(inR[pos] * inv) + f32(inR[pos + 1] * alpha)) * self.rgain) * env) * vol)
+                     if (inR is not None and inb) else l)
+            else:
+                # :204-205 -- only the second tap carries gain * envelope * volume (Q1)
+                l = (f32(f32(inL[pos] * inv) + f32(f32(f32(f32(inL[pos + 1] * alpha) * self.lgain) * env) * vol)) if inb else f32(0))
+                r = (f32(f32(inR[pos] * inv) + f32(f32(f32(f32(inR[pos + 1] * alpha) * self.rgain) * env) * vol))
+                     if (inR is not None and inb) else l)
+            m = f32(f64(0.5) * f64(f32(l + r)))
+            s = f32(l - r)
+            l = f32(f32(lpan * m) + s)
+            r = f32(f32(rpan * m) - s)
+            g = f32(l + r)
+            if g > peak:
+                peak = g
+            if fix_delay:
+                L[frame] = f32(L[frame] + l)
+                R[frame] = f32(R[frame] + r)
+            elif frame + 1 < nframes:                      # Q2: pre-incremented pointers; last write is out of bounds
+                L[frame + 1] = f32(L[frame + 1] + l)
+                R[frame + 1] = f32(R[frame + 1] + r)
+            self.P = f64(self.P + self.pitch_ratio)
+            if looping:
+                if f32(math.trunc(float(clip.length_beats))) == clip.length_beats:
+                    if _u64(clk.current_usecs + _f_to_u64(f64(frame) * upf)) >= self.next_loop_usecs:
+                        ticks = _f_to_u64(f32(clip.length_beats * f32(BEAT_SUBDIVISIONS)))
+                        self.next_loop_tick = _u64(self.next_loop_tick + ticks)
+                        diff = _u64(self.next_loop_tick - clk.playhead)
+                        self.next_loop_usecs = _u64(clk.playhead_usecs + _u64(diff * clk.subbeat_usecs))
+                        self.P = f64(int(f64(clip.get_start(self.cmd.slice)) * sr))
+                elif self.P >= f64(stop_pos):
+                    self.P = f64(int(f64(clip.get_start(self.cmd.slice)) * sr))
+            else:
+                if self.P >= f64(stop_pos):
+                    self.stop_note(False)
+                    break
+                elif self.P >= f64(stop_pos) - (f64(self.adsr.release) * sr):
+                    self.stop_note(True)
+            if not self.adsr.active():
+                self.stop_note(False)
+                break
+        if self.clip is not None:
+            return True, f32(peak * f32(0.5)), f32(self.P / self.src_len), trace
+        return False, f32(0), f32(0), trace
+
+
+# ---------------------------------------------------------------- SamplerChannel / SamplerSynth
+class Synth:
+    def __init__(self, num_buses, voices_per_bus, fs, mode=0):
+        self.B, self.VPB, self.fs, self.mode = num_buses, voices_per_bus, fs, mode
+        self.voices = [[Voice() for _ in range(voices_per_bus)] for _ in range(num_buses)]
+        self.sounds: List[Sound] = []
+        self.clips: List[Clip] = []
+
+    def register(self, L, R, sr):
+        self.sounds.append(Sound(np.asarray(L, dtype=np.float32), None if R is None else np.asarray(R, dtype=np.float32), sr))
+        c = Clip()
+        c.duration = f32(len(L) / sr)
+        c.length_sec = c.duration
+        c.set_slices(16)
+        self.clips.append(c)
+        return len(self.clips) - 1
+
+    def handle(self, cmd: Command, tick=0):                               # SamplerSynth.cpp:328-341,187-230
+        bus = cmd.midi_channel + 2
+        if bus < 0 or bus >= self.B or not (0 <= cmd.clip < len(self.clips)):
+            return
+        voices = self.voices[bus]
+        snd = self.sounds[cmd.clip]
+        if cmd.stop or cmd.start:
+            if cmd.stop:
+                for v in voices:
+                    if v.sound is snd and v.cmd is not None and v.cmd.equivalent(cmd):
+                        v.stop_note(True)
+            if cmd.start:
+                for v in voices:
+                    if not v.is_playing:
+                        v.cmd = Command(**cmd.__dict__)
+                        v.is_playing = True
+                        v.start_tick = tick
+                        v.start_note(cmd.midi_note, cmd.volume, snd, self.clips[cmd.clip], self.fs)
+                        break
+        else:
+            for v in voices:
+                if v.sound is snd and v.cmd is not None and v.cmd.equivalent(cmd):
+                    if cmd.change_looping:
+                        v.cmd.looping = cmd.looping
+                    if cmd.change_volume:
+                        v.cmd.volume = cmd.volume
+                        v.lgain = f32(cmd.volume)
+                        v.rgain = f32(cmd.volume)
+                    if cmd.change_slice:
+                        v.cmd.slice = cmd.slice
+
+    def process(self, nframes, clk: Clock):                               # SamplerSynth.cpp:116-148
+        L = np.zeros((self.B, nframes), dtype=np.float32)
+        R = np.zeros((self.B, nframes), dtype=np.float32)
+        reports = {}
+        for b in range(self.B):
+            for i, v in enumerate(self.voices[b]):
+                if v.is_playing:
+                    reports[(b, i)] = v.process(L[b], R[b], nframes, clk, self.mode)
+        return L, R, reports
+
+
+# ---------------------------------------------------------------- AudioLevels (AudioLevels.cpp:330-412)
+def sample_to_peak_int(x) -> int:
+    v = abs(float(f32(f32(131072.0) * f32(x))))
+    return int(v)
+
+
+def levels_tick(peak_a, peak_b, L, R):
+    peak_a = max(0, peak_a - 10000)
+    peak_b = max(0, peak_b - 10000)
+    for x in L:
+        peak_a = max(peak_a, sample_to_peak_int(x))
+    for x in R:
+        peak_b = max(peak_b, sample_to_peak_int(x))
+    return peak_a, peak_b
+
+
+def to_dbfs(raw):
+    raw = f32(raw)
+    if raw <= 0:
+        return f32(-200)
+    v = f32(f32(20) * f32(np.log10(raw, dtype=np.float32)))
+    return f32(-200) if v < f32(-200) else v
+
+
+# ---------------------------------------------------------------- JackPassthrough (JackPassthrough.cpp:45-115)
+def passthrough(inL, inR, dry, fx1, fx2, pan, muted):
+    n = len(inL)
+    out = [np.zeros(n, dtype=np.float32) for _ in range(6)]
+    if muted:
+        return out
+    pan = f32(pan)
+    lm = min(f32(f32(1) - pan), f32(1.0))
+    rm = min(f32(f32(1) + pan), f32(1.0))
+    for k, amt in enumerate((f32(dry), f32(fx1), f32(fx2))):
+        if pan == 0 and amt == 0:
+            continue
+        if pan == 0 and amt == 1:
+            out[2 * k][:] = inL
+            out[2 * k + 1][:] = inR
+            continue
+        for f in range(n):
+            out[2 * k][f] = f32(f32(amt * f32(inL[f])) * lm)
+            out[2 * k + 1][f] = f32(f32(amt * f32(inR[f])) * rm)
+    return out

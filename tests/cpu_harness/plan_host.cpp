@@ -22,8 +22,8 @@ struct ZlSim {
     std::vector<ZlSound> sounds;
     std::vector<ZlClip> clips;
     std::vector<ZlVoiceState> voices;
-    std::vector<ZlVoiceConst> vconst;
-    std::vector<ZlBlockPlan> plans;
+    std::vector<ZlVoiceConst> vconst; std::vector<ZlRunList> runs;
+    std::vector<ZlPlanHdr> planHdr; std::vector<ZlPlanSeg0> planSeg0; std::vector<ZlPlanSeg1> planSeg1;
     std::vector<ZlSegment> segs;
     std::vector<double> ctlP; std::vector<float> ctlEnv;
     std::vector<ZlReport> reports;
@@ -53,7 +53,7 @@ static void render_all(ZlSim &S, const ZlBatch &A, float *bus)
                     float accL = 0.0f, accR = 0.0f;
                     for (int v = v0; v < v1; ++v) {
                         const size_t pidx = (size_t)k * V + v;
-                        const ZlBlockPlan &pl = A.plans[pidx];
+                        const ZlBlockPlan pl = zl_plan_lookup(A, k, v, A.vconst[v].env);
                         if (!(pl.flags & ZL_PLAN_ACTIVE)) continue;
                         const ZlVoiceConst &vc = A.vconst[v];
                         const bool act = f < pl.n_active;
@@ -99,7 +99,7 @@ ZlSim *zlsim_create(int B, int VPB, int max_sounds, double fs, uint32_t mode, in
     S->sounds.assign((size_t)max_sounds, ZlSound{0, 0, 0, 0.0});
     S->clips.assign((size_t)max_sounds, ZlClip{});
     S->voices.assign((size_t)S->V, ZlVoiceState{});
-    S->vconst.assign((size_t)S->V, ZlVoiceConst{});
+    S->vconst.assign((size_t)S->V, ZlVoiceConst{}); S->runs.assign((size_t)S->V, ZlRunList{});
     S->reports.assign((size_t)S->V, ZlReport{});
     return S;
 }
@@ -151,7 +151,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     const size_t V = (size_t)S->V;
     std::vector<ZlClock> ck((size_t)K);
     for (int k = 0; k < K; ++k) ZlHostControl::fill_clock(ck[(size_t)k], clocks[k], N);
-    S->plans.assign((size_t)K * V, ZlBlockPlan{});
+    S->planHdr.assign((size_t)K * V, ZlPlanHdr{}); S->planSeg0.assign((size_t)K * V, ZlPlanSeg0{}); S->planSeg1.assign((size_t)K * V, ZlPlanSeg1{});
     S->segs.assign((size_t)K * V * (ZL_MAXSEG - 2), ZlSegment{});
     S->ctlP.assign((size_t)K * V * N, 0.0); S->ctlEnv.assign((size_t)K * V * N, 0.0f);
     S->trace.assign((size_t)K * V * N, -1);
@@ -163,7 +163,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     ZlBatch A; std::memset(&A, 0, sizeof A);
     A.V = S->V; A.B = S->B; A.VPB = S->VPB; A.K = K; A.N = N; A.G = S->G; A.groups = (S->VPB + S->G - 1) / S->G; A.mode = S->mode;
     A.clocks = ck.data(); A.sounds = S->sounds.data(); A.clips = S->clips.data(); A.arena = S->arena.data();
-    A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.plans = S->plans.data(); A.segs = S->segs.data();
+    A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data(); A.segs = S->segs.data();
     A.ctl_P = S->ctlP.data(); A.ctl_env = S->ctlEnv.data(); A.reports = S->reports.data();
 
     for (const ZlOpRange &rg : ranges) {                          // K0
@@ -182,12 +182,12 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     S->expanded = expandCount;
     for (int e = 0; e < expandCount; ++e) {                       // K1b
         const size_t pidx = (size_t)expandList[(size_t)e];
-        ZlBlockPlan &pl = S->plans[pidx];
+        const ZlBlockPlan pl = zl_plan_load(A, pidx);
         for (int f = 0; f < N; ++f) {
             S->ctlP[pidx * (size_t)N + f] = zl_expand_position(pl, S->segs.data() + pidx * (ZL_MAXSEG - 2), f < pl.n_active ? f : 0);
             S->ctlEnv[pidx * (size_t)N + f] = pl.env;
         }
-        pl.flags |= ZL_PLAN_SLOW;
+        S->planHdr[pidx].flags |= ZL_PLAN_SLOW;
     }
     switch (S->mode & 7u) {                                       // K2 + K3
 #define C(M) case M: render_all<M>(*S, A, bus); break;
@@ -219,8 +219,9 @@ int zlsim_expanded_blocks(ZlSim *S) { return S->expanded; }
 unsigned long long zlsim_slow_blocks(ZlSim *S) { return S->stats.slow_blocks; }
 unsigned long long zlsim_source_bytes(ZlSim *S) { return S->stats.source_bytes; }
 // segments used by (block, voice) of the last batch (0 for slow / inactive blocks)
-int zlsim_nseg(ZlSim *S, int k, int v) { return S->plans[(size_t)k * S->V + v].nseg; }
-int zlsim_plan_flags(ZlSim *S, int k, int v) { return S->plans[(size_t)k * S->V + v].flags; }
+int zlsim_nseg(ZlSim *S, int k, int v) { return S->planHdr[(size_t)k * S->V + v].nseg; }
+int zlsim_num_runs(ZlSim *S, int v) { return S->runs[(size_t)v].n; }
+int zlsim_plan_flags(ZlSim *S, int k, int v) { return S->planHdr[(size_t)k * S->V + v].flags; }
 
 // ---- direct fuzz of the exact-linear-run machinery against the naive recurrence -----------------
 // Walks `steps` additions P += r both ways; returns the index of the first mismatch or -1.

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz with the independent numpy restatement (oracle/np_restatement.py).
+
+The reference ships no golden vectors and cannot be built or imported here, so these fixtures pin the
+build's OWN specification: inputs + the outputs of the pure-numpy restatement, against which the C
+oracle (CPU tier) and the HIP engine (GPU tier) are compared bit for bit.  Run from the repo root:
+    python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import np_restatement as nr  # noqa: E402
+
+f32 = np.float32
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def clocks_for(k, nframes, fs, bpm=120, playhead_fn=None):
+    period = int(round(1e6 * nframes / fs))
+    sub = ((60000000000) // (bpm * 96)) // 1000
+    c = nr.Clock(k * period, (k + 1) * period, 0, 0, sub)
+    if playhead_fn:
+        c.playhead, c.playhead_usecs = playhead_fn(k, period, sub)
+    return c
+
+
+def run_scene(name, *, B, VPB, fs, mode, nframes, nblocks, sounds, clips, events, bpm=120, playhead=None):
+    """sounds: list of (L, R|None, sr); clips: list of dict of Clip field overrides; events: {block: [cmd dict + 'tick']}"""
+    syn = nr.Synth(B, VPB, fs, mode)
+    for (L, R, sr), cf in zip(sounds, clips):
+        i = syn.register(L, R, sr)
+        c = syn.clips[i]
+        if "set_length" in cf:
+            c.set_length(*cf["set_length"])
+        for k, v in cf.items():
+            if k == "set_length":
+                continue
+            if k == "adsr":
+                c.adsr = tuple(f32(x) for x in v)
+            elif k == "root_note":
+                c.root_note = int(v)
+            elif k == "slice_pos":
+                c.slice_pos = [float(x) for x in v]
+            else:
+                setattr(c, k, f32(v))
+    busL = np.zeros((B, nblocks * nframes), dtype=np.float32)
+    busR = np.zeros((B, nblocks * nframes), dtype=np.float32)
+    trace = np.full((nblocks, B * VPB, nframes), -1, dtype=np.int32)
+    last_reports = {}
+    clock_rows = []
+    for k in range(nblocks):
+        for ev in events.get(k, []):
+            ev = dict(ev)
+            tick = ev.pop("tick", 0)
+            syn.handle(nr.Command(**{kk: (f32(vv) if kk == "volume" else vv) for kk, vv in ev.items()}), tick)
+        clk = clocks_for(k, nframes, fs, bpm, playhead)
+        clock_rows.append([clk.current_usecs, clk.next_usecs, clk.playhead, clk.playhead_usecs, clk.subbeat_usecs])
+        L, R, reports = syn.process(nframes, clk)
+        busL[:, k * nframes:(k + 1) * nframes] = L
+        busR[:, k * nframes:(k + 1) * nframes] = R
+        for (b, i), (valid, gain, prog, tr) in reports.items():
+            trace[k, b * VPB + i] = tr
+        last_reports = reports
+    V = B * VPB
+    rep = np.zeros((V, 3), dtype=np.float64)      # valid, gain, progress of the last block
+    state = np.zeros((V, 2), dtype=np.float64)    # isPlaying, sourceSamplePosition
+    for b in range(B):
+        for i, v in enumerate(syn.voices[b]):
+            state[b * VPB + i] = (1.0 if v.is_playing else 0.0, float(v.P))
+            if (b, i) in last_reports:
+                valid, gain, prog, _ = last_reports[(b, i)]
+                rep[b * VPB + i] = (1.0 if valid else 0.0, float(gain), float(prog))
+    clip_fields = []
+    for c in syn.clips:
+        clip_fields.append(dict(start_sec=float(c.start_sec), length_sec=float(c.length_sec), length_beats=float(c.length_beats),
+                                volume_abs=float(c.volume_abs), pan=float(c.pan), duration=float(c.duration), root_note=c.root_note,
+                                slice_pos=[float(x) for x in c.slice_pos], adsr=[float(x) for x in c.adsr]))
+    meta = dict(name=name, B=B, VPB=VPB, fs=fs, mode=mode, nframes=nframes, nblocks=nblocks, bpm=bpm,
+                events={str(k): v for k, v in events.items()}, clips=clip_fields,
+                sample_rates=[s[2] for s in sounds], stereo=[s[1] is not None for s in sounds])
+    arrays = dict(meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), busL=busL, busR=busR, trace=trace,
+                  reports=rep, state=state, clocks=np.array(clock_rows, dtype=np.uint64))
+    for i, (L, R, sr) in enumerate(sounds):
+        arrays[f"snd{i}_L"] = np.asarray(L, dtype=np.float32)
+        if R is not None:
+            arrays[f"snd{i}_R"] = np.asarray(R, dtype=np.float32)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: peak |x| = {max(np.abs(busL).max(), np.abs(busR).max()):.4f}  -> {os.path.relpath(path, ROOT)} ({os.path.getsize(path)} bytes)")
+
+
+def main():
+    rng = np.random.default_rng(0x5A17)
+
+    def src(n, stereo=True):
+        L = rng.uniform(-1, 1, n).astype(np.float32)
+        return (L, rng.uniform(-1, 1, n).astype(np.float32) if stereo else None)
+
+    play = lambda clip, ch=-2, loop=True, note=60, vol=1.0, **kw: dict(clip=clip, midi_channel=ch, midi_note=note, start=True, stop=loop,
+                                                                      looping=loop, change_volume=True, volume=vol, **kw)
+    stop = lambda clip, ch=-2, note=60: dict(clip=clip, midi_channel=ch, midi_note=note, stop=True)
+
+    # G1: single mono 44.1 kHz loop, ratio 1, fractional-beat loop (sample-space wrap), default ADSR -- BASELINE config 1 in miniature
+    L, _ = src(1500, stereo=False)
+    run_scene("g1_mono_loop", B=1, VPB=2, fs=44100.0, mode=0, nframes=128, nblocks=16, sounds=[(L, None, 44100.0)],
+              clips=[dict(set_length=(0.0625, 120), volume_abs=1.0, pan=0.0)], events={0: [play(0)]})
+
+    # G2: stereo clips, pitched and resampled (44.1k -> 48k), pan / volume, wraps inside blocks, two buses, slice playback
+    s0, s1, s2 = src(2600), src(1900), src(2200, stereo=False)
+    clips = [dict(set_length=(0.09, 120), volume_abs=0.8, pan=-0.35), dict(set_length=(0.07, 120), volume_abs=0.55, pan=0.6, root_note=62),
+             dict(set_length=(0.083, 120), volume_abs=0.9, pan=0.15)]
+    ev = {0: [play(0, ch=-2, note=63, vol=0.7), play(1, ch=-1, note=57, vol=0.9), play(2, ch=-2, note=60, vol=0.5, change_slice=True, slice=3)]}
+    for mode, nm in ((0, "g2_stereo_pitched"), (3, "g2_stereo_pitched_fixed"), (4, "g2_stereo_pitched_hermite")):
+        run_scene(nm, B=2, VPB=4, fs=48000.0, mode=mode, nframes=128, nblocks=12,
+                  sounds=[(s0[0], s0[1], 44100.0), (s1[0], s1[1], 48000.0), (s2[0], None, 44100.0)], clips=clips, events=ev)
+
+    # G3: one-shot (non-looping) voices: release tail (quirk Q7) and hard stop at the slice end; voice slots free up
+    a, b = src(1400), src(1100, stereo=False)
+    run_scene("g3_oneshot_tail", B=1, VPB=4, fs=48000.0, mode=0, nframes=128, nblocks=14,
+              sounds=[(a[0], a[1], 48000.0), (b[0], None, 48000.0)],
+              clips=[dict(set_length=(0.05, 120), adsr=(0.0, 0.1, 1.0, 0.004)), dict(set_length=(0.04, 120), adsr=(0.0, 0.1, 1.0, 0.0))],
+              events={0: [play(0, loop=False, note=60, vol=0.8), play(1, loop=False, note=67, vol=0.6)], 9: [play(1, loop=False, note=55, vol=1.0)]})
+
+    # G4: beat-locked loop (integer beats): restart driven by the JACK clock against nextLoopUsecs (Q9a)
+    c0 = src(3000)
+    run_scene("g4_beat_locked", B=1, VPB=2, fs=48000.0, mode=0, nframes=128, nblocks=20, bpm=200,
+              sounds=[(c0[0], c0[1], 48000.0)], clips=[dict(length_beats=1.0, length_sec=0.05, volume_abs=0.7, pan=0.2)],
+              events={0: [dict(play(0, note=60, vol=0.9), tick=0)]},
+              playhead=lambda k, period, sub: (0, 0))
+
+    # G5: attack / decay envelope, note-off by stop command (linear release), volume change and restart merge
+    d0 = src(2400)
+    run_scene("g5_adsr_commands", B=1, VPB=3, fs=48000.0, mode=0, nframes=128, nblocks=18,
+              sounds=[(d0[0], d0[1], 48000.0)], clips=[dict(set_length=(0.1, 120), adsr=(0.006, 0.004, 0.6, 0.008), pan=-0.2)],
+              events={0: [play(0, note=60, vol=0.9)],
+                      5: [dict(clip=0, midi_channel=-2, midi_note=60, change_volume=True, volume=0.4)],
+                      8: [stop(0)],
+                      12: [play(0, note=65, vol=0.7)]})
+
+
+if __name__ == "__main__":
+    main()

@@ -195,3 +195,92 @@ def rand_source(rng, length, stereo=True):
     L = rng.uniform(-1, 1, length).astype(np.float32)
     R = rng.uniform(-1, 1, length).astype(np.float32) if stereo else None
     return L, R
+
+
+def random_scene(seed, *, num_buses=3, voices_per_bus=8, nframes=128, nblocks=24, nclips=10, mode=0, mix_group=0,
+                 fs=48000.0, min_len=1500, max_len=6000, events=True):
+    """Seeded mixed scene: looping (sample-space and beat-locked) and one-shot clips, mono and stereo, pitched and
+    resampled, envelopes with attack / decay / release, commands and clip-parameter edits between blocks."""
+    rng = np.random.default_rng(seed)
+    sc = Scene(num_buses=num_buses, voices_per_bus=voices_per_bus, fs=fs, mode=mode, mix_group=mix_group,
+               nframes=nframes, nblocks=nblocks, bpm=int(rng.choice([90, 120, 174])))
+    kinds = []
+    for i in range(nclips):
+        sr = float(rng.choice([44100.0, 48000.0, 22050.0]))
+        n = int(rng.integers(min_len, max_len))
+        L, R = rand_source(rng, n, stereo=bool(rng.random() < 0.7))
+        sc.sounds.append((L, R, sr))
+        kind = ["loop", "loop", "beat", "oneshot"][int(rng.integers(0, 4))]
+        kinds.append(kind)
+        beats = float(rng.uniform(0.03, 0.2)) if kind != "beat" else float(rng.integers(1, 3))
+        vol, pan = float(rng.uniform(0.2, 1.0)), float(rng.uniform(-1, 1))
+        adsr_kind = int(rng.integers(0, 4))
+        start = float(rng.uniform(0, 0.01)) if rng.random() < 0.4 else 0.0
+        dur = n / sr
+
+        def setup(lib, clip, kind=kind, beats=beats, vol=vol, pan=pan, adsr_kind=adsr_kind, start=start, dur=dur):
+            if kind == "beat":
+                clip.lengthInBeats = beats                     # integer beats -> clock-driven restart (Q9a)
+                clip.lengthInSeconds = float(np.float32(dur * 0.6))
+            else:
+                lib.zlo_clip_set_length(clip, C.c_float(beats), 120)
+                if clip.lengthInSeconds > dur * 0.9:
+                    clip.lengthInSeconds = float(np.float32(dur * 0.5))
+            lib.zlo_clip_set_start_position(clip, C.c_float(start))
+            lib.zlo_clip_set_volume_absolute(clip, C.c_float(vol))
+            lib.zlo_clip_set_pan(clip, C.c_float(pan))
+            if adsr_kind == 1:
+                clip.adsr.p.attack, clip.adsr.p.decay, clip.adsr.p.sustain, clip.adsr.p.release = (0.004, 0.003, 0.7, 0.006)
+            elif adsr_kind == 2:
+                clip.adsr.p.attack, clip.adsr.p.decay, clip.adsr.p.sustain, clip.adsr.p.release = (0.0, 0.1, 1.0, 0.0)
+            elif adsr_kind == 3:
+                clip.adsr.p.attack, clip.adsr.p.decay, clip.adsr.p.sustain, clip.adsr.p.release = (0.0, 0.002, 0.5, 0.01)
+        sc.clip_setup[i] = setup
+    ev0 = []
+    for i in range(nclips):
+        ch = int(rng.integers(0, num_buses)) - 2
+        ev0.append(("cmd", play_cmd(i, midi_channel=ch, loop=(kinds[i] != "oneshot"), note=int(rng.integers(52, 70)),
+                                    volume=float(np.float32(rng.uniform(0.2, 1.0))),
+                                    **({"changeSlice": 1, "slice": int(rng.integers(0, 12))} if rng.random() < 0.2 else {})), int(rng.integers(0, 50))))
+    sc.events[0] = ev0
+    if events:
+        for k in sorted(set(int(x) for x in rng.integers(1, nblocks, size=6))):
+            i = int(rng.integers(0, nclips))
+            ch_all = [c for c in range(-2, num_buses - 2)]
+            what = int(rng.integers(0, 4))
+            lst = sc.events.setdefault(k, [])
+            for ch in ch_all:
+                if what == 0:
+                    lst.append(("cmd", stop_cmd(i, midi_channel=ch, note=ev0[i][1]["midiNote"]), 0))
+                elif what == 1:
+                    lst.append(("cmd", dict(clip=i, midiChannel=ch, midiNote=ev0[i][1]["midiNote"], changeVolume=1,
+                                            volume=float(np.float32(rng.uniform(0.1, 1.0)))), 0))
+                elif what == 2:
+                    lst.append(("cmd", play_cmd(i, midi_channel=ch, loop=(kinds[i] != "oneshot"), note=int(rng.integers(55, 66)), volume=0.6), k * 7))
+            if what == 3:
+                newpan, newvol = float(rng.uniform(-1, 1)), float(rng.uniform(0.1, 1))
+
+                def edit(lib, clip, newpan=newpan, newvol=newvol):
+                    lib.zlo_clip_set_pan(clip, C.c_float(newpan))
+                    lib.zlo_clip_set_volume_absolute(clip, C.c_float(newvol))
+                lst.append(("clip", i, edit))
+    return sc
+
+
+def compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, V, *, exact=True, tol=1e-6):
+    """Asserts audio, voice state and reports of a backend run equal the oracle's."""
+    if exact:
+        assert np.array_equal(ref_bus.view(np.int32), bus.view(np.int32)), \
+            f"audio differs: max abs diff {np.abs(ref_bus - bus).max()} at {np.argwhere(ref_bus != bus)[:3].tolist()}"
+    else:
+        scale = max(1.0, float(np.abs(ref_bus).max()))
+        assert np.abs(ref_bus - bus).max() <= tol * scale
+    for v in range(V):
+        ov = ref_syn.voices[v]
+        assert bool(ov.isPlaying) == bool(rep[v].playing), f"voice {v}: isPlaying {ov.isPlaying} vs {rep[v].playing}"
+        if ov.isPlaying:
+            assert ov.sourceSamplePosition == rep[v].source_sample_position, f"voice {v}: position"
+        assert ref_rep[v].valid == rep[v].valid, f"voice {v}: report validity"
+        if ref_rep[v].valid:
+            assert ref_rep[v].gain == rep[v].gain and ref_rep[v].progress == rep[v].progress, \
+                f"voice {v}: report ({ref_rep[v].gain}, {ref_rep[v].progress}) vs ({rep[v].gain}, {rep[v].progress})"

@@ -1,0 +1,238 @@
+"""GPU tier (MI355X): the HIP engine, called through the C-ABI of include/zlhip.h, against the CPU oracle and the
+golden vectors.  Integer / index work and fp32 audio are compared BIT-EXACTLY (the kernels are built with
+-ffp-contract=off and follow the oracle's operation order); the tolerance north_star allows (1e-6 abs per sample)
+is only used where the summation order differs on purpose (mix groups vs the strictly sequential reference)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from golden_util import golden_names, load_golden
+from scenario import (Scene, compare_runs, oracle_trace, play_cmd, rand_source, random_scene, run_backend, run_oracle,
+                      stop_cmd)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; the engine has no CPU path")
+    from libzl_amd import SamplerSynth
+    return SamplerSynth
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("batch", [1, 4, 1 << 30])
+def test_golden_vectors(Engine, name, batch):
+    sc, ex = load_golden(name)
+    bus, rep, syn, trace = run_backend(sc, Engine, batch=batch, trace=True)
+    assert np.array_equal(bus.view(np.int32), ex["bus"].view(np.int32)), f"max diff {np.abs(bus - ex['bus']).max()}"
+    assert np.array_equal(trace, ex["trace"]), "per-frame source index differs"
+    for v in range(sc.num_buses * sc.voices_per_bus):
+        assert bool(rep[v].playing) == bool(ex["state"][v, 0])
+        if rep[v].playing:
+            assert rep[v].source_sample_position == ex["state"][v, 1]
+        assert rep[v].valid == int(ex["reports"][v, 0])
+        if rep[v].valid:
+            assert np.float32(rep[v].gain) == np.float32(ex["reports"][v, 1]) and np.float32(rep[v].progress) == np.float32(ex["reports"][v, 2])
+    syn.close()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_vectors_pipelined_path(Engine, name):
+    """Without the trace (which the debug store adds to the gather loop) and with the per-frame control path forced."""
+    sc, ex = load_golden(name)
+    bus, _, syn, _ = run_backend(sc, Engine, batch=6)
+    assert np.array_equal(bus.view(np.int32), ex["bus"].view(np.int32))
+    syn.close()
+    bus, _, syn, _ = run_backend(sc, Engine, batch=6, force_slow=True)
+    assert np.array_equal(bus.view(np.int32), ex["bus"].view(np.int32))
+    syn.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("mode", [0, 3, 4])
+def test_mixed_scenes_bit_exact(Engine, seed, mode):
+    sc = random_scene(100 + seed, mode=mode, nframes=[64, 128, 256][seed % 3], nblocks=20)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=[1, 3, 7, 1 << 30][seed % 4])
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    syn.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_source_indices_and_batch_split(Engine, seed):
+    sc = random_scene(200 + seed, nframes=128, nblocks=16, events=False)
+    a, _, s1, ta = run_backend(sc, Engine, batch=1, trace=True)
+    b, _, s2, tb = run_backend(sc, Engine, batch=16, trace=True)
+    assert np.array_equal(a.view(np.int32), b.view(np.int32)) and np.array_equal(ta, tb)
+    tr, _ = oracle_trace(sc)
+    assert np.array_equal(ta, tr)          # bit-exact loop-index / wrap arithmetic
+    s1.close(); s2.close()
+
+
+@pytest.mark.parametrize("group", [1, 2, 4])
+def test_mix_groups(Engine, group):
+    sc = random_scene(300 + group, mix_group=group, num_buses=2, voices_per_bus=8, nclips=14, nblocks=10)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=5)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 16)                  # same two-level order: bit-exact
+    sc.mix_group = 0
+    seq_bus, _, _ = run_oracle(sc)
+    tol = 1e-6                                                             # north_star: 1e-6 fp32 per sample
+    assert np.abs(seq_bus - bus).max() <= tol * max(1.0, float(np.abs(seq_bus).max()))
+    syn.close()
+
+
+def test_realtime_process_equals_batch(Engine):
+    """zlhip_render (one JACK cycle, host buffers) gives the same bits as the batched path."""
+    from libzl_amd.engine import synthetic_clocks
+    sc = random_scene(700, nframes=256, nblocks=6, events=False)
+    ref_bus, _, _ = run_oracle(sc)
+    from scenario import snapshot_clip, engine_cmd
+    from oracle import zl_oracle as zo
+    ref = zo.OracleSynth(1, 1, sc.fs, 0, max_sounds=16)
+    syn = Engine(sc.num_buses, sc.voices_per_bus, max_frames=256, max_batch_blocks=4, max_sounds=16, playback_sample_rate=sc.fs)
+    for i, (L, R, sr) in enumerate(sc.sounds):
+        ref.register_clip(L, R, sr); syn.register_clip(L, R, sr)
+        sc.clip_setup[i](ref.lib, ref.clips[i]); syn.set_clip_params(i, snapshot_clip(ref.clips[i]))
+    for ev in sc.events[0]:
+        syn.handle_clip_command(engine_cmd(**ev[1]), ev[2])
+    for k in range(sc.nblocks):
+        L, R = syn.process(256, sc.make_clocks(k, 1)[0])
+        assert np.array_equal(L.view(np.int32), ref_bus[:, 0, k * 256:(k + 1) * 256].view(np.int32))
+        assert np.array_equal(R.view(np.int32), ref_bus[:, 1, k * 256:(k + 1) * 256].view(np.int32))
+    syn.close()
+
+
+def _big_scene(V=1024, B=8, nframes=256, nblocks=24, loop=3000, seed=0x5A19, hermite=False, ratios=False):
+    """BASELINE-sized voice count on short sources so the oracle finishes in seconds."""
+    rng = np.random.default_rng(seed)
+    sc = Scene(num_buses=B, voices_per_bus=V // B, fs=48000.0, nframes=nframes, nblocks=nblocks, mode=4 if hermite else 0)
+    ev = []
+    for v in range(V):
+        L, R = rand_source(rng, loop + int(rng.integers(0, 500)), stereo=True)
+        sc.sounds.append((L, R, 48000.0))
+        vol, pan = float(np.float32(rng.uniform(0.25, 1.0))), float(np.float32(rng.uniform(-1, 1)))
+        ln = float(np.float32((loop - 40 - (v % 17)) / 48000.0))
+
+        def setup(lib, clip, vol=vol, pan=pan, ln=ln):
+            clip.lengthInBeats = 3.5
+            clip.lengthInSeconds = ln
+            clip.volumeAbsolute = vol
+            clip.pan = pan
+        sc.clip_setup[v] = setup
+        note = int(rng.integers(48, 73)) if ratios else 60
+        ev.append(("start", v // (V // B), v % (V // B), play_cmd(v, midi_channel=v // (V // B) - 2, note=note,
+                                                                    volume=float(np.float32(rng.uniform(0.1, 1.0)))), 0))
+    sc.events[0] = ev
+    return sc
+
+
+def test_full_voice_count_bit_exact_against_oracle(Engine):
+    """1024 stereo voices x 256-frame blocks (the BASELINE metric's shape), whole buses summed in voice order."""
+    sc = _big_scene()
+    ref_bus, ref_rep, ref_syn = run_oracle(sc, threads=8)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=24)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 1024)
+    peaks = syn.block_peaks()
+    exp = np.stack([np.abs(np.float32(131072.0) * bus[:, c].reshape(8, 24, 256)).astype(np.int64).max(axis=2) for c in (0, 1)], axis=-1)
+    assert np.array_equal(peaks, exp.transpose(1, 0, 2))                   # AudioLevels integer peaks, every block
+    syn.close()
+
+
+def test_config4_shape_pitched_hermite(Engine):
+    """BASELINE config 4 per-GPU shape: 1024 voices on one bus, pitch 0.5-2x, 4-tap Hermite (build-defined extension)."""
+    sc = _big_scene(V=1024, B=1, nblocks=8, hermite=True, ratios=True, seed=0x5A1B)
+    sc.mix_group = 64
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=8)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 1024)
+    syn.close()
+
+
+def test_size_independent_properties_at_full_size(Engine):
+    """Linearity in the command volume (second tap only, Q1) and determinism across batch splits at 1024 voices."""
+    sc = _big_scene(nblocks=32, seed=0x5A1C)
+    a, _, s1, _ = run_backend(sc, Engine, batch=32)
+    b, _, s2, _ = run_backend(sc, Engine, batch=5)
+    assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    # Q2: first frame of every block is silent, in every bus
+    assert not a.reshape(8, 2, 32, 256)[:, :, :, 0].any()
+    s1.close(); s2.close()
+
+
+def test_voice_stealing_and_slot_reuse(Engine):
+    """One-shots end on the device; their slots must become allocatable again exactly as in the oracle."""
+    sc = random_scene(800, num_buses=1, voices_per_bus=3, nclips=4, nblocks=30, nframes=128, events=False, min_len=900, max_len=1400)
+    for ev in sc.events[0]:
+        ev[1].update(midiChannel=-2, looping=0); ev[1].pop("stopPlayback", None)
+    for k in (6, 12, 18, 24):
+        sc.events[k] = [("cmd", play_cmd(k % 4, midi_channel=-2, loop=False, note=58 + k % 5, volume=0.7), k)]
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=4)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 3)
+    syn.close()
+
+
+def test_levels_tick_matches_oracle(Engine):
+    from oracle import zl_oracle as zo
+    sc = random_scene(900, num_buses=4, nblocks=6, nframes=128, events=False)
+    bus, _, syn, _ = run_backend(sc, Engine, batch=6)
+    lib = zo.load()
+    chans = [zo.LevelsChannel() for _ in range(4)]
+    for k in (2, 5, -2, 5):
+        lv = syn.levels_tick(block_index=k, with_hold_bus=1)
+        for b in range(4):
+            if k == -2:
+                lib.zlo_levels_tick(C.byref(chans[b]), None, None, 0, 1 if b == 1 else 0)
+            else:
+                L = np.ascontiguousarray(bus[b, 0, k * 128:(k + 1) * 128]); R = np.ascontiguousarray(bus[b, 1, k * 128:(k + 1) * 128])
+                lib.zlo_levels_tick(C.byref(chans[b]), L.ctypes.data, R.ctypes.data, 128, 1 if b == 1 else 0)
+            assert (lv[b].peak_a, lv[b].peak_b) == (chans[b].peakA, chans[b].peakB)
+            assert lv[b].peak_db_a == chans[b].peakDbA and lv[b].peak_db_b == chans[b].peakDbB and lv[b].combined_db == chans[b].combinedDb
+            if b == 1:
+                assert lv[b].peak_a_hold_signal == chans[b].peakAHoldSignal and lv[b].hold_db_b == chans[b].holdDbB
+            if k != -2:
+                rms = lib.zlo_block_rms(L.ctypes.data, 128)
+                assert abs(lv[b].rms_a - rms) <= 1e-5 * max(rms, 1e-6)      # build-defined RMS extension: different (tree) sum order
+    syn.close()
+
+
+def test_passthrough_matches_oracle(Engine):
+    import torch
+    from oracle import zl_oracle as zo
+    from libzl_amd import PassthroughParams
+    lib = zo.load()
+    B, n = 3, 1000
+    x = torch.rand((B, 2, n), device="cuda") * 2 - 1
+    out = torch.full((B, 6, n), 7.0, device="cuda")
+    syn = Engine(B, 2, max_frames=64, max_batch_blocks=1, max_sounds=4)
+    params = [PassthroughParams(1.0, 0.0, 0.5, 0.0, 0), PassthroughParams(0.8, 1.0, 1.0, -0.3, 0), PassthroughParams(1.0, 1.0, 1.0, 0.0, 1)]
+    syn.passthrough(params, x.data_ptr(), out.data_ptr(), n)
+    syn.synchronize(); torch.cuda.synchronize()
+    xh, oh = x.cpu().numpy(), out.cpu().numpy()
+    for b in range(B):
+        outs = [np.zeros(n, dtype=np.float32) for _ in range(6)]
+        arr = (C.c_void_p * 6)(*[o.ctypes.data for o in outs])
+        p = zo.Passthrough(params[b].dry_amount, params[b].wet_fx1_amount, params[b].wet_fx2_amount, params[b].pan_amount, params[b].muted)
+        L = np.ascontiguousarray(xh[b, 0]); R = np.ascontiguousarray(xh[b, 1])
+        lib.zlo_passthrough_process(C.byref(p), L.ctypes.data, R.ctypes.data, arr, n)
+        for c in range(6):
+            assert np.array_equal(oh[b, c].view(np.int32), outs[c].view(np.int32)), (b, c)
+    syn.close()
+
+
+def test_errors_are_reported(Engine):
+    from libzl_amd import ZlHipError
+    from libzl_amd.engine import synthetic_clocks
+    syn = Engine(2, 4, max_frames=128, max_batch_blocks=2, max_sounds=2, sound_arena_bytes=1 << 16)
+    with pytest.raises(ZlHipError):
+        syn.render_batch(3, 128, synthetic_clocks(3, 128, 48000.0))        # more blocks than max_batch_blocks
+    with pytest.raises(ZlHipError):
+        syn.render_batch(1, 100, synthetic_clocks(1, 100, 48000.0))        # nframes not a multiple of 64
+    with pytest.raises(ZlHipError):
+        syn.register_clip(np.zeros(1 << 20, dtype=np.float32), None, 48000.0)   # arena full
+    syn.close()

@@ -1,0 +1,118 @@
+/*
+ * libzl_hotpath.h -- the libzl.h-named entry points of the hot path, served by the MI355X engine.
+ *
+ * Same unmangled symbol names, argument orders and (absent) error behaviour as the reference's
+ * extern "C" block (/root/reference/lib/libzl.h:18-179, implemented in lib/libzl.cpp:107-575), for
+ * the functions that feed or read the sampler hot path.  A host that drives libzl through ctypes
+ * (reference test/playtest.py:25-49) binds these exactly as before; handles stay opaque pointers.
+ * Functions of libzl.h that belong to out-of-scope subsystems (SyncTimer scheduling, MIDI routing,
+ * WAV recording, QML registration) are NOT declared here; see INTEGRATION.md for how they keep
+ * linking against the unchanged reference objects.
+ *
+ * Differences that are visible at this boundary:
+ *   - ClipAudioSource_new decodes RIFF/WAVE itself (PCM 8/16/24/32, float32/64; first two channels,
+ *     as SamplerSynthSound.cpp:45) instead of going through JUCE / tracktion.
+ *   - audio is pulled with libzl_hotpath_process() by whoever owns the JACK callback (the reference's
+ *     SamplerChannel::process, SamplerSynth.cpp:116-148) instead of being pushed to JACK from inside.
+ *   - ClipAudioSource_play/stop act on the next rendered block (the reference schedules them through
+ *     SyncTimer with delay 0, ClipAudioSource.cpp:428,437, which is the same block).
+ */
+#ifndef LIBZL_HOTPATH_H
+#define LIBZL_HOTPATH_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#include "zlhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ClipAudioSource ClipAudioSource;
+
+/* ---- ClipAudioSource API bridge (libzl.h:23-61, libzl.cpp:107-302) ------------------------- */
+ClipAudioSource *ClipAudioSource_byID(int id);                                          /* libzl.h:23 */
+ClipAudioSource *ClipAudioSource_new(const char *filepath, bool muted);                 /* libzl.h:24 */
+void ClipAudioSource_setProgressCallback(ClipAudioSource *c, void (*functionPtr)(float)); /* libzl.h:25 */
+void ClipAudioSource_play(ClipAudioSource *c, bool loop);                               /* libzl.h:28 */
+void ClipAudioSource_stop(ClipAudioSource *c);                                          /* libzl.h:29 */
+void ClipAudioSource_playOnChannel(ClipAudioSource *c, bool loop, int midiChannel);     /* libzl.h:30 */
+void ClipAudioSource_stopOnChannel(ClipAudioSource *c, int midiChannel);                /* libzl.h:31 */
+float ClipAudioSource_getDuration(ClipAudioSource *c);                                  /* libzl.h:32 */
+const char *ClipAudioSource_getFileName(ClipAudioSource *c);                            /* libzl.h:33 */
+void ClipAudioSource_setStartPosition(ClipAudioSource *c, float startPositionInSeconds);/* libzl.h:34 */
+void ClipAudioSource_setLength(ClipAudioSource *c, float beat, int bpm);                /* libzl.h:36 */
+void ClipAudioSource_setPan(ClipAudioSource *c, float pan);                             /* libzl.h:37 */
+void ClipAudioSource_setSpeedRatio(ClipAudioSource *c, float speedRatio);               /* libzl.h:38 (stored, unused by the voice: Q11) */
+void ClipAudioSource_setPitch(ClipAudioSource *c, float pitchChange);                   /* libzl.h:39 (stored, unused by the voice: Q11) */
+void ClipAudioSource_setGain(ClipAudioSource *c, float db);                             /* libzl.h:40 (stored, unused by the voice: Q11) */
+void ClipAudioSource_setVolume(ClipAudioSource *c, float vol);                          /* libzl.h:41 */
+void ClipAudioSource_setAudioLevelChangedCallback(ClipAudioSource *c, void (*functionPtr)(float)); /* libzl.h:42 */
+void ClipAudioSource_setSlices(ClipAudioSource *c, int slices);                         /* libzl.h:44 */
+int  ClipAudioSource_keyZoneStart(ClipAudioSource *c);                                  /* libzl.h:45 */
+void ClipAudioSource_setKeyZoneStart(ClipAudioSource *c, int keyZoneStart);             /* libzl.h:46 */
+int  ClipAudioSource_keyZoneEnd(ClipAudioSource *c);                                    /* libzl.h:47 */
+void ClipAudioSource_setKeyZoneEnd(ClipAudioSource *c, int keyZoneEnd);                 /* libzl.h:48 */
+int  ClipAudioSource_rootNote(ClipAudioSource *c);                                      /* libzl.h:49 */
+void ClipAudioSource_setRootNote(ClipAudioSource *c, int rootNote);                     /* libzl.h:50 */
+void ClipAudioSource_destroy(ClipAudioSource *c);                                       /* libzl.h:51 */
+int  ClipAudioSource_id(ClipAudioSource *c);                                            /* libzl.h:52 */
+float ClipAudioSource_adsrAttack(ClipAudioSource *c);                                   /* libzl.h:54 */
+void ClipAudioSource_setADSRAttack(ClipAudioSource *c, float newValue);                 /* libzl.h:55 */
+float ClipAudioSource_adsrDecay(ClipAudioSource *c);                                    /* libzl.h:56 */
+void ClipAudioSource_setADSRDecay(ClipAudioSource *c, float newValue);                  /* libzl.h:57 */
+float ClipAudioSource_adsrSustain(ClipAudioSource *c);                                  /* libzl.h:58 */
+void ClipAudioSource_setADSRSustain(ClipAudioSource *c, float newValue);                /* libzl.h:59 */
+float ClipAudioSource_adsrRelease(ClipAudioSource *c);                                  /* libzl.h:60 */
+void ClipAudioSource_setADSRRelease(ClipAudioSource *c, float newValue);                /* libzl.h:61 */
+
+/* ---- misc (libzl.h:72,84-90) ----------------------------------------------------------------- */
+int  SyncTimer_getMultiplier(void);                                                     /* libzl.h:72, SyncTimer.cpp:946-948 */
+void initJuce(void);                                                                    /* libzl.h:84: brings the engine up (12 channels x 8 voices) */
+void shutdownJuce(void);                                                                /* libzl.h:85 */
+void stopClips(int size, ClipAudioSource **clips);                                      /* libzl.h:89 */
+float dBFromVolume(float vol);                                                          /* libzl.h:90 */
+
+/* ---- JackPassthrough API bridge (libzl.h:117-175, libzl.cpp JackPassthrough_*) --------------- */
+void  JackPassthrough_setPanAmount(int channel, float amount);
+float JackPassthrough_getPanAmount(int channel);
+float JackPassthrough_getWetFx1Amount(int channel);
+void  JackPassthrough_setWetFx1Amount(int channel, float amount);
+float JackPassthrough_getWetFx2Amount(int channel);
+void  JackPassthrough_setWetFx2Amount(int channel, float amount);
+float JackPassthrough_getDryAmount(int channel);
+void  JackPassthrough_setDryAmount(int channel, float amount);
+float JackPassthrough_getMuted(int channel);
+void  JackPassthrough_setMuted(int channel, bool muted);
+
+/* the parameter set of one passthrough client as zlhip_passthrough_process takes it (build-defined) */
+int   JackPassthrough_getParams(int channel, zlhip_passthrough_params *out);
+
+/* ---- build-defined additions (absent in libzl.h) ---------------------------------------------- */
+/* engine configuration used by the next initJuce() (defaults: 12 x 8 voices, 48 kHz, faithful mode) */
+void libzl_hotpath_configure(const zlhip_config *cfg);
+/* 0 if the engine is up, else the zlhip status that initJuce() hit (e.g. ZLHIP_ERR_NO_DEVICE) */
+int  libzl_hotpath_status(void);
+zlhip_engine *libzl_hotpath_engine(void);
+/* a clip from memory instead of a file (planar fp32, right == NULL for mono) */
+ClipAudioSource *ClipAudioSource_newFromBuffer(const float *left, const float *right, int length, double sampleRate, const char *name);
+/* the per-cycle seam: what SamplerChannel::process does for every channel (SamplerSynth.cpp:116-148).
+ * out_left / out_right: [num_buses][nframes].  Afterwards the per-clip positions models are updated from
+ * the voice reports and the progress / audio-level callbacks fire (ClipAudioSource.cpp:88-113,225-240). */
+int  libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right);
+/* ClipAudioSourcePositionsModel read-outs of a clip (ClipAudioSourcePositionsModel.cpp:160-185) */
+float  ClipAudioSource_peakGain(ClipAudioSource *c);
+double ClipAudioSource_firstProgress(ClipAudioSource *c);
+float  ClipAudioSource_volumeAbsolute(ClipAudioSource *c);                              /* ClipAudioSource.cpp:338-346 */
+void   ClipAudioSource_setVolumeAbsolute(ClipAudioSource *c, float vol);                /* ClipAudioSource.cpp:328-336 */
+int    ClipAudioSource_engineClip(ClipAudioSource *c);                                  /* zlhip clip id */
+/* minimal RIFF/WAVE IO (decode side of SamplerSynthSound.cpp:28-59; record side of AudioLevels.cpp:35-119) */
+int  libzl_wav_read(const char *path, float **left, float **right, int *length, double *sampleRate);  /* malloc'd planes; free with libzl_wav_free */
+void libzl_wav_free(float *plane);
+int  libzl_wav_write(const char *path, const float *left, const float *right, int length, double sampleRate, int bitsPerSample /* 16 or 32(float) */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,598 @@
+// zl_libzl.cpp -- the libzl.h-named C-ABI of the hot path (include/libzl_hotpath.h) on top of the engine.
+//
+// Plain C++ restatement of the control-plane pieces of the reference that sit directly on the hot path:
+//   ClipAudioSource parameter setters / getters   lib/ClipAudioSource.cpp:255-277,313-367,495-528,606-700
+//   ClipAudioSource::play / stop                    lib/ClipAudioSource.cpp:415-455
+//   ClipAudioSourcePositionsModel                   lib/ClipAudioSourcePositionsModel.cpp:78-209
+//   level / progress callbacks                      lib/ClipAudioSource.cpp:88-113,225-240
+//   JackPassthrough parameter bridge                lib/libzl.cpp:476-575
+// No Qt, JUCE or tracktion: sources are decoded by the RIFF/WAVE reader below, audio is rendered by
+// the HIP kernels behind zlhip_render, and this file only keeps parameters and forwards commands.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/libzl_hotpath.h"
+
+namespace {
+
+int64_t now_ms()
+{
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- tracktion_engine volume fader curve (third-party, absent from /root/reference; restated from the
+//      public tracktion_engine source, version unpinned): used only by setVolume(dB) / dBFromVolume ----
+float decibelsToVolumeFaderPosition(float db) { return (db > -100.0f) ? std::exp((db - 6.0f) * (1.0f / 20.0f)) : 0.0f; }
+float volumeFaderPositionToDB(float pos) { return (pos > 0.0f) ? (20.0f * std::log(pos)) + 6.0f : -100.0f; }
+float gainToDecibels(float gain) { return gain > 0.0f ? std::max(-100.0f, (float)std::log10(gain) * 20.0f) : -100.0f; }   // juce::Decibels
+double decibelsToGain(double db) { return db > -100.0 ? std::pow(10.0, db * 0.05) : 0.0; }
+
+struct AdsrParams { float attack = 0.1f, decay = 0.1f, sustain = 1.0f, release = 0.1f; };   // juce::ADSR::Parameters defaults
+
+// ClipAudioSourcePositionsModel (ClipAudioSourcePositionsModel.cpp)
+struct PositionsModel {
+    static const int COUNT = 32;                                   // :5
+    struct Row { int64_t id = -1; float progress = 0.0f, gain = 0.0f; int64_t lastUpdated = 0; } rows[COUNT];
+    bool updatePeakGain = false;
+    float peak = 0.0f;
+    void cleanUp(int64_t now)                                      // :191-209
+    {
+        for (Row &r : rows) if (r.id > -1 && r.lastUpdated < now - 1000) { r.id = -1; r.gain = 0.0f; r.progress = 0.0f; }
+    }
+    int64_t create(float initialProgress, int64_t now)             // :78-100
+    {
+        int row = -1; Row *pos = nullptr;
+        for (Row &r : rows) { ++row; if (r.id == -1) { pos = &r; break; } }
+        if (pos) { pos->id = row; pos->progress = initialProgress; pos->lastUpdated = now; updatePeakGain = true; cleanUp(now); }
+        return row;
+    }
+    void set(int64_t id, float gain, float progress, int64_t now)  // :126-138
+    {
+        if (id > -1 && id < COUNT) { rows[id].gain = gain; rows[id].progress = progress; rows[id].lastUpdated = now; updatePeakGain = true; }
+    }
+    void remove(int64_t id, int64_t now)                           // :140-153
+    {
+        if (id > -1 && id < COUNT) { rows[id].id = -1; rows[id].gain = 0.0f; rows[id].progress = 0.0f; updatePeakGain = true; }
+        cleanUp(now);
+    }
+    float peakGain()                                               // :160-173
+    {
+        if (updatePeakGain) {
+            float p = 0.0f;
+            for (Row &r : rows) p = std::max(p, r.gain);
+            if (std::fabs((double)(peak - p)) > 0.01) peak = p;
+            updatePeakGain = false;
+        }
+        return peak;
+    }
+    double firstProgress() const                                   // :175-185
+    {
+        for (const Row &r : rows) if (r.id > -1) return r.progress;
+        return -1.0;
+    }
+};
+
+struct PassState { float dry = 1.0f, fx1 = 1.0f, fx2 = 1.0f, pan = 0.0f; bool muted = false; };   // JackPassthrough.cpp:27-31
+
+}  // namespace
+
+struct ClipAudioSource {
+    int id = 0;
+    int engineClip = -1;
+    std::string fileName, filePath;
+    double sourceSampleRate = 0.0;
+    int lengthFrames = 0;
+    // ClipAudioSource::Private (ClipAudioSource.cpp:63-82)
+    float startPositionInSeconds = 0;
+    float lengthInSeconds = -1;
+    float lengthInBeats = -1;
+    float volumeAbsolute = 1.0f;
+    float pitchChange = 0, speedRatio = 1.0f, gainDb = 0;
+    float pan = 0.0f;
+    float duration = 0.0f;
+    int slices = 0;
+    std::vector<double> slicePositions;
+    int sliceBaseMidiNote = 60, keyZoneStart = 0, keyZoneEnd = 127, rootNote = 60;
+    AdsrParams adsr;
+    PositionsModel positions;
+    void (*progressCb)(float) = nullptr;
+    void (*levelCb)(float) = nullptr;
+    double currentLeveldB = -400.0, prevLeveldB = -400.0, firstPositionProgress = 0.0;
+    int64_t nextGainUpdateTime = 0, nextPositionUpdateTime = 0;
+};
+
+namespace {
+
+struct Global {
+    std::mutex mu;
+    zlhip_config cfg;
+    bool cfgSet = false;
+    zlhip_engine *engine = nullptr;
+    int status = ZLHIP_ERR_STATE;
+    std::vector<ClipAudioSource *> clips;      // createdClips, libzl.cpp:126
+    int nextClipId = 1;                        // libzl.cpp:122
+    std::vector<int64_t> voicePositionId;      // per voice slot: row in its clip's positions model
+    std::vector<ClipAudioSource *> voiceClip;  // per voice slot: clip being played (host view)
+    std::vector<zlhip_voice_report> reports;
+    PassState pass[11];                        // [0] GlobalPlayback (channel -1), [1..10] channels 0..9 (MidiRouter.cpp:876-883)
+} G;
+
+void push_params(ClipAudioSource *c)
+{
+    if (!G.engine || c->engineClip < 0) return;
+    zlhip_clip_params p;
+    std::memset(&p, 0, sizeof p);
+    p.start_position_seconds = c->startPositionInSeconds;
+    p.length_seconds = c->lengthInSeconds;
+    p.length_in_beats = c->lengthInBeats;
+    p.volume_absolute = c->volumeAbsolute;
+    p.pan = c->pan;
+    p.duration_seconds = c->duration;
+    p.adsr_attack = c->adsr.attack; p.adsr_decay = c->adsr.decay; p.adsr_sustain = c->adsr.sustain; p.adsr_release = c->adsr.release;
+    p.root_note = c->rootNote;
+    p.num_slice_positions = (int32_t)std::min<size_t>(c->slicePositions.size(), ZLHIP_MAX_SLICES);
+    for (int i = 0; i < p.num_slice_positions; ++i) p.slice_positions[i] = c->slicePositions[(size_t)i];
+    zlhip_clip_set(G.engine, c->engineClip, &p);
+}
+
+void set_slices(ClipAudioSource *c, int slices)                    // ClipAudioSource.cpp:495-528
+{
+    if (c->slices == slices) return;
+    if (slices == 0) {
+        c->slicePositions.clear();
+    } else if (c->slices > slices) {
+        while ((int)c->slicePositions.size() > slices) c->slicePositions.pop_back();
+    } else {
+        double lastSlicePosition = 0.0f;
+        if (!c->slicePositions.empty()) lastSlicePosition = c->slicePositions.back();
+        double positionIncrement = (1.0f - lastSlicePosition) / (slices - c->slices);
+        double newPosition = lastSlicePosition + positionIncrement;
+        if (c->slicePositions.empty()) c->slicePositions.push_back(0.0f);
+        while ((int)c->slicePositions.size() < slices) { c->slicePositions.push_back(newPosition); newPosition += positionIncrement; }
+    }
+    c->slices = slices;
+}
+
+float subbeat_count_to_seconds(uint64_t bpm, uint64_t beats)       // SyncTimer.cpp:180-183,936-939
+{
+    bpm = std::min<uint64_t>(std::max<uint64_t>(bpm, 50), 200);     // qBound(BPM_MINIMUM, bpm, BPM_MAXIMUM)
+    const uint64_t ns = (beats * 60000000000ULL) / (bpm * (uint64_t)ZLHIP_BEAT_SUBDIVISIONS);
+    return ns / (float)1000000000;
+}
+
+uint64_t f32_to_u64_sat(float f)
+{
+    if (!(f > 0.0f)) return 0;
+    if (f >= 18446744073709551616.0f) return ~0ull;
+    return (uint64_t)f;
+}
+
+ClipAudioSource *make_clip(const float *L, const float *R, int length, double sr, const char *path)
+{
+    ClipAudioSource *c = new ClipAudioSource();
+    c->filePath = path ? path : "";
+    const size_t slash = c->filePath.find_last_of('/');
+    c->fileName = slash == std::string::npos ? c->filePath : c->filePath.substr(slash + 1);
+    c->sourceSampleRate = sr;
+    c->lengthFrames = length;
+    c->duration = (float)(length / sr);                            // edit->getLength(), ClipAudioSource.cpp:158,367
+    c->lengthInSeconds = c->duration;                              // :158
+    c->adsr.attack = 0.0f; c->adsr.release = 0.05f;                // :164-168
+    set_slices(c, 16);                                             // :204
+    if (G.engine) {
+        int32_t id = -1;
+        if (zlhip_sound_upload(G.engine, L, R, length, sr, &id) == ZLHIP_OK) c->engineClip = id;
+    }
+    c->id = G.nextClipId++;                                        // libzl.cpp:122-124
+    G.clips.push_back(c);
+    push_params(c);
+    return c;
+}
+
+void send_command(const zlhip_clip_command &cmd)
+{
+    if (!G.engine) return;
+    // voice slots that take this command: remember which clip they play so reports can be routed back
+    zlhip_handle_command(G.engine, &cmd, 0);
+}
+
+zlhip_clip_command channel_command(ClipAudioSource *c, int midiChannel)   // ClipCommand::channelCommand, ClipCommand.h:66-72
+{
+    zlhip_clip_command cmd;
+    zlhip_clip_command_clear(&cmd);
+    cmd.clip = c->engineClip;
+    cmd.midi_channel = midiChannel;
+    return cmd;
+}
+
+void clip_play(ClipAudioSource *c, bool loop, int midiChannel)     // ClipAudioSource::play, ClipAudioSource.cpp:415-429
+{
+    zlhip_clip_command cmd = channel_command(c, midiChannel);
+    cmd.midi_note = 60;
+    cmd.change_volume = 1;
+    cmd.volume = 1.0f;
+    cmd.looping = loop ? 1 : 0;
+    if (loop) cmd.stop_playback = 1;                               // stops any current loop plays, then starts a new one
+    cmd.start_playback = 1;
+    send_command(cmd);
+}
+
+void clip_stop(ClipAudioSource *c, int midiChannel)                // ClipAudioSource::stop, ClipAudioSource.cpp:431-455
+{
+    if (midiChannel > -3) {
+        zlhip_clip_command cmd = channel_command(c, midiChannel);
+        cmd.midi_note = 60; cmd.stop_playback = 1;
+        send_command(cmd);
+    } else {
+        zlhip_clip_command cmd = channel_command(c, -2);           // noEffectCommand: midi note 60 (ClipCommand.h:44-51)
+        cmd.midi_note = 60; cmd.stop_playback = 1;
+        send_command(cmd);
+        cmd = channel_command(c, -1);                              // effectedCommand
+        cmd.midi_note = 60; cmd.stop_playback = 1;
+        send_command(cmd);
+        for (int i = 0; i < 10; ++i) {
+            cmd = channel_command(c, i);
+            cmd.midi_note = 60; cmd.stop_playback = 1;
+            send_command(cmd);
+        }
+    }
+}
+
+void sync_audio_level(ClipAudioSource *c, int64_t now)             // ClipAudioSource::Private::syncAudioLevel, :88-113
+{
+    if (c->nextGainUpdateTime < now) {
+        c->prevLeveldB = c->currentLeveldB;
+        c->currentLeveldB = gainToDecibels(c->positions.peakGain());   // the tracktion LevelMeasurer client stays silent here
+        const double prevLevel = decibelsToGain(c->prevLeveldB);
+        if (c->prevLeveldB > c->currentLeveldB) c->currentLeveldB = gainToDecibels((float)(prevLevel * 0.94));
+        if (std::fabs(c->currentLeveldB - c->prevLeveldB) > 0.1 && c->levelCb) c->levelCb((float)c->currentLeveldB);
+        c->nextGainUpdateTime = now + 30;
+    }
+}
+
+void sync_progress(ClipAudioSource *c, int64_t now)                // ClipAudioSource::syncProgress, :225-240
+{
+    if (c->nextPositionUpdateTime < now) {
+        double newPosition = c->startPositionInSeconds / c->duration;
+        if (c->progressCb != nullptr && c->positions.firstProgress() > -1.0f) newPosition = c->positions.firstProgress();
+        if (std::fabs(c->firstPositionProgress - newPosition) > 0.001) {
+            c->firstPositionProgress = newPosition;
+            if (c->progressCb) c->progressCb((float)(c->firstPositionProgress * c->duration));
+            c->nextPositionUpdateTime = now + 100;
+        }
+    }
+}
+
+ClipAudioSource *clip_by_engine_id(int engineClip)
+{
+    for (ClipAudioSource *c : G.clips) if (c->engineClip == engineClip) return c;
+    return nullptr;
+}
+
+PassState *pass_for(int channel)                                   // libzl.cpp:476-575 channel mapping
+{
+    if (channel == -1) return &G.pass[0];
+    if (channel > -1 && channel < 10) return &G.pass[channel + 1];
+    return nullptr;
+}
+
+// ---- RIFF / WAVE --------------------------------------------------------------------------------
+uint32_t rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+}  // namespace
+
+extern "C" {
+
+// ---- WAV IO -------------------------------------------------------------------------------------
+int libzl_wav_read(const char *path, float **left, float **right, int *length, double *sampleRate)
+{
+    if (!path || !left || !right || !length || !sampleRate) return ZLHIP_ERR_INVALID;
+    *left = *right = nullptr; *length = 0; *sampleRate = 0.0;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return ZLHIP_ERR_INVALID;
+    std::vector<unsigned char> buf;
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (sz < 44) { std::fclose(f); return ZLHIP_ERR_INVALID; }
+    buf.resize((size_t)sz);
+    const size_t got = std::fread(buf.data(), 1, buf.size(), f);
+    std::fclose(f);
+    if (got != buf.size() || std::memcmp(buf.data(), "RIFF", 4) || std::memcmp(buf.data() + 8, "WAVE", 4)) return ZLHIP_ERR_INVALID;
+    int fmt = 0, channels = 0, bits = 0; uint32_t rate = 0; const unsigned char *data = nullptr; uint32_t dataBytes = 0;
+    for (size_t pos = 12; pos + 8 <= buf.size();) {
+        const uint32_t csz = rd32(&buf[pos + 4]);
+        const unsigned char *body = &buf[pos + 8];
+        if (!std::memcmp(&buf[pos], "fmt ", 4) && csz >= 16 && pos + 8 + 16 <= buf.size()) {
+            fmt = rd16(body); channels = rd16(body + 2); rate = rd32(body + 4); bits = rd16(body + 14);
+            if (fmt == 0xFFFE && csz >= 26) fmt = rd16(body + 24);            // WAVE_FORMAT_EXTENSIBLE sub-format
+        } else if (!std::memcmp(&buf[pos], "data", 4)) {
+            data = body; dataBytes = (uint32_t)std::min<size_t>(csz, buf.size() - (pos + 8));
+        }
+        pos += 8 + (size_t)csz + (csz & 1);
+    }
+    if (!data || channels < 1 || rate == 0 || !(fmt == 1 || fmt == 3)) return ZLHIP_ERR_INVALID;
+    const int bytesPer = bits / 8;
+    if (bytesPer < 1 || bytesPer > 8) return ZLHIP_ERR_INVALID;
+    const int frames = (int)(dataBytes / (uint32_t)(bytesPer * channels));
+    const int outCh = std::min(2, channels);                                   // jmin(2, numChannels), SamplerSynthSound.cpp:45
+    float *planes[2] = { (float *)std::malloc(sizeof(float) * (size_t)std::max(frames, 1)),
+                         outCh > 1 ? (float *)std::malloc(sizeof(float) * (size_t)std::max(frames, 1)) : nullptr };
+    for (int i = 0; i < frames; ++i) {
+        for (int c = 0; c < outCh; ++c) {
+            const unsigned char *p = data + ((size_t)i * channels + c) * bytesPer;
+            float v;
+            if (fmt == 3) {
+                if (bits == 32) { std::memcpy(&v, p, 4); }
+                else { double d; std::memcpy(&d, p, 8); v = (float)d; }
+            } else {
+                // JUCE convention: integer PCM is widened to left-justified int32 and scaled by 1 / 0x7fffffff
+                int32_t s;
+                if (bits == 8) s = ((int32_t)p[0] - 128) << 24;
+                else if (bits == 16) s = (int32_t)((uint32_t)rd16(p) << 16);
+                else if (bits == 24) s = (int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24));
+                else s = (int32_t)rd32(p);
+                v = (float)s * (1.0f / 2147483648.0f);        // JUCE writes 1.0f / 0x7fffffff, which is this float
+            }
+            planes[c][i] = v;
+        }
+    }
+    *left = planes[0]; *right = planes[1]; *length = frames; *sampleRate = (double)rate;
+    return ZLHIP_OK;
+}
+
+void libzl_wav_free(float *plane) { std::free(plane); }
+
+int libzl_wav_write(const char *path, const float *left, const float *right, int length, double sampleRate, int bitsPerSample)
+{
+    if (!path || !left || length < 0 || !(bitsPerSample == 16 || bitsPerSample == 32)) return ZLHIP_ERR_INVALID;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return ZLHIP_ERR_INVALID;
+    const int ch = right ? 2 : 1, bytesPer = bitsPerSample / 8;
+    const uint32_t dataBytes = (uint32_t)length * ch * bytesPer, rate = (uint32_t)sampleRate;
+    unsigned char h[44];
+    auto w32 = [&](int o, uint32_t v) { h[o] = v & 255; h[o + 1] = (v >> 8) & 255; h[o + 2] = (v >> 16) & 255; h[o + 3] = (v >> 24) & 255; };
+    auto w16 = [&](int o, uint16_t v) { h[o] = v & 255; h[o + 1] = (v >> 8) & 255; };
+    std::memcpy(h, "RIFF", 4); w32(4, 36 + dataBytes); std::memcpy(h + 8, "WAVEfmt ", 8); w32(16, 16);
+    w16(20, bitsPerSample == 32 ? 3 : 1); w16(22, (uint16_t)ch); w32(24, rate); w32(28, rate * ch * bytesPer); w16(32, (uint16_t)(ch * bytesPer));
+    w16(34, (uint16_t)bitsPerSample); std::memcpy(h + 36, "data", 4); w32(40, dataBytes);
+    std::fwrite(h, 1, 44, f);
+    for (int i = 0; i < length; ++i) {
+        for (int c = 0; c < ch; ++c) {
+            const float v = c ? right[i] : left[i];
+            if (bitsPerSample == 32) std::fwrite(&v, 4, 1, f);
+            else {
+                const float cl = std::max(-1.0f, std::min(1.0f, v));
+                const int16_t s = (int16_t)std::lrintf(cl * 32767.0f);
+                std::fwrite(&s, 2, 1, f);
+            }
+        }
+    }
+    std::fclose(f);
+    return ZLHIP_OK;
+}
+
+// ---- engine lifecycle -----------------------------------------------------------------------------
+void libzl_hotpath_configure(const zlhip_config *cfg)
+{
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (cfg) { G.cfg = *cfg; G.cfgSet = true; } else G.cfgSet = false;
+}
+
+int libzl_hotpath_status(void) { return G.engine ? ZLHIP_OK : G.status; }
+zlhip_engine *libzl_hotpath_engine(void) { return G.engine; }
+
+void initJuce(void)                                                 // libzl.cpp:358-410
+{
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (G.engine) return;
+    zlhip_config cfg;
+    if (G.cfgSet) cfg = G.cfg;
+    else { zlhip_config_default(&cfg); cfg.max_batch_blocks = 16; }   // 12 channels x 8 voices (SamplerSynth.cpp:254-278)
+    G.status = zlhip_engine_create(&cfg, &G.engine);
+    if (G.status != ZLHIP_OK) {
+        G.engine = nullptr;
+        std::fprintf(stderr, "libzl hot path: engine not available: %s\n", zlhip_strerror(G.status));   // reference logs and carries on
+        return;
+    }
+    const size_t V = (size_t)cfg.num_buses * cfg.voices_per_bus;
+    G.voicePositionId.assign(V, -1);
+    G.voiceClip.assign(V, nullptr);
+    G.reports.assign(V, zlhip_voice_report{});
+    for (ClipAudioSource *c : G.clips) c->engineClip = -1;
+}
+
+void shutdownJuce(void)                                             // libzl.cpp:412-419
+{
+    std::lock_guard<std::mutex> lk(G.mu);
+    for (ClipAudioSource *c : G.clips) delete c;
+    G.clips.clear();
+    if (G.engine) { zlhip_engine_destroy(G.engine); G.engine = nullptr; }
+    G.status = ZLHIP_ERR_STATE;
+    G.nextClipId = 1;
+}
+
+// ---- ClipAudioSource bridge -------------------------------------------------------------------------
+ClipAudioSource *ClipAudioSource_byID(int id)                      // libzl.cpp:107-116
+{
+    for (ClipAudioSource *c : G.clips) if (c->id == id) return c;
+    return nullptr;
+}
+
+ClipAudioSource *ClipAudioSource_newFromBuffer(const float *left, const float *right, int length, double sampleRate, const char *name)
+{
+    if (!left || length < 1 || !(sampleRate > 0.0)) return nullptr;
+    std::lock_guard<std::mutex> lk(G.mu);
+    return make_clip(left, right, length, sampleRate, name ? name : "");
+}
+
+ClipAudioSource *ClipAudioSource_new(const char *filepath, bool muted)   // libzl.cpp:118-128, ClipAudioSource.cpp:135-205
+{
+    float *L = nullptr, *R = nullptr; int n = 0; double sr = 0.0;
+    if (libzl_wav_read(filepath, &L, &R, &n, &sr) != ZLHIP_OK || n < 1) {
+        std::fprintf(stderr, "libzl hot path: cannot open %s\n", filepath ? filepath : "(null)");
+        return nullptr;
+    }
+    ClipAudioSource *c;
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        c = make_clip(L, R, n, sr, filepath);
+    }
+    libzl_wav_free(L); libzl_wav_free(R);
+    if (muted) ClipAudioSource_setVolume(c, -100.0f);              // ClipAudioSource.cpp:178-181
+    return c;
+}
+
+void ClipAudioSource_destroy(ClipAudioSource *c)                   // libzl.cpp:258-267
+{
+    if (!c) return;
+    std::lock_guard<std::mutex> lk(G.mu);
+    clip_stop(c, -3);                                              // ~ClipAudioSource: stop(), ClipAudioSource.cpp:209
+    G.clips.erase(std::remove(G.clips.begin(), G.clips.end(), c), G.clips.end());
+    for (auto &vc : G.voiceClip) if (vc == c) vc = nullptr;
+    // the engine keeps the sound until the voices that still play its release tail are done; the slot is
+    // released lazily by libzl_hotpath_process once no voice reports it
+    c->id = -c->id - 1;
+    G.clips.push_back(c);   // parked (negative id) until its voices ended; see reap in libzl_hotpath_process
+}
+
+int ClipAudioSource_id(ClipAudioSource *c) { return c->id; }
+int ClipAudioSource_engineClip(ClipAudioSource *c) { return c->engineClip; }
+void ClipAudioSource_setProgressCallback(ClipAudioSource *c, void (*functionPtr)(float)) { c->progressCb = functionPtr; }
+void ClipAudioSource_setAudioLevelChangedCallback(ClipAudioSource *c, void (*functionPtr)(float)) { c->levelCb = functionPtr; }
+
+void ClipAudioSource_play(ClipAudioSource *c, bool loop) { std::lock_guard<std::mutex> lk(G.mu); clip_play(c, loop, -2); }            // play(loop) default channel -2
+void ClipAudioSource_stop(ClipAudioSource *c) { std::lock_guard<std::mutex> lk(G.mu); clip_stop(c, -3); }                          // stop() default -3: everywhere
+void ClipAudioSource_playOnChannel(ClipAudioSource *c, bool loop, int midiChannel) { std::lock_guard<std::mutex> lk(G.mu); clip_play(c, loop, midiChannel); }
+void ClipAudioSource_stopOnChannel(ClipAudioSource *c, int midiChannel) { std::lock_guard<std::mutex> lk(G.mu); clip_stop(c, midiChannel); }
+void stopClips(int size, ClipAudioSource **clips) { for (int i = 0; i < size; ++i) ClipAudioSource_stop(clips[i]); }               // libzl.cpp:87-94
+
+float ClipAudioSource_getDuration(ClipAudioSource *c) { return c->duration; }
+const char *ClipAudioSource_getFileName(ClipAudioSource *c) { return c->fileName.c_str(); }
+
+void ClipAudioSource_setStartPosition(ClipAudioSource *c, float s)  // ClipAudioSource.cpp:255-259
+{
+    c->startPositionInSeconds = std::max(0.0f, s);
+    push_params(c);
+}
+
+void ClipAudioSource_setLength(ClipAudioSource *c, float beat, int bpm)   // ClipAudioSource.cpp:352-360
+{
+    c->lengthInSeconds = subbeat_count_to_seconds((uint64_t)bpm, f32_to_u64_sat(beat * ZLHIP_BEAT_SUBDIVISIONS));
+    c->lengthInBeats = beat;
+    push_params(c);
+}
+
+void ClipAudioSource_setPan(ClipAudioSource *c, float pan) { if (c->pan != pan) { c->pan = pan; push_params(c); } }                // :623-629
+void ClipAudioSource_setSpeedRatio(ClipAudioSource *c, float v) { c->speedRatio = v; }                                             // :292-303 (offline re-render, out of scope)
+void ClipAudioSource_setPitch(ClipAudioSource *c, float v) { c->pitchChange = v; }                                                 // :279-290
+void ClipAudioSource_setGain(ClipAudioSource *c, float db) { c->gainDb = db; }                                                     // :305-311
+
+void ClipAudioSource_setVolume(ClipAudioSource *c, float vol)      // ClipAudioSource.cpp:313-326
+{
+    c->volumeAbsolute = (vol <= -40.0f) ? 0.0f : decibelsToVolumeFaderPosition(vol);
+    push_params(c);
+}
+
+void ClipAudioSource_setVolumeAbsolute(ClipAudioSource *c, float vol)   // ClipAudioSource.cpp:328-336
+{
+    c->volumeAbsolute = std::max(0.0f, std::min(vol, 1.0f));
+    push_params(c);
+}
+
+float ClipAudioSource_volumeAbsolute(ClipAudioSource *c) { return c->volumeAbsolute; }
+float dBFromVolume(float vol) { return volumeFaderPositionToDB(vol); }                                                              // libzl.cpp:429
+
+void ClipAudioSource_setSlices(ClipAudioSource *c, int slices) { set_slices(c, slices); push_params(c); }
+int  ClipAudioSource_keyZoneStart(ClipAudioSource *c) { return c->keyZoneStart; }
+void ClipAudioSource_setKeyZoneStart(ClipAudioSource *c, int v) { c->keyZoneStart = v; }
+int  ClipAudioSource_keyZoneEnd(ClipAudioSource *c) { return c->keyZoneEnd; }
+void ClipAudioSource_setKeyZoneEnd(ClipAudioSource *c, int v) { c->keyZoneEnd = v; }
+int  ClipAudioSource_rootNote(ClipAudioSource *c) { return c->rootNote; }
+void ClipAudioSource_setRootNote(ClipAudioSource *c, int v) { if (c->rootNote != v) { c->rootNote = v; push_params(c); } }
+
+// quirk Q13: every ADSR setter starts from a fresh default Parameters (ClipAudioSource.cpp:636-685)
+float ClipAudioSource_adsrAttack(ClipAudioSource *c) { return c->adsr.attack; }
+void  ClipAudioSource_setADSRAttack(ClipAudioSource *c, float v) { if (c->adsr.attack != v) { AdsrParams p; p.attack = v; c->adsr = p; push_params(c); } }
+float ClipAudioSource_adsrDecay(ClipAudioSource *c) { return c->adsr.decay; }
+void  ClipAudioSource_setADSRDecay(ClipAudioSource *c, float v) { if (c->adsr.decay != v) { AdsrParams p; p.decay = v; c->adsr = p; push_params(c); } }
+float ClipAudioSource_adsrSustain(ClipAudioSource *c) { return c->adsr.sustain; }
+void  ClipAudioSource_setADSRSustain(ClipAudioSource *c, float v) { if (c->adsr.sustain != v) { AdsrParams p; p.sustain = v; c->adsr = p; push_params(c); } }
+float ClipAudioSource_adsrRelease(ClipAudioSource *c) { return c->adsr.release; }
+void  ClipAudioSource_setADSRRelease(ClipAudioSource *c, float v) { if (c->adsr.release != v) { AdsrParams p; p.release = v; c->adsr = p; push_params(c); } }
+
+float ClipAudioSource_peakGain(ClipAudioSource *c) { return c->positions.peakGain(); }
+double ClipAudioSource_firstProgress(ClipAudioSource *c) { return c->positions.firstProgress(); }
+
+int SyncTimer_getMultiplier(void) { return ZLHIP_BEAT_SUBDIVISIONS; }   // SyncTimer.cpp:946-948
+
+// ---- the per-cycle seam -------------------------------------------------------------------------------
+int libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right)
+{
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (!G.engine) return G.status;
+    int rc = zlhip_render(G.engine, (int32_t)nframes, clock, out_left, out_right);
+    if (rc != ZLHIP_OK) return rc;
+    const int V = (int)G.reports.size();
+    rc = zlhip_voice_reports(G.engine, G.reports.data(), V);
+    if (rc != ZLHIP_OK) return rc;
+    const int64_t now = now_ms();
+    // route the per-voice reports into the per-clip positions models (SamplerSynthVoice.cpp:126-129,154-158,265-267)
+    for (int v = 0; v < V; ++v) {
+        const zlhip_voice_report &r = G.reports[(size_t)v];
+        ClipAudioSource *cur = r.playing ? clip_by_engine_id(r.clip) : nullptr;
+        if (G.voiceClip[(size_t)v] != cur) {
+            if (G.voiceClip[(size_t)v]) G.voiceClip[(size_t)v]->positions.remove(G.voicePositionId[(size_t)v], now);
+            G.voiceClip[(size_t)v] = cur;
+            G.voicePositionId[(size_t)v] = cur ? cur->positions.create(0.0f, now) : -1;
+        }
+        if (cur && r.valid) cur->positions.set(G.voicePositionId[(size_t)v], r.gain, r.progress, now);
+    }
+    for (size_t i = 0; i < G.clips.size();) {
+        ClipAudioSource *c = G.clips[i];
+        if (c->id < 0) {            // destroyed by the host: release once no voice plays it any more
+            bool used = false;
+            for (int v = 0; v < V; ++v) used = used || (G.reports[(size_t)v].playing && G.reports[(size_t)v].clip == c->engineClip);
+            if (!used) {
+                if (c->engineClip >= 0) zlhip_sound_release(G.engine, c->engineClip);
+                delete c;
+                G.clips.erase(G.clips.begin() + (long)i);
+                continue;
+            }
+        } else {
+            sync_audio_level(c, now);
+            sync_progress(c, now);
+        }
+        ++i;
+    }
+    return ZLHIP_OK;
+}
+
+// ---- JackPassthrough bridge (libzl.cpp:476-575) ------------------------------------------------------------
+void  JackPassthrough_setPanAmount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->pan = amount; }
+float JackPassthrough_getPanAmount(int channel) { PassState *p = pass_for(channel); return p ? p->pan : 0.0f; }
+float JackPassthrough_getWetFx1Amount(int channel) { PassState *p = pass_for(channel); return p ? p->fx1 : 0.0f; }
+void  JackPassthrough_setWetFx1Amount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->fx1 = amount; }
+float JackPassthrough_getWetFx2Amount(int channel) { PassState *p = pass_for(channel); return p ? p->fx2 : 0.0f; }
+void  JackPassthrough_setWetFx2Amount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->fx2 = amount; }
+float JackPassthrough_getDryAmount(int channel) { PassState *p = pass_for(channel); return p ? p->dry : 0.0f; }
+void  JackPassthrough_setDryAmount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->dry = amount; }
+float JackPassthrough_getMuted(int channel) { PassState *p = pass_for(channel); return p ? (p->muted ? 1.0f : 0.0f) : 0.0f; }
+void  JackPassthrough_setMuted(int channel, bool muted) { if (PassState *p = pass_for(channel)) p->muted = muted; }
+int   JackPassthrough_getParams(int channel, zlhip_passthrough_params *out)
+{
+    PassState *p = pass_for(channel);
+    if (!p || !out) return ZLHIP_ERR_INVALID;
+    out->dry_amount = p->dry; out->wet_fx1_amount = p->fx1; out->wet_fx2_amount = p->fx2; out->pan_amount = p->pan; out->muted = p->muted ? 1 : 0;
+    return ZLHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+"""The libzl.h-named C-ABI (include/libzl_hotpath.h): parameter-setter semantics against the oracle's restated
+setters and the RIFF/WAVE IO on the CPU; play/stop through ClipAudioSource_* against the oracle on the GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import zl_oracle as zo
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def zl(built):
+    from libzl_amd import libzl
+    return libzl.load()
+
+
+def _wav(tmp_path, zl, L, R, sr, bits, name="a.wav"):
+    p = str(tmp_path / name).encode()
+    assert zl.libzl_wav_write(p, L.ctypes.data, None if R is None else R.ctypes.data, len(L), sr, bits) == 0
+    return p
+
+
+def _read(zl, path):
+    Lp, Rp = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+    n, sr = C.c_int(), C.c_double()
+    assert zl.libzl_wav_read(path, C.byref(Lp), C.byref(Rp), C.byref(n), C.byref(sr)) == 0
+    L = np.ctypeslib.as_array(Lp, (n.value,)).copy()
+    R = np.ctypeslib.as_array(Rp, (n.value,)).copy() if Rp else None
+    zl.libzl_wav_free(Lp); zl.libzl_wav_free(Rp)
+    return L, R, sr.value
+
+
+def test_wav_roundtrip_float_and_pcm16(zl, tmp_path):
+    rng = np.random.default_rng(5)
+    L = rng.uniform(-1, 1, 777).astype(np.float32); R = rng.uniform(-1, 1, 777).astype(np.float32)
+    l2, r2, sr = _read(zl, _wav(tmp_path, zl, L, R, 44100.0, 32))
+    assert sr == 44100.0 and np.array_equal(l2, L) and np.array_equal(r2, R)
+    l3, r3, _ = _read(zl, _wav(tmp_path, zl, L, None, 48000.0, 16, "b.wav"))
+    assert r3 is None
+    q = np.rint(np.clip(L, -1, 1) * f32(32767.0)).astype(np.int32)
+    np.testing.assert_array_equal(l3, (q << 16).astype(np.float32) * f32(1.0 / 2147483648.0))   # JUCE int->float convention
+    assert zl.libzl_wav_read(b"/nonexistent.wav", C.byref(C.POINTER(C.c_float)()), C.byref(C.POINTER(C.c_float)()), C.byref(C.c_int()), C.byref(C.c_double())) != 0
+    assert zl.ClipAudioSource_new(b"/nonexistent.wav", False) is None       # reference: failures are logged, not raised
+
+
+def test_setters_follow_the_reference_semantics(zl, tmp_path):
+    """Every setter of the bridge against the oracle's restatement of ClipAudioSource.cpp (no GPU needed: without
+    initJuce the clips only hold parameters)."""
+    lib = zo.load()
+    L = np.zeros(96000, dtype=np.float32)
+    c = zl.ClipAudioSource_new(_wav(tmp_path, zl, L, None, 48000.0, 16, "c.wav"), False)
+    oc = zo.Clip(); lib.zlo_clip_init(C.byref(oc), C.c_float(96000 / 48000.0), 48000.0)
+    assert zl.ClipAudioSource_getDuration(c) == oc.duration == 2.0
+    assert zl.ClipAudioSource_getFileName(c) == b"c.wav"
+    assert zl.ClipAudioSource_id(c) >= 1 and zl.ClipAudioSource_byID(zl.ClipAudioSource_id(c)) == c
+    assert zl.ClipAudioSource_byID(987654) is None
+    # ADSR: ctor defaults, then quirk Q13 on every setter
+    assert (zl.ClipAudioSource_adsrAttack(c), zl.ClipAudioSource_adsrRelease(c)) == (oc.adsr.p.attack, oc.adsr.p.release) == (0.0, f32(0.05))
+    for name, fn in (("Release", lib.zlo_clip_set_adsr_release), ("Attack", lib.zlo_clip_set_adsr_attack),
+                     ("Sustain", lib.zlo_clip_set_adsr_sustain), ("Decay", lib.zlo_clip_set_adsr_decay)):
+        getattr(zl, f"ClipAudioSource_setADSR{name}")(c, 0.37)
+        fn(C.byref(oc), C.c_float(0.37))
+        got = tuple(getattr(zl, f"ClipAudioSource_adsr{n}")(c) for n in ("Attack", "Decay", "Sustain", "Release"))
+        assert got == (oc.adsr.p.attack, oc.adsr.p.decay, oc.adsr.p.sustain, oc.adsr.p.release)
+    # root note / key zone
+    zl.ClipAudioSource_setRootNote(c, 64); zl.ClipAudioSource_setKeyZoneStart(c, 12); zl.ClipAudioSource_setKeyZoneEnd(c, 100)
+    assert (zl.ClipAudioSource_rootNote(c), zl.ClipAudioSource_keyZoneStart(c), zl.ClipAudioSource_keyZoneEnd(c)) == (64, 12, 100)
+    # volume: clamp of setVolumeAbsolute, -40 dB floor of setVolume
+    zl.ClipAudioSource_setVolumeAbsolute(c, 1.5); assert zl.ClipAudioSource_volumeAbsolute(c) == 1.0
+    zl.ClipAudioSource_setVolume(c, -40.0); assert zl.ClipAudioSource_volumeAbsolute(c) == 0.0
+    zl.ClipAudioSource_setVolume(c, 6.0); assert abs(zl.ClipAudioSource_volumeAbsolute(c) - 1.0) < 1e-6
+    assert abs(zl.dBFromVolume(1.0) - 6.0) < 1e-6
+    assert zl.SyncTimer_getMultiplier() == 96
+    zl.ClipAudioSource_destroy(c)
+
+
+def test_passthrough_parameter_bridge(zl):
+    from libzl_amd import PassthroughParams
+    assert zl.JackPassthrough_getDryAmount(3) == 1.0 and zl.JackPassthrough_getPanAmount(-1) == 0.0
+    zl.JackPassthrough_setPanAmount(3, -0.25); zl.JackPassthrough_setWetFx1Amount(3, 0.5); zl.JackPassthrough_setMuted(-1, True)
+    assert zl.JackPassthrough_getPanAmount(3) == -0.25 and zl.JackPassthrough_getWetFx1Amount(3) == 0.5 and zl.JackPassthrough_getMuted(-1) == 1.0
+    zl.JackPassthrough_setDryAmount(10, 0.1)            # out of range: ignored, getters return 0 (libzl.cpp:476-575)
+    assert zl.JackPassthrough_getDryAmount(10) == 0.0 and zl.JackPassthrough_getDryAmount(-2) == 0.0
+    p = PassthroughParams()
+    assert zl.JackPassthrough_getParams(3, C.byref(p)) == 0 and (p.pan_amount, p.wet_fx1_amount, p.muted) == (-0.25, 0.5, 0)
+    zl.JackPassthrough_setMuted(-1, False); zl.JackPassthrough_setPanAmount(3, 0.0); zl.JackPassthrough_setWetFx1Amount(3, 1.0)
+
+
+@pytest.mark.gpu
+def test_play_stop_through_the_libzl_symbols_matches_oracle(zl, tmp_path):
+    """The calling pattern of the reference's test/playtest.py: initJuce, ClipAudioSource_new, setLength, play;
+    audio pulled per JACK cycle.  Compared bit for bit with the oracle driven through its restated setters."""
+    from libzl_amd.engine import synthetic_clocks
+    rng = np.random.default_rng(11)
+    lib = zo.load()
+    zl.initJuce()
+    assert zl.libzl_hotpath_status() == 0
+    osyn = zo.OracleSynth(12, 8, 48000.0, 0)
+    clips = []
+    for i in range(3):
+        n = 5000 + 700 * i
+        L = rng.uniform(-1, 1, n).astype(np.float32); R = rng.uniform(-1, 1, n).astype(np.float32) if i != 1 else None
+        path = _wav(tmp_path, zl, L, R, 44100.0, 32, f"clip{i}.wav")
+        c = zl.ClipAudioSource_new(path, False)
+        oid = osyn.register_clip(L, R, 44100.0)
+        oc = osyn.clips[oid]
+        zl.ClipAudioSource_setLength(c, 0.13 + 0.02 * i, 120); lib.zlo_clip_set_length(C.byref(oc), C.c_float(0.13 + 0.02 * i), 120)
+        zl.ClipAudioSource_setPan(c, -0.5 + 0.4 * i); lib.zlo_clip_set_pan(C.byref(oc), C.c_float(-0.5 + 0.4 * i))
+        zl.ClipAudioSource_setVolumeAbsolute(c, 0.5 + 0.2 * i); lib.zlo_clip_set_volume_absolute(C.byref(oc), C.c_float(0.5 + 0.2 * i))
+        zl.ClipAudioSource_setStartPosition(c, 0.004 * i); lib.zlo_clip_set_start_position(C.byref(oc), C.c_float(0.004 * i))
+        zl.ClipAudioSource_setADSRRelease(c, 0.01); lib.zlo_clip_set_adsr_release(C.byref(oc), C.c_float(0.01))
+        clips.append((c, oid))
+    levels = []
+    cb = __import__("libzl_amd.libzl", fromlist=["CB"]).CB(lambda db: levels.append(db))
+    zl.ClipAudioSource_setAudioLevelChangedCallback(clips[0][0], cb)
+
+    def ocmd(oid, ch, loop, stop_only=False):
+        f = dict(clip=oid, midiChannel=ch, midiNote=60, stopPlayback=1) if stop_only else \
+            dict(clip=oid, midiChannel=ch, midiNote=60, changeVolume=1, volume=1.0, looping=1 if loop else 0, startPlayback=1, **({"stopPlayback": 1} if loop else {}))
+        osyn.handle_clip_command(zo.clip_command(**f), 0)
+
+    N = 128
+    outL = np.zeros((12, N), dtype=np.float32); outR = np.zeros((12, N), dtype=np.float32)
+    for k in range(30):
+        if k == 0:
+            zl.ClipAudioSource_play(clips[0][0], True); ocmd(clips[0][1], -2, True)
+            zl.ClipAudioSource_playOnChannel(clips[1][0], True, 3); ocmd(clips[1][1], 3, True)
+        if k == 5:
+            zl.ClipAudioSource_playOnChannel(clips[2][0], False, 0); ocmd(clips[2][1], 0, False)
+        if k == 12:
+            zl.ClipAudioSource_stopOnChannel(clips[1][0], 3); ocmd(clips[1][1], 3, False, stop_only=True)
+        if k == 20:
+            zl.ClipAudioSource_stop(clips[0][0])
+            for ch in [-2, -1] + list(range(10)):
+                ocmd(clips[0][1], ch, False, stop_only=True)
+        clk = synthetic_clocks(1, N, 48000.0, start_block=k)
+        assert zl.libzl_hotpath_process(N, clk, outL.ctypes.data, outR.ctypes.data) == 0
+        bus, _ = osyn.render_batch(1, N, clk)
+        assert np.array_equal(outL.view(np.int32), bus[:, 0].view(np.int32)) and np.array_equal(outR.view(np.int32), bus[:, 1].view(np.int32)), k
+        if k == 3:
+            assert zl.ClipAudioSource_peakGain(clips[0][0]) == lib.zlo_positions_peak_gain(C.byref(osyn.clips[clips[0][1]].positions))
+            assert zl.ClipAudioSource_firstProgress(clips[0][0]) == lib.zlo_positions_first_progress(C.byref(osyn.clips[clips[0][1]].positions))
+    assert levels and all(np.isfinite(levels))
+    for c, _ in clips:
+        zl.ClipAudioSource_destroy(c)
+    zl.shutdownJuce()

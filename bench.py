@@ -98,13 +98,20 @@ def cpu_baseline(args, seed):
         assert osyn.start_voice(bus, slot, cmd, 0) == 1
     clocks = synthetic_clocks(blocks, args.frames, args.fs)
     osyn.render_batch(2, args.frames, clocks, threads=threads, want_reports=False)       # warm-up
+    # bounded sample: repeat batches of `blocks` blocks until about args.cpu_seconds of CPU wall time have passed
+    done = 0
     t0 = time.perf_counter()
-    osyn.render_batch(blocks, args.frames, clocks, threads=threads, want_reports=False)
-    dt = time.perf_counter() - t0
+    while True:
+        osyn.render_batch(blocks, args.frames, clocks, threads=threads, want_reports=False)
+        done += blocks
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds:
+            break
     return {
-        "value": V * blocks * args.frames / dt, "unit": "voice-samples/s", "cores": threads, "kind": "port",
-        "sample": f"{V} stereo voices (128 buses x 8) x {blocks} blocks x {args.frames} frames, 0.5 s loops, ratio 1, "
-                  f"oracle/zl_oracle.c -O3 -march=native, {dt:.2f} s wall on {cores} visible cores",
+        "value": V * done * args.frames / dt, "unit": "voice-samples/s", "cores": threads, "kind": "port",
+        "sample": f"{V} stereo voices (128 buses x 8, the reference's voices per channel) x {done} blocks x {args.frames} frames, "
+                  f"0.5 s loops, ratio 1, faithful mode, oracle/zl_oracle.c built -O3 -march=native, {threads} threads "
+                  f"(buses partitioned, one thread per JACK client as in the reference), {dt:.1f} s wall; {cores} host cores visible",
     }
 
 
@@ -121,6 +128,7 @@ def main():
     ap.add_argument("--loop-seconds", type=float, default=2.0)
     ap.add_argument("--voices-per-task", type=int, default=0)
     ap.add_argument("--cpu-blocks", type=int, default=64)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -166,13 +174,14 @@ def main():
     fin_ms = []
     src_bytes = 0
 
+    from libzl_amd import sharding
+
     def step(i, timed):
-        nonlocal src_bytes
-        syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr)
+        # render this rank's voices, sum the partial buses onto rank 0 (one RCCL reduce), levels on the root
         if distributed:
-            dist.reduce(bus, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                syn.levels_scan_device(bus.data_ptr(), KB, N, stream=sptr)
+            sharding.render_sharded(syn, KB, N, clock_sets[i], bus, dst=0, stream=sptr)
+        else:
+            syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr)
 
     for i in range(args.warmup):
         step(i, False)
@@ -183,7 +192,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, True)
-        if not distributed or True:
+        if True:
             # per-kernel HIP-event timings of this step (events were recorded on the launch stream);
             # reading them waits for the step, which render_batch would do anyway before reusing its staging
             t = syn.last_timings()

@@ -1,0 +1,52 @@
+"""Multi-GPU sharding of the sampler hot path: one process per GPU, voices partitioned across ranks,
+one RCCL sum-reduce of the stereo buses onto rank 0.
+
+Voices are independent given the shared clock and clip parameters (SamplerSynthVoice::process has no
+cross-voice state); the only coupling is the per-bus sum of SamplerChannel::process
+(reference lib/SamplerSynth.cpp:134-140).  Every rank therefore renders the voices it owns into a
+partial bus [num_buses, 2, frames]; the partial buses are summed with ONE collective per batch and
+AudioLevels (which must see the final mix, not the partials) runs on the root afterwards.
+
+`torch.distributed` with backend "nccl" is RCCL over xGMI on ROCm; the same code runs on "gloo" for
+the CPU tests.  The reduce's operand order is the backend's (ring / tree), so for more than two ranks
+the root's sum may differ from the reference's voice-order sum in the last bits (within 1e-6 of the
+mix magnitude); with two ranks a + b is order-independent and the result is bit-exact.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def voice_range(num_voices: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Block partition: rank g owns voices [g*V/G, (g+1)*V/G) (sources never move between GPUs)."""
+    return (num_voices * rank) // world_size, (num_voices * (rank + 1)) // world_size
+
+
+def bus_owner(bus: int, num_buses: int, world_size: int) -> int:
+    """Bus-aligned partition for the case num_buses >= world_size: whole buses per GPU, no collective."""
+    return (bus * world_size) // num_buses
+
+
+def slots_for_rank(voices_per_bus_global: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """When a bus spans ranks: the slice of each bus's voice slots that lives on `rank`."""
+    return voice_range(voices_per_bus_global, world_size, rank)
+
+
+def reduce_bus(bus, dst: int = 0, group=None):
+    """Sum the per-rank partial buses onto `dst` in place (one collective per batch).  `bus` is a torch tensor
+    [num_buses, 2, frames] living where the backend expects it (HBM for nccl/RCCL, host for gloo)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return bus
+
+
+def render_sharded(synth, nblocks: int, nframes: int, clocks, bus, dst: int = 0, stream=None, group=None):
+    """One batch on this rank's voices into `bus` (device pointer of a torch tensor), then the bus reduce;
+    on the root the reduced bus is scanned for AudioLevels.  `synth` is a libzl_amd.SamplerSynth."""
+    import torch.distributed as dist
+    synth.render_batch(nblocks, nframes, clocks, bus_out_dev=bus.data_ptr(), stream=stream)
+    reduce_bus(bus, dst=dst, group=group)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == dst:
+        synth.levels_scan_device(bus.data_ptr(), nblocks, nframes, stream=stream)
+    return bus

@@ -64,7 +64,7 @@ def _build_engine(force: bool, verbose: bool, extra: list) -> str:
         "-I", os.path.join(ROOT, "include"), "-I", CSRC,
         "-Wall", "-Wno-unused-function",
         "-o", LIB,
-    ] + extra + srcs
+    ] + extra + [f for f in os.environ.get("ZL_EXTRA_HIPCC_FLAGS", "").split() if f] + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

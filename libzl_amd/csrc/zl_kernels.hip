@@ -106,7 +106,12 @@ typedef float zl_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef float zl_f2a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 #define ZL_K2_CHUNK 128      // voice records staged in LDS per pass
+#ifndef ZL_K2_U
 #define ZL_K2_U     8        // gathers in flight per wavefront
+#endif
+#ifndef ZL_K2_MINWAVES
+#define ZL_K2_MINWAVES 1      // __launch_bounds__ minimum waves per SIMD (caps the VGPR budget)
+#endif
 
 // 16-byte gather of the interpolation taps: interleaved stereo [L0 R0 L1 R1] or mono [x0 x1 . .]
 typedef float zl_f4a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -119,6 +124,54 @@ struct ZlK2Tap { ZlTaps t; float alpha; int flags; };   // flags: 1 act, 2 inb, 
 // and stay in flight together; the voices are then mixed and accumulated in voice order.
 // CTL = the chunk contains a block with per-frame control (envelope not in steady sustain, or a
 // block expanded by K1b); regular voices of such a chunk read a dummy control word.
+// SIMPLE chunks (the steady state): every voice of the chunk plays the whole block from one position segment, in
+// sustain, from a stereo source.  No per-voice predicates are needed, which halves the VALU work.
+template <uint32_t MODE, bool SEG2, int U>
+static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
+                                                           int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
+{
+    zl_f4a4 d[U];
+    float alpha[U];
+    int   inbm = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = c0 + u;
+        double P;
+        if (SEG2) {                                               // a binade crossing or loop restart inside the block
+            const bool seg1 = f >= s_plan[i].n1;
+            P = fma((double)(f - (seg1 ? s_plan[i].n1 : 0)), seg1 ? s_plan[i].step1 : s_plan[i].step, seg1 ? s_plan[i].P1 : s_plan[i].P0);
+        } else {
+            P = fma(fd, s_plan[i].step, s_plan[i].P0);            // exact, see zl_plan.h
+        }
+        int pos;
+        zl_split_position(P, pos, alpha[u]);                      // :198-199
+        const bool inb = s_vc[i].sample_duration > pos;           // :204 guard (Q5); P >= 0 so pos >= 0
+        const int p = inb ? pos : 0;
+        const uint64_t so = s_vc[i].src_offset;
+        const float *src = A.arena + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(so >> 32)) << 32)
+                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)so));
+        d[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p);
+        inbm |= inb ? (1 << u) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = c0 + u;
+        ZlTaps t;
+        t.x0l = d[u].x; t.x0r = d[u].y; t.x1l = d[u].z; t.x1r = d[u].w;
+        t.xml = t.xmr = t.x2l = t.x2r = 0.0f;
+        float l, r;
+        zl_mix_frame<MODE>(t, alpha[u], (inbm >> u) & 1, false, true, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env,
+                           s_vc[i].clip_volume, s_vc[i].lpan, s_vc[i].rpan, l, r);
+        accL += l; accR += r;                                     // :218-221 (index shift applied at the store)
+        if (wantPeak) {                                           // :213-216, signed peak from 0 (Q6)
+            const float ng = l + r;
+            float pk = ng > 0.0f ? ng : 0.0f;
+            pk = zl_wave_max(pk);
+            if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[vfirst + i].peak_bits, __float_as_uint(pk));
+        }
+    }
+}
+
 template <uint32_t MODE, bool CTL, int U>
 static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
                                                     const int *s_cls, int c0, size_t pbase, int vfirst, int f, bool wantPeak,
@@ -201,7 +254,7 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
 }
 
 template <uint32_t MODE>
-__global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
+__global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
 {
     constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U / 2 : ZL_K2_U;
     __shared__ ZlBlockPlan  s_plan[ZL_K2_CHUNK];
@@ -218,8 +271,9 @@ __global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
     const int vend = (bus + 1) * A.VPB;
     const int v1 = (v0 + A.G < vend) ? v0 + A.G : vend;
     const bool wantPeak = (k == A.K - 1);
+    const double fd = (double)f;
 #ifdef ZL_STAMPS
-    unsigned long long zl_t0 = __builtin_amdgcn_s_memrealtime(), zl_t1 = 0;
+    unsigned long long zl_t0 = __builtin_amdgcn_s_memrealtime(), zl_t1 = 0, zl_paths = 0;
 #endif
 
     float accL = 0.0f, accR = 0.0f;
@@ -239,7 +293,11 @@ __global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
             zl_plan_clear(pl);
             if (i < nv) pl = zl_plan_lookup(A, k, vb + i, s_vc[i].env);    // implied by a run, explicit, or idle
             s_plan[i] = pl;                       // idle slots: a harmless record with no active frame
-            s_cls[i] = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
+            int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
+            // 4 = "simple": whole block, sustain, stereo (and no debug trace); 8 = it has a second position segment
+            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && s_vc[i].channels == 2 && !(MODE & ZL_MODE_HERMITE) && !A.trace)
+                cls |= 4 | (pl.nseg == 2 ? 8 : 0);
+            s_cls[i] = cls;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < ZL_K2_CHUNK; i += blockDim.x) {
@@ -249,9 +307,9 @@ __global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
             }
         }
         for (int c = threadIdx.x; c < ZL_K2_CHUNK / U; c += blockDim.x) {
-            int cc = 0;
-            for (int u = 0; u < U; ++u) cc |= s_cls[c * U + u];
-            s_chunk[c] = cc;
+            int cc = 0, all = 4;
+            for (int u = 0; u < U; ++u) { cc |= s_cls[c * U + u]; all &= s_cls[c * U + u]; }
+            s_chunk[c] = (cc & 11) | all;
         }
         __syncthreads();
 #ifdef ZL_STAMPS
@@ -261,8 +319,20 @@ __global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
         for (int c0 = 0; c0 < nv; c0 += U) {
             const int cc = __builtin_amdgcn_readfirstlane(s_chunk[c0 / U]);
             if (cc == 0) continue;                                // nobody in this chunk plays (SamplerSynth.cpp:137)
-            if (cc & 2) zl_k2_chunk<MODE, true, U>(A, s_plan, s_vc, s_cls, c0, pbase, vb, f, wantPeak, accL, accR);
-            else        zl_k2_chunk<MODE, false, U>(A, s_plan, s_vc, s_cls, c0, pbase, vb, f, wantPeak, accL, accR);
+#ifdef ZL_STAMPS
+            zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
+#endif
+            if ((cc & 12) == 4)  zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else if (cc & 4) zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else {
+                // general chunks (events, second segments, mono sources, per-frame control) are rare: run them as
+                // two half-chunks so their extra per-voice registers do not set the kernel's register budget
+                constexpr int H = U / 2;
+                for (int h = 0; h < U; h += H) {
+                    if (cc & 2) zl_k2_chunk<MODE, true, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, f, wantPeak, accL, accR);
+                    else        zl_k2_chunk<MODE, false, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, f, wantPeak, accL, accR);
+                }
+            }
         }
     }
 
@@ -270,7 +340,7 @@ __global__ void __launch_bounds__(256) zl_k2_render(const ZlBatch A)
     if (threadIdx.x == 0 && A.pos_trace) {
         unsigned long long *st = reinterpret_cast<unsigned long long *>(A.pos_trace) + 4 * ((size_t)blockIdx.z * gridDim.y + blockIdx.y);
         st[0] = zl_t0; st[1] = zl_t1; st[2] = __builtin_amdgcn_s_memrealtime();
-        st[3] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /*XCC_ID*/ | ((unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4) /*HW_ID*/ << 8);
+        st[3] = zl_paths;
     }
 #endif
     float *outL, *outR;

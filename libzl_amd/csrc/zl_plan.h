@@ -131,9 +131,10 @@ ZL_HD inline void zl_linear_run(double P, double r, double inv_r, double &s, int
     const double sq = q + c;                                     // step in ulps
     s = sq * u;                                                  // exact
     if (sq <= 0.0) { L = ZL_RUN_CAP; return; }                   // r < ulp/2: P never moves
-    // step i (0-based) starts at mantissa m0 + i*sq and must satisfy m + q + 1 <= 2^53 so the exact
-    // sum stays inside [2^e, 2^(e+1)] where the spacing is u
-    const double a = (top - P) - (q + 1.0) * u;                  // exact
+    // step i (0-based) starts at mantissa m_i = m0 + i*sq and is an in-binade step iff its result m_i + sq <= 2^53,
+    // i.e. it lands inside the binade or exactly on 2^(e+1): the exact sum is then below 2^(e+1) + u/2 (c = 0) or
+    // below 2^(e+1) (c = 1), where rounding to the spacing u (resp. to the top itself) gives m_i + sq.
+    const double a = (top - P) - s;                              // exact
     if (a < 0.0) { s = 0.0; return; }
     // count = floor(a / s) + 1, estimated without a division (inv_r ~ 1 / s) and then corrected downwards
     // exactly: fma(c, s, -a) has the sign of the exact c*s - a
@@ -416,26 +417,24 @@ struct ZlPlanner {
             const double s0 = s; const int L0 = L, ie0 = ie; const bool haveRun0 = haveRun;
             ZlSegment *segs = A.segs + pidx * (ZL_MAXSEG - 2);
             int n = 0, nseg = 0;
+            bool needSeg = true;                                   // frame n is not covered by an emitted segment yet
             while (n < N) {
                 if (!haveRun) {
                     zl_linear_run(st.P, st.pitch_ratio, inv_r, s, L);
                     haveRun = true;
+                    needSeg = true;
                     ie = posMode ? zl_steps_to_reach(st.P, s, inv_r, L, X) : ZL_INF_STEPS;
                 }
-                if (nseg >= ZL_MAXSEG) { slow = true; break; }
-                if (nseg == 0) { pl.P0 = st.P; pl.step = s; }
-                else if (nseg == 1) { pl.n1 = n; pl.P1 = st.P; pl.step1 = s; }
-                else { ZlSegment sg; sg.P0 = st.P; sg.step = s; sg.n0 = n; sg.pad = 0; segs[nseg - 2] = sg; }
-                ++nseg;
-                if (L == 0) {
-                    // one real addition from frame n
-                    const double Pn = st.P + st.pitch_ratio;
-                    const bool ev = posMode ? (Pn >= X)
-                                            : (clockMode ? (zl_clock_event_frame(ck, st.next_loop_usecs, n, N) == n) : false);
-                    n += 1;
-                    haveRun = false;
-                    if (!ev) { st.P = Pn; continue; }
-                } else {
+                if (needSeg) {
+                    if (nseg >= ZL_MAXSEG) { slow = true; break; }
+                    if (nseg == 0) { pl.P0 = st.P; pl.step = s; }
+                    else if (nseg == 1) { pl.n1 = n; pl.P1 = st.P; pl.step1 = s; }
+                    else { ZlSegment sg; sg.P0 = st.P; sg.step = s; sg.n0 = n; sg.pad = 0; segs[nseg - 2] = sg; }
+                    ++nseg;
+                    needSeg = false;
+                }
+                bool realStep = (L == 0);
+                if (!realStep) {
                     const int room = N - n;
                     const int m = L < room ? L : room;
                     int iclk = ZL_INF_STEPS;
@@ -448,11 +447,22 @@ struct ZlPlanner {
                         st.P = fma((double)m, s, st.P);
                         n += m; L -= m;
                         if (ie != ZL_INF_STEPS) ie -= m;
-                        if (L == 0) haveRun = false;
-                        continue;
+                        if (L != 0 || n >= N) { if (L == 0) haveRun = false; continue; }
+                        // run exhausted inside the block: frame n is still covered by the current segment (P0 + L*s);
+                        // leave the binade with one real addition, without opening a one-frame segment
+                        realStep = true;
+                    } else {
+                        n += iev;
+                        haveRun = false;
                     }
-                    n += iev;
+                }
+                if (realStep) {
+                    const double Pn = st.P + st.pitch_ratio;       // one real fp64 addition from frame n
+                    const bool ev = posMode ? (Pn >= X)
+                                            : (clockMode ? (zl_clock_event_frame(ck, st.next_loop_usecs, n, N) == n) : false);
+                    n += 1;
                     haveRun = false;
+                    if (!ev) { st.P = Pn; continue; }
                 }
                 // ---- event after rendering frame n-1 ----
                 if (st.looping) {
@@ -517,12 +527,16 @@ ZL_HD inline ZlBlockPlan zl_plan_lookup(const ZlBatch &A, int k, int v, float ru
 {
     ZlBlockPlan pl;
     zl_plan_clear(pl);
-    const ZlRunList *rl = A.runs + v;
+    const ZlRunList rl_ = A.runs[v];                              // one struct copy: independent wide loads, one round trip
+    const ZlRunList *rl = &rl_;
     if (k >= rl->dead_from) return pl;                            // idle
     const int n = rl->n;
-    for (int j = 0; j < n; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < ZL_MAXRUNS; ++j) {
         const ZlRun r = rl->r[j];
-        if (k >= r.k0 && k < r.k1) {
+        if (j < n && k >= r.k0 && k < r.k1) {
             pl.flags = ZL_PLAN_ACTIVE; pl.n_active = A.N; pl.nseg = 1; pl.env = run_env;
             pl.P0 = fma((double)((k - r.k0) * A.N), r.step, r.P);  // exact: inside the linear run
             pl.step = r.step;

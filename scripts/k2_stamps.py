@@ -43,9 +43,18 @@ for a, b in zip(edges[:-1], edges[1:]):
     mid = (a + b) / 2 + base
     conc = int(((t0 <= mid) & (t2 > mid)).sum())
     print(f"  t={(a*10e-3):7.1f} us  resident WGs {conc}")
-xcc = (hw & 0xff)
-print("WGs per XCC:", np.bincount(xcc.astype(np.int64), minlength=8))
+paths = np.stack([(hw >> np.uint64(sh)) & np.uint64(0xffff) for sh in (0, 16, 32, 48)], axis=1).astype(np.int64)
+print("chunks by path (simple1, simple2, general, ctl): total", paths.sum(axis=0))
 # slowest workgroups
 idx = np.argsort(-dur)[:8]
 for i in idx:
     print(f"  slow wg {i}: bus {i // KB} block {i % KB} dur {dur[i]:.1f} us start {(t0[i]-base)*10e-3:.1f}")
+# duration by block index (averaged over buses)
+byk = dur.reshape(-1, KB).mean(axis=0) if nwg == KB * B else None
+if byk is not None:
+    order = np.argsort(-byk)[:24]
+    print("slowest blocks (mean us over buses):", [(int(k), round(float(byk[k]), 1)) for k in sorted(order)])
+    print("median block:", float(np.median(byk)))
+    pk = paths.reshape(-1, KB, 4).sum(axis=0)
+    for k in sorted(order)[:12]:
+        print("   block", int(k), "paths", pk[k].tolist())

@@ -64,7 +64,8 @@ typedef struct zlhip_config {
     uint64_t sound_arena_bytes;      /* HBM reserved for decoded sources */
     int32_t  voices_per_task;        /* voices summed sequentially by one wavefront (mix group); 0 = the whole bus,
                                         i.e. the reference's order.  Smaller groups = two-level order, more parallelism */
-    int32_t  reserved;
+    int32_t  plan_window_blocks;     /* blocks planned per window (planning of window i+1 overlaps rendering of window i);
+                                        0 = min(2048, max_batch_blocks) */
 } zlhip_config;
 
 /* clock inputs of one block: JACK cycle times + SyncTimer playhead getters
@@ -132,13 +133,15 @@ typedef struct zlhip_passthrough_params {
 
 /* profiling counters of the last zlhip_render_batch (HIP events on the engine's stream) */
 typedef struct zlhip_timings {
-    float plan_ms;        /* control-plan kernel (K1) */
-    float render_ms;      /* gather-interp-mix kernel (K2), the dominant one */
-    float finalize_ms;    /* bus reduce + levels kernel (K3) */
+    float plan_ms;        /* planning (K0+K1+K1b) not hidden behind rendering: first launch to first K2 */
+    float render_ms;      /* gather-interp-mix kernel (K2), the dominant one: sum over the call's launches */
+    float finalize_ms;    /* total - render - plan: K3 (bus reduce + levels), reports, gaps between launches */
     float total_ms;       /* first launch to last completion */
     uint64_t source_bytes;   /* algorithmic source bytes of the batch: sum (ceil(N*ratio)+taps-1)*ch*4 */
     uint64_t slow_blocks;    /* voice-blocks that needed the per-frame control path */
     uint64_t active_voice_frames; /* voice-samples rendered */
+    int32_t  render_launches;  /* K2 launches of the call (one per plan window); render_ms is their sum */
+    int32_t  reserved;
 } zlhip_timings;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */

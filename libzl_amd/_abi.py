@@ -29,7 +29,7 @@ class Config(C.Structure):
         ("struct_size", C.c_uint32), ("device", C.c_int32), ("num_buses", C.c_int32),
         ("voices_per_bus", C.c_int32), ("max_frames", C.c_int32), ("max_batch_blocks", C.c_int32),
         ("max_sounds", C.c_int32), ("mode", C.c_uint32), ("playback_sample_rate", C.c_double),
-        ("sound_arena_bytes", C.c_uint64), ("voices_per_task", C.c_int32), ("reserved", C.c_int32),
+        ("sound_arena_bytes", C.c_uint64), ("voices_per_task", C.c_int32), ("plan_window_blocks", C.c_int32),
     ]
 
 
@@ -90,6 +90,7 @@ class Timings(C.Structure):
     _fields_ = [
         ("plan_ms", C.c_float), ("render_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float),
         ("source_bytes", C.c_uint64), ("slow_blocks", C.c_uint64), ("active_voice_frames", C.c_uint64),
+        ("render_launches", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

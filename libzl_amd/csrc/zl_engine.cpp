@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/zlhip.h"
@@ -40,15 +41,24 @@ struct zlhip_engine {
     // HBM
     float *arena = nullptr; size_t arenaFloats = 0, arenaUsed = 0;
     ZlSound *dSounds = nullptr; ZlClip *dClips = nullptr;
-    ZlVoiceState *dVoices = nullptr; ZlVoiceConst *dVconst = nullptr; ZlRunList *dRuns = nullptr;
-    ZlPlanHdr *dPlanHdr = nullptr; ZlPlanSeg0 *dPlanSeg0 = nullptr; ZlPlanSeg1 *dPlanSeg1 = nullptr; ZlSegment *dSegs = nullptr;
-    double *dCtlP = nullptr; float *dCtlEnv = nullptr;
+    ZlVoiceState *dVoices = nullptr;
+    // K1 -> K2 records, double buffered so that planning window i+1 overlaps rendering window i
+    struct PlanSet {
+        ZlVoiceConst *vconst = nullptr; ZlRunList *runs = nullptr;
+        ZlPlanHdr *hdr = nullptr; ZlPlanSeg0 *seg0 = nullptr; ZlPlanSeg1 *seg1 = nullptr; ZlSegment *segs = nullptr;
+        double *ctlP = nullptr; float *ctlEnv = nullptr; int32_t *expandList = nullptr; int32_t *expandCount = nullptr;
+        float *partials = nullptr;
+        hipEvent_t planned = nullptr, rendered = nullptr;
+    } ps[2];
+    int window = 0;                      // blocks per plan window
+    hipStream_t planStream = nullptr;
+    hipEvent_t evStart = nullptr;
+    std::vector<hipEvent_t> evK2;        // [2 * max windows] start/end of every K2 launch (profiling)
     ZlReport *dReports = nullptr; float *dGain = nullptr;
-    float *dPartials = nullptr; float *dBus = nullptr;
+    float *dBus = nullptr;
     ZlBlockLevels *dLevels = nullptr; ZlLevelsState *dLevelState = nullptr;
     ZlClock *dClocks = nullptr; ZlVoiceOp *dOps = nullptr; ZlOpRange *dOpRanges = nullptr;
     ZlBatchStats *dStats = nullptr; int32_t *dTrace = nullptr; PassParamsDev *dPass = nullptr;
-    int32_t *dExpandList = nullptr; int32_t *dExpandCount = nullptr;
     size_t opsCap = 0, rangesCap = 0, traceInts = 0;
     int maxGroups = 1;
 
@@ -61,7 +71,7 @@ struct zlhip_engine {
     std::vector<ZlVoiceOp> sortedOps; std::vector<ZlOpRange> ranges;
 
     // last batch
-    int lastK = 0, lastN = 0; float *lastBus = nullptr; bool outstanding = false; bool reportsFresh = false;
+    int lastK = 0, lastN = 0, lastWindows = 0; float *lastBus = nullptr; bool outstanding = false; bool reportsFresh = false;
     bool trace = false; int traceK = 0, traceN = 0;
     int forceSlow = 0;
 
@@ -134,10 +144,19 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dVconst, e->dRuns, e->dPlanHdr, e->dPlanSeg0, e->dPlanSeg1, e->dSegs, e->dCtlP, e->dCtlEnv,
-                    e->dReports, e->dGain, e->dPartials, e->dBus, e->dLevels, e->dLevelState, e->dClocks, e->dOps,
-                    e->dOpRanges, e->dStats, e->dTrace, e->dPass, e->dExpandList, e->dExpandCount };
+    if (e->planStream) (void)hipStreamSynchronize(e->planStream);
+    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dReports, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dClocks, e->dOps,
+                    e->dOpRanges, e->dStats, e->dTrace, e->dPass };
     for (void *p : dev) if (p) (void)hipFree(p);
+    for (auto &q : e->ps) {
+        void *pd[] = { q.vconst, q.runs, q.hdr, q.seg0, q.seg1, q.segs, q.ctlP, q.ctlEnv, q.expandList, q.expandCount, q.partials };
+        for (void *p : pd) if (p) (void)hipFree(p);
+        if (q.planned) (void)hipEventDestroy(q.planned);
+        if (q.rendered) (void)hipEventDestroy(q.rendered);
+    }
+    for (auto &x : e->evK2) if (x) (void)hipEventDestroy(x);
+    if (e->evStart) (void)hipEventDestroy(e->evStart);
+    if (e->planStream) (void)hipStreamDestroy(e->planStream);
     void *host[] = { e->hClocks, e->hReports, e->hGain, e->hBus, e->hLevelState, e->hStats };
     for (void *p : host) if (p) (void)hipHostFree(p);
     for (auto &x : e->ev) if (x) (void)hipEventDestroy(x);
@@ -178,24 +197,44 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     chk(dalloc(&e->dSounds, (size_t)cfg->max_sounds), "sounds");
     chk(dalloc(&e->dClips, (size_t)cfg->max_sounds), "clips");
     chk(dalloc(&e->dVoices, V), "voices");
-    chk(dalloc(&e->dVconst, V), "vconst");
-    chk(dalloc(&e->dRuns, V), "run lists");
-    chk(dalloc(&e->dPlanHdr, K * V), "plan headers");
-    chk(dalloc(&e->dPlanSeg0, K * V), "plan segment 0");
-    chk(dalloc(&e->dPlanSeg1, K * V), "plan segment 1");
-    chk(dalloc(&e->dSegs, K * V * (ZL_MAXSEG - 2)), "segments");
-    chk(dalloc(&e->dCtlP, K * V * N), "ctlP");
-    chk(dalloc(&e->dCtlEnv, K * V * N), "ctlEnv");
+    {
+        // plan window: K1 -> K2 records are sized for `window` blocks and double buffered; plan_window_blocks
+        // overrides the default of min(512, max_batch_blocks) blocks
+        int w = cfg->plan_window_blocks > 0 ? cfg->plan_window_blocks : 2048;
+        if (w > cfg->max_batch_blocks) w = cfg->max_batch_blocks;
+        e->window = w;
+        const size_t W = (size_t)w;
+        chk(hipStreamCreateWithFlags(&e->planStream, hipStreamNonBlocking), "plan stream");
+        chk(hipEventCreateWithFlags(&e->evStart, hipEventDisableTiming), "event");
+        const int nsets = (cfg->max_batch_blocks > w) ? 2 : 1;
+        for (int i = 0; i < 2; ++i) {
+            zlhip_engine::PlanSet &q = e->ps[i];
+            chk(hipEventCreateWithFlags(&q.planned, hipEventDisableTiming), "event");
+            chk(hipEventCreateWithFlags(&q.rendered, hipEventDisableTiming), "event");
+            if (i >= nsets) continue;
+            chk(dalloc(&q.vconst, V), "vconst");
+            chk(dalloc(&q.runs, V), "run lists");
+            chk(dalloc(&q.hdr, W * V), "plan headers");
+            chk(dalloc(&q.seg0, W * V), "plan segment 0");
+            chk(dalloc(&q.seg1, W * V), "plan segment 1");
+            chk(dalloc(&q.segs, W * V * (ZL_MAXSEG - 2)), "segments");
+            chk(dalloc(&q.ctlP, W * V * N), "ctlP");
+            chk(dalloc(&q.ctlEnv, W * V * N), "ctlEnv");
+            chk(dalloc(&q.expandList, W * V), "expand list");
+            chk(dalloc(&q.expandCount, 1), "expand count");
+            chk(dalloc(&q.partials, e->maxGroups > 1 ? W * B * (size_t)e->maxGroups * 2 * N : 1), "partials");
+        }
+        const size_t nwin = (K + W - 1) / W + 1;                  // + the short first window
+        e->evK2.assign(2 * nwin, nullptr);
+        for (auto &x : e->evK2) chk(hipEventCreate(&x), "hipEventCreate");
+    }
     chk(dalloc(&e->dReports, V), "reports");
     chk(dalloc(&e->dGain, V), "gain");
-    chk(dalloc(&e->dPartials, e->maxGroups > 1 ? K * B * (size_t)e->maxGroups * 2 * N : 1), "partials");
     chk(dalloc(&e->dBus, B * 2 * K * N), "bus");
     chk(dalloc(&e->dLevels, K * B), "levels");
     chk(dalloc(&e->dLevelState, B), "levelState");
     chk(dalloc(&e->dClocks, K), "clocks");
     chk(dalloc(&e->dStats, 1), "stats");
-    chk(dalloc(&e->dExpandList, K * V), "expand list");
-    chk(dalloc(&e->dExpandCount, 1), "expand count");
     chk(dalloc(&e->dPass, B), "passthrough params");
     chk(hipHostMalloc((void **)&e->hClocks, K * sizeof(ZlClock)), "hClocks");
     chk(hipHostMalloc((void **)&e->hReports, V * sizeof(ZlReport)), "hReports");
@@ -405,15 +444,15 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     ZL_HIP(e, hipMemcpyAsync(e->dClocks, e->hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, s));
 
     ZlBatch A; std::memset(&A, 0, sizeof A);
-    A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.N = nframes;
+    A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.N = nframes; A.Ktot = nblocks;
     A.G = pick_group(e, nblocks, nframes);
     A.groups = (A.VPB + A.G - 1) / A.G;
     A.mode = e->cfg.mode;
-    A.clocks = e->dClocks; A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
-    A.voices = e->dVoices; A.vconst = e->dVconst; A.runs = e->dRuns; A.plan_hdr = e->dPlanHdr; A.plan_seg0 = e->dPlanSeg0; A.plan_seg1 = e->dPlanSeg1; A.segs = e->dSegs;
-    A.ctl_P = e->dCtlP; A.ctl_env = e->dCtlEnv; A.reports = e->dReports; A.partials = e->dPartials;
-    A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.levels = e->dLevels; A.stats = e->dStats;
+    A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
+    A.voices = e->dVoices; A.reports = e->dReports;
+    A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.stats = e->dStats;
     A.trace = 0; A.pos_trace = nullptr;
+    int32_t *traceBase = nullptr;
     if (e->trace) {
         const size_t need = (size_t)nblocks * e->V * nframes;
         if (need > e->traceInts) {
@@ -422,7 +461,7 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
             e->traceInts = need;
         }
         ZL_HIP(e, hipMemsetAsync(e->dTrace, 0xff, need * sizeof(int32_t), s));
-        A.trace = 1; A.pos_trace = e->dTrace; e->traceK = nblocks; e->traceN = nframes;
+        A.trace = 1; traceBase = e->dTrace; e->traceK = nblocks; e->traceN = nframes;
 #ifdef ZL_STAMPS
         A.trace = 0;       // diagnostic build: the trace buffer receives per-workgroup timestamps instead
 #endif
@@ -430,17 +469,55 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     rc = upload_ops(e, A, s);
     if (rc != ZLHIP_OK) return rc;
     ZL_HIP(e, hipMemsetAsync(e->dStats, 0, sizeof(ZlBatchStats), s));
-    ZL_HIP(e, hipMemsetAsync(e->dExpandCount, 0, sizeof(int32_t), s));
-    A.expand_list = e->dExpandList; A.expand_count = e->dExpandCount;
 
+    // ---- plan windows: K0/K1/K1b of window i+1 run on the planning stream while K2/K3 of window i render ----
+    // Window layout: large windows keep K2 launches long (their ramp-up and drain are a fixed cost per launch); the
+    // first window of a multi-window call is short because its planning is the only one rendering cannot hide.
+    const int W = e->window;
+    std::vector<std::pair<int, int>> wins;                         // (first block, blocks)
+    if (nblocks <= W || e->ps[1].hdr == nullptr) {
+        for (int k0 = 0; k0 < nblocks; k0 += W) wins.push_back({k0, std::min(W, nblocks - k0)});
+    } else {
+        const int first = std::min(W, 256);
+        wins.push_back({0, first});
+        for (int k0 = first; k0 < nblocks; k0 += W) wins.push_back({k0, std::min(W, nblocks - k0)});
+    }
+    const int nwin = (int)wins.size();
+    const bool overlap = nwin > 1 && e->ps[1].hdr != nullptr;
+    hipStream_t ps = overlap ? e->planStream : s;
+    if (overlap) {
+        ZL_HIP(e, hipEventRecord(e->evStart, s));                  // clocks / ops / memsets above
+        ZL_HIP(e, hipStreamWaitEvent(ps, e->evStart, 0));
+    }
     if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[0], s));
-    ZL_KERNEL(e, zl_launch_apply_ops(A, s));
-    ZL_KERNEL(e, zl_launch_plan(A, e->forceSlow, s));
-    ZL_KERNEL(e, zl_launch_expand(A, s));
-    if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[1], s));
-    ZL_KERNEL(e, zl_launch_render(A, s));
-    if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[2], s));
-    ZL_KERNEL(e, zl_launch_finalize(A, nullptr, s));
+    for (int w = 0; w < nwin; ++w) {
+        zlhip_engine::PlanSet &q = e->ps[overlap ? (w & 1) : 0];
+        ZlBatch Aw = A;
+        Aw.k0 = wins[(size_t)w].first;
+        Aw.K = wins[(size_t)w].second;
+        Aw.clocks = e->dClocks + Aw.k0;
+        Aw.levels = e->dLevels + (size_t)Aw.k0 * A.B;
+        Aw.pos_trace = traceBase ? traceBase + (size_t)Aw.k0 * e->V * nframes : nullptr;
+        Aw.vconst = q.vconst; Aw.runs = q.runs; Aw.plan_hdr = q.hdr; Aw.plan_seg0 = q.seg0; Aw.plan_seg1 = q.seg1; Aw.segs = q.segs;
+        Aw.ctl_P = q.ctlP; Aw.ctl_env = q.ctlEnv; Aw.expand_list = q.expandList; Aw.expand_count = q.expandCount; Aw.partials = q.partials;
+        if (w > 0) { Aw.n_op_ranges = 0; Aw.ops = nullptr; Aw.op_ranges = nullptr; }     // commands apply before the first block only
+        // planning of window w may not overwrite the set while window w-2 is still being rendered from it
+        if (overlap && w >= 2) ZL_HIP(e, hipStreamWaitEvent(ps, q.rendered, 0));
+        ZL_HIP(e, hipMemsetAsync(q.expandCount, 0, sizeof(int32_t), ps));
+        ZL_KERNEL(e, zl_launch_apply_ops(Aw, ps));
+        ZL_KERNEL(e, zl_launch_plan(Aw, e->forceSlow, ps));
+        ZL_KERNEL(e, zl_launch_expand(Aw, ps));
+        if (overlap) {
+            ZL_HIP(e, hipEventRecord(q.planned, ps));
+            ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
+        }
+        if (e->profiling) ZL_HIP(e, hipEventRecord(e->evK2[2 * (size_t)w], s));
+        ZL_KERNEL(e, zl_launch_render(Aw, s));
+        if (e->profiling) ZL_HIP(e, hipEventRecord(e->evK2[2 * (size_t)w + 1], s));
+        ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
+        if (overlap) ZL_HIP(e, hipEventRecord(q.rendered, s));
+    }
+    e->lastWindows = nwin;
     ZL_KERNEL(e, zl_launch_reports(e->dReports, e->V, e->dGain, s));
     if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[3], s));
     ZL_HIP(e, hipMemcpyAsync(e->hReports, e->dReports, (size_t)e->V * sizeof(ZlReport), hipMemcpyDeviceToHost, s));
@@ -597,7 +674,7 @@ int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblo
     ZL_HIP(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     ZlBatch A; std::memset(&A, 0, sizeof A);
-    A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.N = nframes; A.G = A.VPB; A.groups = 1;
+    A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.Ktot = nblocks; A.k0 = 0; A.N = nframes; A.G = A.VPB; A.groups = 1;
     A.levels = e->dLevels; A.bus = nullptr;
     ZL_KERNEL(e, zl_launch_finalize(A, bus_dev, s));
     if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->ev[4], s)); ZL_HIP(e, hipStreamWaitEvent(e->stream, e->ev[4], 0)); }
@@ -643,11 +720,20 @@ int zlhip_last_timings(zlhip_engine *e, zlhip_timings *out)
     e->outstanding = false;
     if (e->profiling && e->lastK > 0) {
         ZL_HIP(e, hipEventSynchronize(e->ev[3]));
-        ZL_HIP(e, hipEventElapsedTime(&out->plan_ms, e->ev[0], e->ev[1]));
-        ZL_HIP(e, hipEventElapsedTime(&out->render_ms, e->ev[1], e->ev[2]));
-        ZL_HIP(e, hipEventElapsedTime(&out->finalize_ms, e->ev[2], e->ev[3]));
         ZL_HIP(e, hipEventElapsedTime(&out->total_ms, e->ev[0], e->ev[3]));
+        float k2 = 0.0f;
+        for (int w = 0; w < e->lastWindows; ++w) {
+            float t = 0.0f;
+            ZL_HIP(e, hipEventElapsedTime(&t, e->evK2[2 * (size_t)w], e->evK2[2 * (size_t)w + 1]));
+            k2 += t;
+        }
+        out->render_ms = k2;                                       // sum over the K2 launches of the call
+        float first = 0.0f;
+        ZL_HIP(e, hipEventElapsedTime(&first, e->ev[0], e->evK2[0]));
+        out->plan_ms = first;                                      // planning that is NOT hidden behind rendering (first window)
+        out->finalize_ms = out->total_ms - k2 - first;             // K3 + reports + gaps between launches
     }
+    out->render_launches = e->lastWindows;
     out->source_bytes = e->hStats->source_bytes;
     out->slow_blocks = e->hStats->slow_blocks;
     out->active_voice_frames = e->hStats->active_frames;

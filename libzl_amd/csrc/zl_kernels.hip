@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
             for (int i = threadIdx.x; i < nk * (int)(sizeof(ZlClock) / 16); i += blockDim.x) sh[i] = g[i];
         }
         __syncthreads();
-        if (mine) {
+        if (mine && pl.valid && pl.st.playing) {               // idle voices need no per-block work (ZlRunList::dead_from)
             for (int k = 0; k < nk;) {
                 const int m = pl.fast_forward(A, kb + k, kb + nk, s_clk + k, force_slow);
                 if (m) { k += m; continue; }
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     const int v0 = bus * A.VPB + g * A.G;
     const int vend = (bus + 1) * A.VPB;
     const int v1 = (v0 + A.G < vend) ? v0 + A.G : vend;
-    const bool wantPeak = (k == A.K - 1);
+    const bool wantPeak = (A.k0 + k == A.Ktot - 1);               // the report covers the last block of the call
     const double fd = (double)f;
 #ifdef ZL_STAMPS
     unsigned long long zl_t0 = __builtin_amdgcn_s_memrealtime(), zl_t1 = 0, zl_paths = 0;
@@ -345,8 +345,8 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
 #endif
     float *outL, *outR;
     if (A.groups == 1) {
-        const size_t KN = (size_t)A.K * N;
-        outL = A.bus + ((size_t)bus * 2) * KN + (size_t)k * N;
+        const size_t KN = (size_t)A.Ktot * N;
+        outL = A.bus + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N;
         outR = outL + KN;
     } else {
         outL = A.partials + ((((size_t)k * A.B + bus) * A.groups + g) * 2) * (size_t)N;
@@ -376,10 +376,10 @@ static __device__ __forceinline__ int zl_sample_to_peak_int(float x)
 __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const float *bus_in)
 {
     const int k = blockIdx.x, bus = blockIdx.y, N = A.N;
-    const size_t KN = (size_t)A.K * N;
-    float *outL = A.bus ? A.bus + ((size_t)bus * 2) * KN + (size_t)k * N : nullptr;
+    const size_t KN = (size_t)A.Ktot * N;
+    float *outL = A.bus ? A.bus + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N : nullptr;
     float *outR = outL ? outL + KN : nullptr;
-    const float *inL = bus_in ? bus_in + ((size_t)bus * 2) * KN + (size_t)k * N : outL;
+    const float *inL = bus_in ? bus_in + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N : outL;
     const float *inR = inL + KN;
 
     int pkL = 0, pkR = 0; float sqL = 0.0f, sqR = 0.0f;

@@ -281,7 +281,10 @@ struct ZlPlanner {
     int L, ie;
     int v, blocks_done;
     bool valid, posMode, clockMode, haveRun;
-    ZlRunList rl;
+    // run list: the open run lives in registers and is stored when the next one opens (no private-memory array)
+    ZlRun cur;
+    int  nruns;
+    bool haveCur;
 
     ZL_HD void begin(const ZlBatch &A, int voice)
     {
@@ -289,7 +292,7 @@ struct ZlPlanner {
         st = A.voices[v];
         stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
         blocks_done = 0;
-        rl.n = 0; rl.dead_from = 0;
+        nruns = 0; haveCur = false; cur.P = 0.0; cur.step = 0.0; cur.k0 = 0; cur.k1 = 0;
         s = 0.0; L = 0; ie = ZL_INF_STEPS; haveRun = false;
         valid = st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0;
         posMode = false; clockMode = false; X = INFINITY; blockBytes = 0; inv_r = 0.0;
@@ -351,15 +354,15 @@ struct ZlPlanner {
             m = j;
             if (m <= 0) return 0;
         }
-        // record: extend the previous run when this one continues it exactly
+        // record: extend the open run when this stretch continues it exactly, else close it and open a new one
         bool recorded = false;
-        if (rl.n > 0) {
-            ZlRun &last = rl.r[rl.n - 1];
-            if (last.k1 == k && last.step == s && fma((double)((k - last.k0) * N), s, last.P) == st.P) { last.k1 = k + m; recorded = true; }
-        }
-        if (!recorded && rl.n < ZL_MAXRUNS) {
-            ZlRun &r = rl.r[rl.n++];
-            r.P = st.P; r.step = s; r.k0 = k; r.k1 = k + m;
+        if (haveCur && cur.k1 == k && cur.step == s && fma((double)((k - cur.k0) * N), s, cur.P) == st.P) {
+            cur.k1 = k + m;
+            recorded = true;
+        } else if (nruns + (haveCur ? 1 : 0) < ZL_MAXRUNS) {
+            if (haveCur) A.runs[v].r[nruns++] = cur;
+            cur.P = st.P; cur.step = s; cur.k0 = k; cur.k1 = k + m;
+            haveCur = true;
             recorded = true;
         }
         if (!recorded) {
@@ -517,8 +520,9 @@ struct ZlPlanner {
         }
         A.reports[v] = rep;
         A.voices[v] = st;
-        rl.dead_from = valid ? blocks_done : 0;                    // blocks >= dead_from are idle (voice ended or never played)
-        A.runs[v] = rl;
+        if (haveCur) A.runs[v].r[nruns++] = cur;
+        A.runs[v].n = nruns;
+        A.runs[v].dead_from = valid ? blocks_done : 0;             // blocks >= dead_from are idle (voice ended or never played)
     }
 };
 
@@ -562,7 +566,7 @@ ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanS
 {
     ZlPlanner pl;
     pl.begin(A, v);
-    for (int k = 0; k < A.K;) {
+    for (int k = 0; k < A.K && pl.valid && pl.st.playing;) {
         const int m = pl.fast_forward(A, k, A.K, A.clocks + k, force_slow);
         if (m) { k += m; continue; }
         pl.plan_block(A, k, A.clocks[k], force_slow);

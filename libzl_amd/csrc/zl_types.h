@@ -155,7 +155,8 @@ struct ZlBatchStats {
 
 // Launch-wide arguments (passed by value to the kernels).
 struct ZlBatch {
-    int32_t V, B, VPB, K, N;      // voices, buses, voices per bus, blocks, frames per block
+    int32_t V, B, VPB, K, N;      // voices, buses, voices per bus, blocks in this plan window, frames per block
+    int32_t k0, Ktot;             // first block of the window inside the call, blocks of the whole call (bus stride)
     int32_t G;                    // voices per render task (mix group); groups per bus = ceil(VPB / G)
     int32_t groups;
     uint32_t mode;
@@ -178,7 +179,7 @@ struct ZlBatch {
     float              *ctl_env;  // [K][V][N]
     ZlReport           *reports;  // [V]
     float              *partials; // [K][B][groups][2][N]  (only when groups > 1)
-    float              *bus;      // [B][2][K*N]
+    float              *bus;      // [B][2][Ktot*N]
     ZlBlockLevels      *levels;   // [K][B]
     int32_t            *pos_trace;// [K][V][N] or null
     ZlBatchStats       *stats;

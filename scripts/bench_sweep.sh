@@ -15,7 +15,7 @@ for line in open("gpurun_out/$TAG.jsonl"):
         print(line.strip()); continue
     try:
         d = json.loads(line); r = d["roofline"]
-        print(f"  value={d['value']:.3e} vs/s  ms/step={d['ms_per_step']:.3f}  k2={r['avg_launch_ms']:.3f} ms  {r['achieved']:.0f} GB/s ({100*r['frac']:.1f}%)  k1={r['other_kernels_ms']['zl_k1_plan+k0']:.3f} ms")
+        print(f"  value={d['value']:.3e} vs/s  ms/step={d['ms_per_step']:.3f}  k2={r['avg_launch_ms']:.3f} ms  {r['achieved']:.0f} GB/s ({100*r['frac']:.1f}%)  plan={list(r['other_ms_per_step'].values())[0]:.3f} other={list(r['other_ms_per_step'].values())[1]:.3f} ms/step launches={r['launches_per_step']}")
     except Exception as e:
         print("  parse error", e, line[:200])
 PY

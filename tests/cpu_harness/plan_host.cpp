@@ -161,7 +161,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     S->hc.drain_ops(ops, ranges);
 
     ZlBatch A; std::memset(&A, 0, sizeof A);
-    A.V = S->V; A.B = S->B; A.VPB = S->VPB; A.K = K; A.N = N; A.G = S->G; A.groups = (S->VPB + S->G - 1) / S->G; A.mode = S->mode;
+    A.V = S->V; A.B = S->B; A.VPB = S->VPB; A.K = K; A.N = N; A.k0 = 0; A.Ktot = K; A.G = S->G; A.groups = (S->VPB + S->G - 1) / S->G; A.mode = S->mode;
     A.clocks = ck.data(); A.sounds = S->sounds.data(); A.clips = S->clips.data(); A.arena = S->arena.data();
     A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data(); A.segs = S->segs.data();
     A.ctl_P = S->ctlP.data(); A.ctl_env = S->ctlEnv.data(); A.reports = S->reports.data();

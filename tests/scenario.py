@@ -130,14 +130,14 @@ def run_oracle(scene: Scene, batch: int = 1 << 30, threads: int = 1, fast: bool 
     return np.concatenate(buses, axis=2), reports, osyn
 
 
-def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bool = False, force_slow: bool = False):
+def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bool = False, force_slow: bool = False, **factory_kw):
     """factory(**kwargs) -> object with the libzl_amd.SamplerSynth surface (engine or CPU harness)."""
     # the oracle's setters are the single source of clip parameters for both sides
     ref = zo.OracleSynth(1, 1, scene.fs, scene.mode, max_sounds=max(8, len(scene.sounds)))
     syn = factory(num_buses=scene.num_buses, voices_per_bus=scene.voices_per_bus, mode=scene.mode,
                   playback_sample_rate=scene.fs, voices_per_task=scene.mix_group, max_frames=max(64, scene.nframes),
                   max_batch_blocks=max(1, min(batch, scene.nblocks)), max_sounds=max(8, len(scene.sounds)),
-                  sound_arena_bytes=max(1 << 20, sum((s[0].shape[0] + 16) * 8 for s in scene.sounds) + (1 << 16)))
+                  sound_arena_bytes=max(1 << 20, sum((s[0].shape[0] + 16) * 8 for s in scene.sounds) + (1 << 16)), **factory_kw)
     for i, (L, R, sr) in enumerate(scene.sounds):
         assert ref.register_clip(L, R, sr) == i
         cid = syn.register_clip(L, R, sr)

@@ -86,6 +86,22 @@ def test_mix_groups(Engine, group):
     syn.close()
 
 
+@pytest.mark.parametrize("window", [1, 3, 8])
+def test_plan_windows_overlap_planning_and_rendering(Engine, window):
+    """One call that spans several plan windows (K1 of window i+1 runs on the planning stream while K2 of window i
+    renders from the other buffer set) gives the same bits as the oracle, including events, tails and reports."""
+    sc = random_scene(1000 + window, nframes=128, nblocks=26, events=False)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, trace = run_backend(sc, Engine, batch=26, trace=True, plan_window_blocks=window)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    tr, _ = oracle_trace(sc)
+    assert np.array_equal(trace, tr)
+    syn.close()
+    bus2, rep2, syn2, _ = run_backend(sc, Engine, batch=26, plan_window_blocks=window)      # untraced (pipelined) path
+    compare_runs(ref_bus, ref_rep, ref_syn, bus2, rep2, sc.num_buses * sc.voices_per_bus)
+    syn2.close()
+
+
 def test_realtime_process_equals_batch(Engine):
     """zlhip_render (one JACK cycle, host buffers) gives the same bits as the batched path."""
     from libzl_amd.engine import synthetic_clocks

@@ -204,7 +204,12 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         if (w > cfg->max_batch_blocks) w = cfg->max_batch_blocks;
         e->window = w;
         const size_t W = (size_t)w;
-        chk(hipStreamCreateWithFlags(&e->planStream, hipStreamNonBlocking), "plan stream");
+        {
+            // planning is a small latency-bound kernel that rendering waits for: give its stream the highest priority
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            chk(hipStreamCreateWithPriority(&e->planStream, hipStreamNonBlocking, hi), "plan stream");
+        }
         chk(hipEventCreateWithFlags(&e->evStart, hipEventDisableTiming), "event");
         const int nsets = (cfg->max_batch_blocks > w) ? 2 : 1;
         for (int i = 0; i < 2; ++i) {
@@ -224,7 +229,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             chk(dalloc(&q.expandCount, 1), "expand count");
             chk(dalloc(&q.partials, e->maxGroups > 1 ? W * B * (size_t)e->maxGroups * 2 * N : 1), "partials");
         }
-        const size_t nwin = (K + W - 1) / W + 1;                  // + the short first window
+        const size_t nwin = (K + W - 1) / W + 16;                 // + the doubling windows at the start of a call
         e->evK2.assign(2 * nwin, nullptr);
         for (auto &x : e->evK2) chk(hipEventCreate(&x), "hipEventCreate");
     }
@@ -471,16 +476,21 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     ZL_HIP(e, hipMemsetAsync(e->dStats, 0, sizeof(ZlBatchStats), s));
 
     // ---- plan windows: K0/K1/K1b of window i+1 run on the planning stream while K2/K3 of window i render ----
-    // Window layout: large windows keep K2 launches long (their ramp-up and drain are a fixed cost per launch); the
-    // first window of a multi-window call is short because its planning is the only one rendering cannot hide.
+    // Window layout: large windows keep K2 launches long (their ramp-up and drain are a fixed cost per launch), but
+    // planning window i+1 must fit behind rendering window i, and the planning of the first window is hidden by
+    // nothing: windows start at 256 blocks and double up to the configured size.
     const int W = e->window;
     std::vector<std::pair<int, int>> wins;                         // (first block, blocks)
     if (nblocks <= W || e->ps[1].hdr == nullptr) {
         for (int k0 = 0; k0 < nblocks; k0 += W) wins.push_back({k0, std::min(W, nblocks - k0)});
     } else {
-        const int first = std::min(W, 256);
-        wins.push_back({0, first});
-        for (int k0 = first; k0 < nblocks; k0 += W) wins.push_back({k0, std::min(W, nblocks - k0)});
+        int size = std::min(W, 256);
+        for (int k0 = 0; k0 < nblocks;) {
+            const int n = std::min(size, nblocks - k0);
+            wins.push_back({k0, n});
+            k0 += n;
+            size = std::min(W, size * 2);
+        }
     }
     const int nwin = (int)wins.size();
     const bool overlap = nwin > 1 && e->ps[1].hdr != nullptr;

@@ -103,11 +103,38 @@ ZL_HD inline void zl_voice_hard_stop(ZlVoiceState &s)
 }
 
 // ---- exact linear runs of P += r --------------------------------------------------------------
+// Exponent of the lowest set bit of a finite positive double (the value is an odd multiple of 2^result).
+ZL_HD inline int zl_lsb_exponent(double x)
+{
+    const uint64_t b = zl_bits(x);
+    const int ex = (int)((b >> 52) & 0x7ff);
+    const uint64_t m = (b & 0xfffffffffffffull) | (ex ? (1ull << 52) : 0ull);
+    if (m == 0) return 4096;                                     // zero: a multiple of every power of two
+    return (ex ? ex : 1) - 1075 + __builtin_ctzll(m);
+}
+
 // Returns the per-step increment s and the number L >= 0 of consecutive additions starting at P
 // that are guaranteed to equal P + i*s exactly (i = 1..L).  L == 0 means "take one real addition".
 // inv_r = 1 / r (computed once per voice and batch); it only shortens runs conservatively.
 ZL_HD inline void zl_linear_run(double P, double r, double inv_r, double &s, int &L)
 {
+    // ---- exact-granule run: when P and r are both multiples of 2^g, every sum P + i*r is a multiple of 2^g and is
+    //      exactly representable (no rounding at all, across binades) while it stays below 2^(53+g).  Covers playback
+    //      at the source rate (r = 1), octaves and other dyadic ratios from integer loop starts.
+    if (P >= 0.0 && r > 0.0 && P < 0x1p62 && r < 0x1p62) {
+        const int gp = zl_lsb_exponent(P), gr = zl_lsb_exponent(r);
+        const int g = gp < gr ? gp : gr;
+        if (g > -1000 && g + 53 < 1000) {
+            const double limit = zl_from_bits((uint64_t)(g + 53 + 1023) << 52);      // 2^(53+g)
+            const double room = limit - P;                                           // exact (multiples of 2^g below 2^(53+g))
+            if (room >= r) {
+                double c0 = floor((room * inv_r) * (1.0 - 0x1p-30));
+                if (c0 > (double)ZL_RUN_CAP) c0 = (double)ZL_RUN_CAP;
+                for (int it = 0; it < 4 && c0 > 0.0 && fma(c0, r, -room) > 0.0; ++it) c0 -= 1.0;
+                if (c0 >= 1024.0 && !(fma(c0, r, -room) > 0.0)) { s = r; L = (int)c0; return; }
+            }
+        }
+    }
     s = 0.0; L = 0;
     const uint64_t pb = zl_bits(P);
     const int ex = (int)((pb >> 52) & 0x7ff);

@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the measured path) or gloo (rehearsal: reduce through host memory)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -144,12 +146,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU render path")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from libzl_amd import SamplerSynth
     from libzl_amd.engine import synthetic_clocks
@@ -177,11 +184,23 @@ def main():
     launches = 1
 
     from libzl_amd import sharding
+    overlapped = None
+    if distributed and args.dist_backend == "nccl":
+        overlapped = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32), dst=0)
 
     def step(i, timed):
         # render this rank's voices, sum the partial buses onto rank 0 (one RCCL reduce), levels on the root
-        if distributed:
-            sharding.render_sharded(syn, KB, N, clock_sets[i], bus, dst=0, stream=sptr)
+        if distributed and args.dist_backend != "nccl":
+            # rehearsal path: the collective runs on a host copy of the partial bus
+            syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr)
+            torch.cuda.synchronize()
+            host = bus.cpu()
+            sharding.reduce_bus(host, dst=0)
+            if rank == 0:
+                bus.copy_(host)
+                syn.levels_scan_device(bus.data_ptr(), KB, N, stream=sptr)
+        elif distributed:
+            overlapped.step(KB, N, clock_sets[i], stream=sptr)       # reduce of step i overlaps rendering of step i+1
         else:
             syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr)
 
@@ -202,6 +221,8 @@ def main():
             src_bytes = t.source_bytes
             slow = t.slow_blocks
             launches = max(1, t.render_launches)
+    if overlapped is not None:
+        overlapped.flush(stream=sptr)                                # the last reduces + level scans are inside the timed region
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()

@@ -524,7 +524,8 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         if (e->profiling) ZL_HIP(e, hipEventRecord(e->evK2[2 * (size_t)w], s));
         ZL_KERNEL(e, zl_launch_render(Aw, s));
         if (e->profiling) ZL_HIP(e, hipEventRecord(e->evK2[2 * (size_t)w + 1], s));
-        ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
+        // K2 scans the block for AudioLevels itself when one workgroup holds the whole block of the final mix
+        if (!(Aw.groups == 1 && nframes <= 256)) ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
         if (overlap) ZL_HIP(e, hipEventRecord(q.rendered, s));
     }
     e->lastWindows = nwin;

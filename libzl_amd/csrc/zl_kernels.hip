@@ -94,6 +94,14 @@ __global__ void __launch_bounds__(256) zl_k1b_expand(const ZlBatch A)
 // (SamplerSynth.cpp:136-140) and lives in two registers.  Every per-voice record is wave-uniform
 // (scalar loads); the only vector memory traffic is the 16-byte two-tap stereo gather and the
 // final coalesced store.
+static __device__ __forceinline__ int zl_sample_to_peak_int(float x)
+{
+    const float v = fabsf(131072.0f * x);                          // AudioLevels.cpp:356,367
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return 0x7fffffff;
+    return (int)v;
+}
+
 static __device__ __forceinline__ float zl_wave_max(float x)
 {
 #pragma unroll
@@ -352,27 +360,49 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
         outL = A.partials + ((((size_t)k * A.B + bus) * A.groups + g) * 2) * (size_t)N;
         outR = outL + N;
     }
+    bool written;
     if (MODE & ZL_MODE_FIX_DELAY) {
         outL[f] = accL; outR[f] = accR;
+        written = true;
     } else {
         // quirk Q2: the reference pre-increments its output pointers, so frame f lands in out[f+1],
         // out[0] stays 0 and the sample of the last frame falls outside the buffer (dropped)
-        if (f + 1 < N) { outL[f + 1] = accL; outR[f + 1] = accR; }
-        if (f == 0)    { outL[0] = 0.0f;    outR[0] = 0.0f; }
+        written = f + 1 < N;
+        if (written) { outL[f + 1] = accL; outR[f + 1] = accR; }
+        if (f == 0)  { outL[0] = 0.0f;    outR[0] = 0.0f; }
+    }
+    // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of the
+    //      whole block (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
+    if (A.groups == 1 && gridDim.x == 1 && A.levels) {
+        __shared__ int   s_pk[2][4];
+        __shared__ float s_sq[2][4];
+        int pkL = written ? zl_sample_to_peak_int(accL) : 0, pkR = written ? zl_sample_to_peak_int(accR) : 0;
+        float sqL = written ? accL * accL : 0.0f, sqR = written ? accR * accR : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int a = __shfl_xor(pkL, o, 64), b = __shfl_xor(pkR, o, 64);
+            pkL = a > pkL ? a : pkL; pkR = b > pkR ? b : pkR;
+            sqL += __shfl_xor(sqL, o, 64); sqR += __shfl_xor(sqR, o, 64);
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_pk[0][w] = pkL; s_pk[1][w] = pkR; s_sq[0][w] = sqL; s_sq[1][w] = sqR; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nw = (blockDim.x + 63) >> 6;
+            ZlBlockLevels lv; lv.peak_l = 0; lv.peak_r = 0; lv.sumsq_l = 0.0f; lv.sumsq_r = 0.0f;
+            for (int i = 0; i < nw; ++i) {
+                lv.peak_l = s_pk[0][i] > lv.peak_l ? s_pk[0][i] : lv.peak_l;
+                lv.peak_r = s_pk[1][i] > lv.peak_r ? s_pk[1][i] : lv.peak_r;
+                lv.sumsq_l += s_sq[0][i]; lv.sumsq_r += s_sq[1][i];
+            }
+            A.levels[(size_t)k * A.B + bus] = lv;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3: one workgroup per (block, bus).  Sums the mix-group partials in group order (when there are
 // any), writes the bus, and scans it for the AudioLevels integer peak and the RMS extension.
-static __device__ __forceinline__ int zl_sample_to_peak_int(float x)
-{
-    const float v = fabsf(131072.0f * x);                          // AudioLevels.cpp:356,367
-    if (!(v == v)) return 0;
-    if (v >= 2147483648.0f) return 0x7fffffff;
-    return (int)v;
-}
-
 __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const float *bus_in)
 {
     const int k = blockIdx.x, bus = blockIdx.y, N = A.N;

@@ -50,3 +50,39 @@ def render_sharded(synth, nblocks: int, nframes: int, clocks, bus, dst: int = 0,
     if not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == dst:
         synth.levels_scan_device(bus.data_ptr(), nblocks, nframes, stream=stream)
     return bus
+
+
+class OverlappedBusReduce:
+    """Double-buffered partial buses: the RCCL reduce of batch i runs on the collective stream while batch i+1
+    renders into the other buffer (xGMI is point-to-point, ~153 GB/s per link, so a 100+ MB bus takes about as
+    long to reduce as to render; hiding it keeps the weak-scaling curve flat)."""
+
+    def __init__(self, synth, make_bus, dst: int = 0, group=None):
+        self.synth, self.dst, self.group = synth, dst, group
+        self.bus = [make_bus(), make_bus()]
+        self.work = [None, None]
+        self.shape = [None, None]
+        self.i = 0
+
+    def _finish(self, j, stream):
+        import torch.distributed as dist
+        if self.work[j] is not None:
+            self.work[j].wait()                       # the current stream waits for the collective
+            self.work[j] = None
+            if dist.get_rank(self.group) == self.dst and self.shape[j] is not None:
+                nb, nf = self.shape[j]
+                self.synth.levels_scan_device(self.bus[j].data_ptr(), nb, nf, stream=stream)   # levels see the final mix
+
+    def step(self, nblocks: int, nframes: int, clocks, stream=None):
+        import torch.distributed as dist
+        j = self.i & 1
+        self._finish(j, stream)                       # buffer j was reduced two steps ago
+        self.synth.render_batch(nblocks, nframes, clocks, bus_out_dev=self.bus[j].data_ptr(), stream=stream)
+        self.work[j] = dist.reduce(self.bus[j], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.shape[j] = (nblocks, nframes)
+        self.i += 1
+        return self.bus[j]
+
+    def flush(self, stream=None):
+        for j in ((self.i & 1), ((self.i + 1) & 1)):
+            self._finish(j, stream)

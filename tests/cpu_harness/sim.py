@@ -77,10 +77,18 @@ class SimSynth:
     def start_voice(self, bus, slot, cmd, current_tick=0):
         return self.l.zlsim_start_voice(self.s, bus, slot, C.byref(cmd), current_tick)
 
-    def render_batch(self, nblocks, nframes, clocks, *a, **k):
+    def render_batch(self, nblocks, nframes, clocks, bus_out_dev=None, stream=None):
         self._bus = np.zeros((self.num_buses, 2, nblocks * nframes), dtype=np.float32)
         self.l.zlsim_render_batch(self.s, nblocks, nframes, clocks, self._bus.ctypes.data, 1 if self.force_slow else 0)
         self._last = (nblocks, nframes)
+        if bus_out_dev:                                  # "device" buffer of the caller = host memory in this harness
+            C.memmove(bus_out_dev, self._bus.ctypes.data, self._bus.nbytes)
+
+    def levels_scan_device(self, bus_ptr, nblocks, nframes, stream=None):
+        n = self.num_buses * 2 * nblocks * nframes
+        buf = np.ctypeslib.as_array(C.cast(bus_ptr, C.POINTER(C.c_float)), (n,)).reshape(self.num_buses, 2, nblocks, nframes)
+        v = np.abs(np.float32(131072.0) * buf)
+        self.scanned_peaks = v.astype(np.int64).max(axis=3).transpose(2, 0, 1)      # [block][bus][channel]
 
     def read_bus(self):
         return self._bus

@@ -43,8 +43,17 @@ def _worker(rank, world, port, q):
     bus, rep, syn, _ = run_backend(sc, SimSynth, batch=5)
     t = torch.from_numpy(np.ascontiguousarray(bus))
     sharding.reduce_bus(t, dst=0)
+    # the double-buffered, overlapped variant bench.py uses at N > 1: three more batches of the same voices
+    from libzl_amd.engine import synthetic_clocks
+    ov = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((sc.num_buses, 2, 4 * sc.nframes), dtype=torch.float32), dst=0)
+    outs = []
+    for i in range(3):
+        b = ov.step(4, sc.nframes, synthetic_clocks(4, sc.nframes, sc.fs, start_block=sc.nblocks + 4 * i, bpm=sc.bpm))
+        outs.append(b)
+    ov.flush()
+    tail = torch.cat([outs[0], outs[1], outs[2]], dim=2) if rank == 0 else None      # buffers 0 and 1 alternate: outs[2] is outs[0]
     if rank == 0:
-        q.put(t.numpy().copy())
+        q.put((t.numpy().copy(), outs[1].numpy().copy(), outs[2].numpy().copy(), getattr(syn, "scanned_peaks", None)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,7 +68,7 @@ def test_sharded_voices_reduce_to_the_full_mix(built, world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=180)
+    got, tail1, tail2, peaks = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -69,6 +78,14 @@ def test_sharded_voices_reduce_to_the_full_mix(built, world):
     sc.mix_group = sc.voices_per_bus // world                      # the sharded order: per-rank partial sums, then a + b
     grouped, _, _ = run_oracle(sc)
     assert np.array_equal(grouped.view(np.int32), got.view(np.int32))
+    # overlapped path: blocks 10..21 of the same scene (batches 2 and 3 are what the two buffers hold at the end)
+    sc.nblocks = 22
+    longer, _, _ = run_oracle(sc)
+    N = sc.nframes
+    assert np.array_equal(longer[:, :, 14 * N:18 * N].view(np.int32), tail1.view(np.int32))
+    assert np.array_equal(longer[:, :, 18 * N:22 * N].view(np.int32), tail2.view(np.int32))
+    exp = np.abs(np.float32(131072.0) * tail2.reshape(sc.num_buses, 2, 4, N)).astype(np.int64).max(axis=3).transpose(2, 0, 1)
+    assert peaks is not None and np.array_equal(peaks, exp)          # levels were scanned on the reduced bus, on the root
 
 
 def test_partition_helpers():

@@ -159,6 +159,68 @@ def test_full_voice_count_bit_exact_against_oracle(Engine):
     syn.close()
 
 
+def test_config1_shape_64_voices_resampled(Engine):
+    """BASELINE configs[1]: 64 stereo voices, linear-interp resample (44.1 kHz and 48 kHz sources, notes +-12),
+    48 kHz playback, 256-frame blocks; attack/decay envelopes as SURVEY.md section 8d cfg 2."""
+    rng = np.random.default_rng(0x5A17 + 1)
+    sc = Scene(num_buses=8, voices_per_bus=8, fs=48000.0, nframes=256, nblocks=40)
+    ev = []
+    for v in range(64):
+        sr = [44100.0, 48000.0][v % 2]
+        L, R = rand_source(rng, int(rng.integers(int(0.05 * sr), int(0.12 * sr))), stereo=True)
+        sc.sounds.append((L, R, sr))
+        vol, pan, A, S = float(rng.uniform(0.25, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(0, 0.05)), float(rng.uniform(0.5, 1))
+        beats = float(rng.uniform(0.04, 0.09))
+
+        def setup(lib, clip, vol=vol, pan=pan, A=A, S=S, beats=beats):
+            lib.zlo_clip_set_length(clip, C.c_float(beats), 120)
+            lib.zlo_clip_set_volume_absolute(clip, C.c_float(vol))
+            lib.zlo_clip_set_pan(clip, C.c_float(pan))
+            clip.adsr.p.attack, clip.adsr.p.decay, clip.adsr.p.sustain, clip.adsr.p.release = (A, 0.1, S, 0.05)
+        sc.clip_setup[v] = setup
+        ev.append(("cmd", play_cmd(v, midi_channel=v // 8 - 2, note=60 + int(rng.integers(-12, 13)), volume=float(np.float32(rng.uniform(0.1, 1)))), 0))
+    sc.events[0] = ev
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=40)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 64)
+    syn.close()
+
+
+def test_config2_shape_1024_loops_128_frames_levels(Engine):
+    """BASELINE configs[2]: 1024 stereo clip loops, per-clip gain/pan, AudioLevels peaks every block, 128-frame blocks."""
+    sc = _big_scene(V=1024, B=16, nframes=128, nblocks=30, seed=0x5A17 + 2)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc, threads=8)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=30)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 1024)
+    peaks = syn.block_peaks()
+    exp = np.stack([np.abs(np.float32(131072.0) * bus[:, c].reshape(16, 30, 128)).astype(np.int64).max(axis=2) for c in (0, 1)], axis=-1)
+    assert np.array_equal(peaks, exp.transpose(1, 0, 2))
+    syn.close()
+
+
+def test_config5_shape_96k_batched_bounce(Engine):
+    """BASELINE configs[4] in miniature: 96 kHz sources and playback, many voices, long batched render that spans
+    several plan windows; throughput-only in the benchmark, parity here."""
+    rng = np.random.default_rng(0x5A17 + 5)
+    V, B = 512, 4
+    sc = Scene(num_buses=B, voices_per_bus=V // B, fs=96000.0, nframes=256, nblocks=48)
+    ev = []
+    for v in range(V):
+        L, R = rand_source(rng, 5000 + int(rng.integers(0, 900)), stereo=True)
+        sc.sounds.append((L, R, 96000.0))
+
+        def setup(lib, clip, v=v):
+            clip.lengthInBeats = 2.5
+            clip.lengthInSeconds = float(np.float32((4800 - v % 23) / 96000.0))
+        sc.clip_setup[v] = setup
+        ev.append(("start", v // (V // B), v % (V // B), play_cmd(v, midi_channel=v // (V // B) - 2, note=60, volume=0.5), 0))
+    sc.events[0] = ev
+    ref_bus, ref_rep, ref_syn = run_oracle(sc, threads=8)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=48, plan_window_blocks=16)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, V)
+    syn.close()
+
+
 def test_config4_shape_pitched_hermite(Engine):
     """BASELINE config 4 per-GPU shape: 1024 voices on one bus, pitch 0.5-2x, 4-tap Hermite (build-defined extension)."""
     sc = _big_scene(V=1024, B=1, nblocks=8, hermite=True, ratios=True, seed=0x5A1B)

@@ -619,16 +619,20 @@ int zlhip_debug_read_trace(zlhip_engine *e, int32_t *out, size_t out_ints)
 }
 
 // ---- levels -------------------------------------------------------------------------------------
+// libm calls exactly as the reference makes them (no compiler rewrite such as pow(10, x) -> exp10(x))
+static double (*volatile zl_pow)(double, double) = static_cast<double (*)(double, double)>(std::pow);
+static float (*volatile zl_log10f)(float) = static_cast<float (*)(float)>(log10f);
+
 static float convert_to_dbfs(float raw)                            // AudioLevels.cpp:330-341
 {
     if (raw <= 0) return -200;
-    const float fValue = 20 * log10f(raw);
+    const float fValue = 20 * zl_log10f(raw);
     if (fValue < -200) return -200;
     return fValue;
 }
 static float add_float_db(float db1, float db2)                    // AudioLevels.cpp:234-236
 {
-    return 10 * log10f((float)(std::pow(10, db1 / 10) + std::pow(10, db2 / 10)));
+    return 10 * zl_log10f((float)(zl_pow(10, db1 / 10) + zl_pow(10, db2 / 10)));
 }
 
 int zlhip_levels_tick(zlhip_engine *e, int32_t block_index, int32_t with_hold_bus, zlhip_levels *out)

@@ -19,6 +19,11 @@
 #include "zl_plan.h"
 #include "zl_types.h"
 
+// std::pow(2.0, x) exactly as the reference calls it (SamplerSynthVoice.cpp:115).  Called through a volatile
+// pointer because clang rewrites pow(2.0, x) into exp2(x), which differs from glibc's pow in the last bit for some
+// x -- enough to move sourceSamplePosition by an ulp after a few hundred frames.
+static double (*volatile zl_libm_pow)(double, double) = static_cast<double (*)(double, double)>(std::pow);
+
 struct ZlHostVoice {                     // control-plane view of one SamplerSynthVoice
     bool hasCommand = false;             // d->clipCommand != nullptr
     zlhip_clip_command cmd{};            // *d->clipCommand
@@ -84,7 +89,7 @@ struct ZlHostControl {
         ZlVoiceOp op; std::memset(&op, 0, sizeof op);
         op.voice = v; op.kind = ZL_OP_START;
         ZlVoiceState &s = op.start;
-        s.pitch_ratio = std::pow(2.0, (cmd.midi_note - cp.root_note) / 12.0) * sr / playback_sample_rate;   // :115-116
+        s.pitch_ratio = zl_libm_pow(2.0, (cmd.midi_note - cp.root_note) / 12.0) * sr / playback_sample_rate;   // :115-116
         s.src_len = cp.duration_seconds * sr;                                                               // :120
         s.P = (int)(clip_start_position(cp, cmd.slice) * sr);                                                // :121
         s.next_loop_tick = zl_f32_to_u64_sat(tick + cp.length_in_beats * ZLHIP_BEAT_SUBDIVISIONS);           // :123 (u64 + float -> float)

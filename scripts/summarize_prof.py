@@ -32,12 +32,12 @@ def main(root, out):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 acc[row.get("Kernel_Name", "?")][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", 0)))
-        lines.append(f"## counters ({os.path.relpath(f, root)}): kernel, counter, dispatches, mean per dispatch")
+        lines.append(f"## counters ({os.path.relpath(f, root)}): kernel, counter, dispatches, mean per dispatch, sum over dispatches")
         for name, cs in acc.items():
             if "zl_k" not in name:
                 continue
             for c, vals in sorted(cs.items()):
-                lines.append(f"{name[:60]}, {c}, {len(vals)}, {sum(vals) / len(vals):.1f}")
+                lines.append(f"{name[:60]}, {c}, {len(vals)}, {sum(vals) / len(vals):.1f}, {sum(vals):.1f}")
     with open(out, "w") as fh:
         fh.write("\n".join(lines) + "\n")
 

@@ -37,30 +37,33 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 VOICE_STATE_BYTES = 104        # sizeof(ZlVoiceState)
 
 
-def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, seed, bpm=120):
-    """Registers one distinct stereo loop per voice (generated on the device) and starts every voice."""
+def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, seed, bpm=120, notes=(60, 60), source_rate=None):
+    """Registers one distinct stereo loop per voice (generated on the device) and starts every voice.
+    `notes` = inclusive MIDI-note range drawn per voice (root note 60: 48..72 is pitch ratio 0.5..2)."""
+    source_rate = source_rate or fs
     from libzl_amd import clip_command
     V = voices_per_bus * num_buses
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     for v in range(V):
         src = torch.rand((2, loop_frames), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0
-        cid = syn.register_clip_device(src[0].data_ptr(), src[1].data_ptr(), loop_frames, fs)
+        cid = syn.register_clip_device(src[0].data_ptr(), src[1].data_ptr(), loop_frames, source_rate)
         assert cid == v
         del src
     torch.cuda.synchronize()
     rng = np.random.default_rng(seed)
     for v in range(V):
-        p = syn.default_clip_params(loop_frames / fs)
+        p = syn.default_clip_params(loop_frames / source_rate)
         # fractional beat length -> deterministic sample-space loop wrap (SamplerSynthVoice.cpp:243-246)
         p.length_in_beats = 3.5
-        p.length_seconds = float(np.float32((loop_frames - 64 - (v % 17)) / fs))
+        p.length_seconds = float(np.float32((loop_frames - 64 - (v % 17)) / source_rate))
         p.volume_absolute = float(np.float32(rng.uniform(0.25, 1.0)))
         p.pan = float(np.float32(rng.uniform(-1.0, 1.0)))
         syn.set_clip_params(v, p)
     for v in range(V):
         bus, slot = divmod(v, voices_per_bus)
-        cmd = clip_command(clip=v, midi_note=60, midi_channel=bus - 2, start_playback=1, looping=1,
+        note = 60 if notes[0] == notes[1] else int(rng.integers(notes[0], notes[1] + 1))
+        cmd = clip_command(clip=v, midi_note=note, midi_channel=bus - 2, start_playback=1, looping=1,
                            change_volume=1, volume=float(np.float32(rng.uniform(0.1, 1.0))))
         assert syn.start_voice(bus, slot, cmd, 0) == 1
 
@@ -126,6 +129,9 @@ def main():
     ap.add_argument("--blocks-per-step", type=int, default=8192)
     ap.add_argument("--fs", type=float, default=48000.0)
     ap.add_argument("--loop-seconds", type=float, default=2.0)
+    ap.add_argument("--notes", default="60,60", help="MIDI note range per voice (root 60); 48,72 = pitch ratio 0.5..2 (config 4)")
+    ap.add_argument("--hermite", action="store_true", help="4-tap Hermite interpolation (ZLHIP_MODE_HERMITE, config 4)")
+    ap.add_argument("--source-rate", type=float, default=0.0, help="sample rate of the sources (default: --fs)")
     ap.add_argument("--voices-per-task", type=int, default=0)
     ap.add_argument("--plan-window", type=int, default=0)
     ap.add_argument("--cpu-blocks", type=int, default=64)
@@ -163,12 +169,14 @@ def main():
 
     V, B, N, KB = args.voices, args.buses, args.frames, args.blocks_per_step
     vpb = V // B
-    loop_frames = int(args.loop_seconds * args.fs)
+    notes = tuple(int(x) for x in args.notes.split(","))
+    source_rate = args.source_rate or args.fs
+    loop_frames = int(args.loop_seconds * source_rate)
     arena = (loop_frames + 16) * 8 * V + (1 << 20)
-    syn = SamplerSynth(B, vpb, max_frames=N, max_batch_blocks=KB, max_sounds=V, mode=0, playback_sample_rate=args.fs,
+    syn = SamplerSynth(B, vpb, max_frames=N, max_batch_blocks=KB, max_sounds=V, mode=(4 if args.hermite else 0), playback_sample_rate=args.fs,
                        sound_arena_bytes=arena, voices_per_task=args.voices_per_task, plan_window_blocks=args.plan_window, device=local_rank)
     seed = 0x5A17 + 2 + 1000 * rank
-    build_scene(syn, torch, dev, vpb, B, args.fs, loop_frames, seed)
+    build_scene(syn, torch, dev, vpb, B, args.fs, loop_frames, seed, notes=notes, source_rate=source_rate)
     syn.set_profiling(True)
 
     # the engine renders into a torch-owned device buffer so the RCCL reduce needs no copy
@@ -253,7 +261,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{V} looping stereo voices per GPU on {B} buses x {vpb}, {N}-frame blocks, {KB} blocks per step ({launches} K2 launches), "
-                            f"fs=sr={args.fs:.0f} (ratio 1), linear interp, faithful mode, distinct {args.loop_seconds:g} s sources "
+                            + (f"fs=sr={args.fs:.0f} (ratio 1)" if notes[0] == notes[1] and source_rate == args.fs else
+                               f"fs={args.fs:.0f}, sources at {source_rate:.0f}, MIDI notes {notes[0]}..{notes[1]} around root 60") +
+                            f", {'4-tap Hermite' if args.hermite else 'linear'} interp, faithful mode, distinct {args.loop_seconds:g} s sources "
                             f"({arena / 1e6:.0f} MB), bus int peaks per block" + (", RCCL bus reduce to rank 0 per step" if distributed else ""),
                 "voices_per_gpu": V, "buses": B, "frames_per_block": N, "blocks_per_step": KB, "parallelism": f"voices sharded x{world}",
             },

@@ -44,7 +44,7 @@ struct zlhip_engine {
     ZlVoiceState *dVoices = nullptr;
     // K1 -> K2 records, double buffered so that planning window i+1 overlaps rendering window i
     struct PlanSet {
-        ZlVoiceConst *vconst = nullptr; ZlRunList *runs = nullptr;
+        ZlVoiceConst *vconst = nullptr; ZlRunList *runs = nullptr; ZlRun *xruns = nullptr;
         ZlPlanHdr *hdr = nullptr; ZlPlanSeg0 *seg0 = nullptr; ZlPlanSeg1 *seg1 = nullptr; ZlSegment *segs = nullptr;
         double *ctlP = nullptr; float *ctlEnv = nullptr; int32_t *expandList = nullptr; int32_t *expandCount = nullptr;
         float *partials = nullptr;
@@ -149,7 +149,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
                     e->dOpRanges, e->dStats, e->dTrace, e->dPass };
     for (void *p : dev) if (p) (void)hipFree(p);
     for (auto &q : e->ps) {
-        void *pd[] = { q.vconst, q.runs, q.hdr, q.seg0, q.seg1, q.segs, q.ctlP, q.ctlEnv, q.expandList, q.expandCount, q.partials };
+        void *pd[] = { q.vconst, q.runs, q.xruns, q.hdr, q.seg0, q.seg1, q.segs, q.ctlP, q.ctlEnv, q.expandList, q.expandCount, q.partials };
         for (void *p : pd) if (p) (void)hipFree(p);
         if (q.planned) (void)hipEventDestroy(q.planned);
         if (q.rendered) (void)hipEventDestroy(q.rendered);
@@ -219,6 +219,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             if (i >= nsets) continue;
             chk(dalloc(&q.vconst, V), "vconst");
             chk(dalloc(&q.runs, V), "run lists");
+            chk(dalloc(&q.xruns, V * (size_t)ZL_XRUNS), "overflow runs");
             chk(dalloc(&q.hdr, W * V), "plan headers");
             chk(dalloc(&q.seg0, W * V), "plan segment 0");
             chk(dalloc(&q.seg1, W * V), "plan segment 1");
@@ -508,7 +509,7 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         Aw.clocks = e->dClocks + Aw.k0;
         Aw.levels = e->dLevels + (size_t)Aw.k0 * A.B;
         Aw.pos_trace = traceBase ? traceBase + (size_t)Aw.k0 * e->V * nframes : nullptr;
-        Aw.vconst = q.vconst; Aw.runs = q.runs; Aw.plan_hdr = q.hdr; Aw.plan_seg0 = q.seg0; Aw.plan_seg1 = q.seg1; Aw.segs = q.segs;
+        Aw.vconst = q.vconst; Aw.runs = q.runs; Aw.xruns = q.xruns; Aw.plan_hdr = q.hdr; Aw.plan_seg0 = q.seg0; Aw.plan_seg1 = q.seg1; Aw.segs = q.segs;
         Aw.ctl_P = q.ctlP; Aw.ctl_env = q.ctlEnv; Aw.expand_list = q.expandList; Aw.expand_count = q.expandCount; Aw.partials = q.partials;
         if (w > 0) { Aw.n_op_ranges = 0; Aw.ops = nullptr; Aw.op_ranges = nullptr; }     // commands apply before the first block only
         // planning of window w may not overwrite the set while window w-2 is still being rendered from it
@@ -517,6 +518,7 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         ZL_KERNEL(e, zl_launch_apply_ops(Aw, ps));
         ZL_KERNEL(e, zl_launch_plan(Aw, e->forceSlow, ps));
         ZL_KERNEL(e, zl_launch_expand(Aw, ps));
+        ZL_KERNEL(e, zl_launch_expand_runs(Aw, ps));
         if (overlap) {
             ZL_HIP(e, hipEventRecord(q.planned, ps));
             ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));

@@ -2,6 +2,7 @@
 //
 //   K0 zl_k0_apply_ops   device half of SamplerChannel::handleCommand (SamplerSynth.cpp:187-230)
 //   K1 zl_k1_plan        per-voice control plan of SamplerSynthVoice::process (:174-270), zl_plan.h
+//   K1b/K1c              multi-segment blocks -> per-frame control; overflow runs -> per-block plans
 //   K2 zl_k2_render      gather + interpolate + gain/ADSR/pan + voice->bus sum (:198-221,
 //                        SamplerSynth.cpp:134-140); HBM-bound, no MFMA (about 22 flop per 8 bytes)
 //   K3 zl_k3_finalize    ordered sum of mix-group partials + AudioLevels block scan
@@ -86,6 +87,18 @@ __global__ void __launch_bounds__(256) zl_k1b_expand(const ZlBatch A)
         if (threadIdx.x == 0) A.plan_hdr[pidx].flags = pl.flags | ZL_PLAN_SLOW;
         __syncthreads();
     }
+}
+
+// K1c: overflow runs -> explicit per-block plans.  One lane per voice (coalesced 16-byte plan stores across the
+// wave), ZL_K1C_BLOCKS consecutive blocks per lane.
+#define ZL_K1C_BLOCKS 16
+__global__ void __launch_bounds__(64) zl_k1c_expand_runs(const ZlBatch A)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= A.V) return;
+    const int kbeg = blockIdx.y * ZL_K1C_BLOCKS;
+    const int kend = kbeg + ZL_K1C_BLOCKS < A.K ? kbeg + ZL_K1C_BLOCKS : A.K;
+    zl_expand_xruns(A, v, kbeg, kend);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,6 +554,14 @@ int zl_launch_plan(const ZlBatch &A, int force_slow, hipStream_t s)
 int zl_launch_expand(const ZlBatch &A, hipStream_t s)
 {
     hipLaunchKernelGGL(zl_k1b_expand, dim3(512), dim3(A.N < 256 ? A.N : 256), 0, s, A);
+    ZL_LAUNCH_CHECK();
+    return 0;
+}
+
+int zl_launch_expand_runs(const ZlBatch &A, hipStream_t s)
+{
+    if (!A.xruns) return 0;
+    hipLaunchKernelGGL(zl_k1c_expand_runs, dim3((A.V + 63) / 64, (A.K + ZL_K1C_BLOCKS - 1) / ZL_K1C_BLOCKS), dim3(64), 0, s, A);
     ZL_LAUNCH_CHECK();
     return 0;
 }

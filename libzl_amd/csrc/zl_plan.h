@@ -313,6 +313,13 @@ struct ZlPlanner {
     int  nruns;
     bool haveCur;
 
+    ZL_HD void flush_run(const ZlBatch &A)
+    {
+        if (nruns < ZL_MAXRUNS) A.runs[v].r[nruns] = cur;
+        else A.xruns[(size_t)v * ZL_XRUNS + (size_t)(nruns - ZL_MAXRUNS)] = cur;
+        ++nruns;
+    }
+
     ZL_HD void begin(const ZlBatch &A, int voice)
     {
         v = voice;
@@ -386,8 +393,8 @@ struct ZlPlanner {
         if (haveCur && cur.k1 == k && cur.step == s && fma((double)((k - cur.k0) * N), s, cur.P) == st.P) {
             cur.k1 = k + m;
             recorded = true;
-        } else if (nruns + (haveCur ? 1 : 0) < ZL_MAXRUNS) {
-            if (haveCur) A.runs[v].r[nruns++] = cur;
+        } else if (nruns + (haveCur ? 1 : 0) < ZL_MAXRUNS + (A.xruns ? ZL_XRUNS : 0)) {
+            if (haveCur) flush_run(A);
             cur.P = st.P; cur.step = s; cur.k0 = k; cur.k1 = k + m;
             haveCur = true;
             recorded = true;
@@ -547,7 +554,7 @@ struct ZlPlanner {
         }
         A.reports[v] = rep;
         A.voices[v] = st;
-        if (haveCur) A.runs[v].r[nruns++] = cur;
+        if (haveCur) flush_run(A);
         A.runs[v].n = nruns;
         A.runs[v].dead_from = valid ? blocks_done : 0;             // blocks >= dead_from are idle (voice ended or never played)
     }
@@ -577,6 +584,28 @@ ZL_HD inline ZlBlockPlan zl_plan_lookup(const ZlBatch &A, int k, int v, float ru
     return zl_plan_load(A, (size_t)k * A.V + v);
 }
 
+// K1c body for one voice: blocks [kbeg, kend) covered by an overflow run get their explicit plan record
+// (the inline runs stay implied).  Runs are sorted by block, so one binary search finds the first candidate.
+ZL_HD inline void zl_expand_xruns(const ZlBatch &A, int v, int kbeg, int kend)
+{
+    const int nx = A.runs[v].n - ZL_MAXRUNS;
+    if (nx <= 0 || !A.xruns) return;
+    const ZlRun *xr = A.xruns + (size_t)v * ZL_XRUNS;
+    int lo = 0, hi = nx;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (xr[mid].k1 <= kbeg) lo = mid + 1; else hi = mid; }
+    if (lo >= nx) return;
+    ZlRun r = xr[lo];
+    ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE; h.n_active = A.N; h.nseg = 1; h.env = A.vconst[v].env;
+    for (int k = kbeg; k < kend; ++k) {
+        while (k >= r.k1) { if (++lo >= nx) return; r = xr[lo]; }
+        if (k < r.k0) continue;                                   // an explicitly planned block between two runs
+        const size_t pidx = (size_t)k * A.V + v;
+        ZlPlanSeg0 s0; s0.P0 = fma((double)((k - r.k0) * A.N), r.step, r.P); s0.step = r.step;   // exact: inside the linear run
+        A.plan_hdr[pidx] = h;
+        A.plan_seg0[pidx] = s0;
+    }
+}
+
 // K1b body for one frame of one queued block: the position of frame f from the block's segments.
 ZL_HD inline double zl_expand_position(const ZlBlockPlan &pl, const ZlSegment *extra, int f)
 {
@@ -601,6 +630,7 @@ ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanS
     }
     pl.end(A);
     stats = pl.stats;
+    zl_expand_xruns(A, v, 0, A.K);
 }
 
 // ---- voice operations (device half of SamplerChannel::handleCommand, SamplerSynth.cpp:187-230) --

@@ -93,10 +93,15 @@ enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2 };
 // one linear position run, so their plan is implied: P0(k) = P + (k - k0) * N * step (exact).  K1 records
 // a handful of these per voice instead of K per-block plans; only the blocks around loop restarts,
 // binade crossings and envelope transients get explicit plan records.
+// The first ZL_MAXRUNS runs of a voice are kept inline (K2 resolves them without touching the plan arrays: the
+// steady state of unpitched playback); further runs of the window go to the overflow table ZlBatch::xruns and are
+// turned into explicit per-block plans by K1c, lane-parallel (pitched voices open ~10 runs per loop pass, one per
+// binade).
 #define ZL_MAXRUNS 6
+#define ZL_XRUNS   250
 struct ZlRun { double P, step; int32_t k0, k1; };
 struct ZlRunList {
-    int32_t n;                    // runs used
+    int32_t n;                    // runs used: the first ZL_MAXRUNS inline, the rest in ZlBatch::xruns
     int32_t dead_from;            // first block in which the voice no longer plays (K if it plays to the end; 0 = idle)
     ZlRun   r[ZL_MAXRUNS];
 };
@@ -171,6 +176,7 @@ struct ZlBatch {
     const ZlOpRange    *op_ranges;
     ZlVoiceConst       *vconst;   // [V]
     ZlRunList          *runs;     // [V]
+    ZlRun              *xruns;    // [V][ZL_XRUNS] overflow runs (null: none, K1 falls back to per-block plans)
     ZlPlanHdr          *plan_hdr; // [K][V] explicit plans (blocks not covered by a run)
     ZlPlanSeg0         *plan_seg0;// [K][V]
     ZlPlanSeg1         *plan_seg1;// [K][V] valid where nseg >= 2

@@ -22,7 +22,7 @@ struct ZlSim {
     std::vector<ZlSound> sounds;
     std::vector<ZlClip> clips;
     std::vector<ZlVoiceState> voices;
-    std::vector<ZlVoiceConst> vconst; std::vector<ZlRunList> runs;
+    std::vector<ZlVoiceConst> vconst; std::vector<ZlRunList> runs; std::vector<ZlRun> xruns;
     std::vector<ZlPlanHdr> planHdr; std::vector<ZlPlanSeg0> planSeg0; std::vector<ZlPlanSeg1> planSeg1;
     std::vector<ZlSegment> segs;
     std::vector<double> ctlP; std::vector<float> ctlEnv;
@@ -99,7 +99,7 @@ ZlSim *zlsim_create(int B, int VPB, int max_sounds, double fs, uint32_t mode, in
     S->sounds.assign((size_t)max_sounds, ZlSound{0, 0, 0, 0.0});
     S->clips.assign((size_t)max_sounds, ZlClip{});
     S->voices.assign((size_t)S->V, ZlVoiceState{});
-    S->vconst.assign((size_t)S->V, ZlVoiceConst{}); S->runs.assign((size_t)S->V, ZlRunList{});
+    S->vconst.assign((size_t)S->V, ZlVoiceConst{}); S->runs.assign((size_t)S->V, ZlRunList{}); S->xruns.assign((size_t)S->V * ZL_XRUNS, ZlRun{});
     S->reports.assign((size_t)S->V, ZlReport{});
     return S;
 }
@@ -163,7 +163,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     ZlBatch A; std::memset(&A, 0, sizeof A);
     A.V = S->V; A.B = S->B; A.VPB = S->VPB; A.K = K; A.N = N; A.k0 = 0; A.Ktot = K; A.G = S->G; A.groups = (S->VPB + S->G - 1) / S->G; A.mode = S->mode;
     A.clocks = ck.data(); A.sounds = S->sounds.data(); A.clips = S->clips.data(); A.arena = S->arena.data();
-    A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data(); A.segs = S->segs.data();
+    A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.xruns = S->xruns.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data(); A.segs = S->segs.data();
     A.ctl_P = S->ctlP.data(); A.ctl_env = S->ctlEnv.data(); A.reports = S->reports.data();
 
     for (const ZlOpRange &rg : ranges) {                          // K0

@@ -102,6 +102,19 @@ def test_plan_windows_overlap_planning_and_rendering(Engine, window):
     syn2.close()
 
 
+@pytest.mark.parametrize("window", [0, 512])
+def test_run_table_overflow(Engine, window):
+    """Short pitched loops over a long batch: inline runs, the overflow table expanded by K1c and, when that is
+    full too, per-block plans (one window of 1500 blocks; three windows of 256/512/512...)."""
+    sc = random_scene(510, nclips=8, min_len=700, max_len=1500, nblocks=1500, nframes=64, events=False)
+    for ev in sc.events[0]:
+        ev[1]["looping"] = 1
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=1500, plan_window_blocks=window)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    syn.close()
+
+
 def test_realtime_process_equals_batch(Engine):
     """zlhip_render (one JACK cycle, host buffers) gives the same bits as the batched path."""
     from libzl_amd.engine import synthetic_clocks

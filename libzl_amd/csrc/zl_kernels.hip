@@ -32,7 +32,7 @@ __global__ void zl_k0_apply_ops(const ZlBatch A)
 
 // ------------------------------------------------------------------------------------------------
 // K1: one lane per voice; the block clocks are staged in LDS so the per-block step of the planner
-// makes no dependent global load.  Steady-state cost is O(1) per block (zl_plan.h).
+// makes no dependent global load.  Cost is O(linear runs + events) per voice, not O(blocks) (zl_plan.h).
 #define ZL_K1_CLOCKS 256
 __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow)
 {
@@ -50,13 +50,10 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
             for (int i = threadIdx.x; i < nk * (int)(sizeof(ZlClock) / 16); i += blockDim.x) sh[i] = g[i];
         }
         __syncthreads();
-        if (mine && pl.valid && pl.st.playing) {               // idle voices need no per-block work (ZlRunList::dead_from)
-            for (int k = 0; k < nk;) {
-                const int m = pl.fast_forward(A, kb + k, kb + nk, s_clk + k, force_slow);
-                if (m) { k += m; continue; }
-                pl.plan_block(A, kb + k, s_clk[k], force_slow);
-                ++k;
-            }
+        if (mine) {
+            // idle voices leave at once (ZlRunList::dead_from); the others run the planner's state machine, whose
+            // iterations are the same straight-line code for every lane (zl_plan.h)
+            while (pl.k < kb + nk) pl.iterate(A, kb + nk, s_clk, kb, force_slow);
         }
     }
     if (mine) {
@@ -147,13 +144,48 @@ struct ZlK2Tap { ZlTaps t; float alpha; int flags; };   // flags: 1 act, 2 inb, 
 // block expanded by K1b); regular voices of such a chunk read a dummy control word.
 // SIMPLE chunks (the steady state): every voice of the chunk plays the whole block from one position segment, in
 // sustain, from a stereo source.  No per-voice predicates are needed, which halves the VALU work.
+// Packed (l, r) arithmetic of zl_mix_frame for the simple chunks: both channels go through the same expression, so
+// the two lanes of a float2 are the reference's l and r sequences, evaluated by v_pk_mul_f32 / v_pk_add_f32 (the
+// kernel's VALU budget is ~49 lane-operations per voice-sample at the HBM roofline; un-fused, -ffp-contract=off).
+typedef float zl_f2 __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ zl_f2 zl_hermite4_pk(zl_f2 y0, zl_f2 y1, zl_f2 y2, zl_f2 y3, float a)
+{
+    const zl_f2 c1 = 0.5f * (y2 - y0);
+    const zl_f2 c2 = (y0 + 2.0f * y2) - (0.5f * y3 + 2.5f * y1);
+    const zl_f2 c3 = (0.5f * y3 + 1.5f * y1) - (0.5f * y0 + 1.5f * y2);
+    return y1 + a * (c1 + a * (c2 + a * c3));
+}
+
+template <uint32_t MODE>
+static __device__ __forceinline__ zl_f2 zl_mix_frame_pk(zl_f2 xm, zl_f2 x0, zl_f2 x1, zl_f2 x2, float alpha, bool inb, bool wide,
+                                                         zl_f2 gain, float env, float vol, zl_f2 pan)
+{
+    const float invAlpha = 1.0f - alpha;                         // :200
+    zl_f2 lr;
+    if (MODE & ZL_MODE_HERMITE) {
+        const zl_f2 h = zl_hermite4_pk(xm, x0, x1, x2, alpha);
+        const zl_f2 lin = x0 * invAlpha + x1 * alpha;
+        lr = (wide ? h : lin) * gain * env * vol;
+    } else if (MODE & ZL_MODE_FIX_GAIN) {
+        lr = (x0 * invAlpha + x1 * alpha) * gain * env * vol;
+    } else {
+        lr = x0 * invAlpha + x1 * alpha * gain * env * vol;      // :204-205, quirk Q1
+    }
+    if (!inb) lr = (zl_f2){0.0f, 0.0f};                          // stereo source: r = l = 0 out of range
+    const float mSignal = 0.5f * (lr.x + lr.y);                  // :208
+    const float sSignal = lr.x - lr.y;                           // :209
+    return pan * mSignal + (zl_f2){sSignal, -sSignal};           // :210-211
+}
+
 template <uint32_t MODE, bool SEG2, int U>
 static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
-                                                           int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
+                                                           int c0, int vfirst, int f, double fd, bool wantPeak, zl_f2 &acc)
 {
-    zl_f4a4 d[U];
+    constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
+    zl_f4a4 d[U], e[HERM ? U : 1];
     float alpha[U];
-    int   inbm = 0;
+    int   inbm = 0, widem = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
@@ -166,26 +198,44 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
         }
         int pos;
         zl_split_position(P, pos, alpha[u]);                      // :198-199
-        const bool inb = s_vc[i].sample_duration > pos;           // :204 guard (Q5); P >= 0 so pos >= 0
-        const int p = inb ? pos : 0;
+        const int dur = s_vc[i].sample_duration;
+        const bool inb = dur > pos;                               // :204 guard (Q5); P >= 0 so pos >= 0
+        int p = inb ? pos : 0;
         const uint64_t so = s_vc[i].src_offset;
         const float *src = A.arena + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(so >> 32)) << 32)
                                       | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)so));
-        d[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p);
+        if (HERM) {
+            // taps pos-1 .. pos+2 as two 16-byte loads; at the source edges (not wide) the pair pos, pos+1 comes first
+            const bool wide = inb && pos >= 1 && pos + 2 <= dur;
+            p -= wide ? 1 : 0;
+            d[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p);
+            e[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p + 4);      // inside the arena padding at the end
+            widem |= wide ? (1 << u) : 0;
+        } else {
+            d[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p);
+        }
         inbm |= inb ? (1 << u) : 0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
-        ZlTaps t;
-        t.x0l = d[u].x; t.x0r = d[u].y; t.x1l = d[u].z; t.x1r = d[u].w;
-        t.xml = t.xmr = t.x2l = t.x2r = 0.0f;
-        float l, r;
-        zl_mix_frame<MODE>(t, alpha[u], (inbm >> u) & 1, false, true, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env,
-                           s_vc[i].clip_volume, s_vc[i].lpan, s_vc[i].rpan, l, r);
-        accL += l; accR += r;                                     // :218-221 (index shift applied at the store)
+        zl_f2 xm, x0, x1, x2;
+        const bool wide = (widem >> u) & 1;
+        if (HERM) {
+            xm = (zl_f2){d[u].x, d[u].y};
+            x0 = wide ? (zl_f2){d[u].z, d[u].w} : (zl_f2){d[u].x, d[u].y};
+            x1 = wide ? (zl_f2){e[u].x, e[u].y} : (zl_f2){d[u].z, d[u].w};
+            x2 = (zl_f2){e[u].z, e[u].w};
+        } else {
+            x0 = (zl_f2){d[u].x, d[u].y}; x1 = (zl_f2){d[u].z, d[u].w};
+            xm = x0; x2 = x1;
+        }
+        const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, alpha[u], (inbm >> u) & 1, wide,
+                                              (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
+                                              (zl_f2){s_vc[i].lpan, s_vc[i].rpan});
+        acc += o;                                                 // :218-221 (index shift applied at the store)
         if (wantPeak) {                                           // :213-216, signed peak from 0 (Q6)
-            const float ng = l + r;
+            const float ng = o.x + o.y;
             float pk = ng > 0.0f ? ng : 0.0f;
             pk = zl_wave_max(pk);
             if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[vfirst + i].peak_bits, __float_as_uint(pk));
@@ -316,7 +366,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
             s_plan[i] = pl;                       // idle slots: a harmless record with no active frame
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
             // 4 = "simple": whole block, sustain, stereo (and no debug trace); 8 = it has a second position segment
-            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && s_vc[i].channels == 2 && !(MODE & ZL_MODE_HERMITE) && !A.trace)
+            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && s_vc[i].channels == 2 && !A.trace)
                 cls |= 4 | (pl.nseg == 2 ? 8 : 0);
             s_cls[i] = cls;
         }
@@ -343,9 +393,12 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
 #ifdef ZL_STAMPS
             zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
 #endif
-            if ((cc & 12) == 4)  zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else if (cc & 4) zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else {
+            if (cc & 4) {
+                zl_f2 acc = {accL, accR};
+                if ((cc & 12) == 4) zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, acc);
+                else                zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, acc);
+                accL = acc.x; accR = acc.y;
+            } else {
                 // general chunks (events, second segments, mono sources, per-frame control) are rare: run them as
                 // two half-chunks so their extra per-voice registers do not set the kernel's register budget
                 constexpr int H = U / 2;

@@ -295,8 +295,13 @@ ZL_HD inline ZlBlockPlan zl_plan_load(const ZlBatch &A, size_t pidx)
     return pl;
 }
 
-// Plans the blocks of a batch for one voice, one block per call (so the caller can feed the clocks
-// from LDS), and leaves the voice state as the reference would after rendering them.
+// Plans the blocks of a batch for one voice and leaves the voice state as the reference would after rendering
+// them.  The planner is a flat state machine: one iterate() call = at most one new linear run (zl_linear_run +
+// the search for the loop / stop event inside it) and everything that run implies -- the rest of the open block,
+// the whole blocks after it (recorded as ONE ZlRun, not per block) and the head of the block in which it ends.
+// All lanes of a wavefront therefore execute the same straight-line code per iteration whatever their block
+// positions are (one lane per voice: a nested per-block / per-segment loop would serialise the lanes' loop
+// restarts, each of which crosses ~log2(N) binades).
 struct ZlPlanner {
     ZlVoiceState st;
     ZlVoiceBatchConst c;
@@ -312,6 +317,11 @@ struct ZlPlanner {
     ZlRun cur;
     int  nruns;
     bool haveCur;
+    // the block being planned: k, frames planned so far (n), its record under construction
+    int k, n, nseg;
+    bool needSeg, slowNext;
+    ZlBlockPlan pl;
+    uint64_t tick0, usecs0;      // loop clock at the start of the open block (restored when the block turns slow)
 
     ZL_HD void flush_run(const ZlBatch &A)
     {
@@ -328,6 +338,8 @@ struct ZlPlanner {
         blocks_done = 0;
         nruns = 0; haveCur = false; cur.P = 0.0; cur.step = 0.0; cur.k0 = 0; cur.k1 = 0;
         s = 0.0; L = 0; ie = ZL_INF_STEPS; haveRun = false;
+        k = 0; n = 0; nseg = 0; needSeg = false; slowNext = false; tick0 = 0; usecs0 = 0;
+        zl_plan_clear(pl);
         valid = st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0;
         posMode = false; clockMode = false; X = INFINITY; blockBytes = 0; inv_r = 0.0;
         if (!valid) return;
@@ -365,14 +377,12 @@ struct ZlPlanner {
         posMode = posLoop || oneShot;
     }
 
-    // Steady-state shortcut: while the current linear run covers whole blocks and no loop / stop event
-    // falls in them, consecutive blocks differ only in P0 and are recorded as ONE run (ZlRunList) instead
-    // of per-block plans.  clk points at the clock of block k (beat-locked loops test every block's clock,
-    // SamplerSynthVoice.cpp:232).  Covers blocks k .. k+m-1 (m <= kmax - k) and returns m; 0 = use plan_block.
-    ZL_HD int fast_forward(const ZlBatch &A, int k, int kmax, const ZlClock *clk, int force_slow)
+    // Steady state: while the current linear run covers whole blocks and no loop / stop event falls in them,
+    // consecutive blocks differ only in P0 and are recorded as ONE run (ZlRunList) instead of per-block plans.
+    // clk points at the clock of block k (beat-locked loops test every block's clock, SamplerSynthVoice.cpp:232).
+    // Covers blocks k .. k+m-1 (m <= kmax - k) and returns m.
+    ZL_HD int whole_blocks(const ZlBatch &A, int kmax, const ZlClock *clk)
     {
-        if (!(valid && st.playing) || force_slow || !haveRun || st.adsr_state != ZL_ADSR_SUSTAIN || st.next_loop_usecs == 0)
-            return 0;
         const int N = A.N;
         int m = L / N;
         if (ie != ZL_INF_STEPS) { const int me = (ie - 1) / N; m = me < m ? me : m; }
@@ -381,9 +391,9 @@ struct ZlPlanner {
         if (clockMode) {
             int j = 0;
             for (; j < m; ++j) {
-                const ZlClock &c = clk[j];
-                if (c.usecs_per_frame >= (1ull << 21)) break;
-                if (!(c.current_usecs + (uint64_t)(N - 1) * c.usecs_per_frame < st.next_loop_usecs)) break;   // restart inside block
+                const ZlClock &cj = clk[j];
+                if (cj.usecs_per_frame >= (1ull << 21)) break;
+                if (!(cj.current_usecs + (uint64_t)(N - 1) * cj.usecs_per_frame < st.next_loop_usecs)) break;   // restart inside block
             }
             m = j;
             if (m <= 0) return 0;
@@ -414,133 +424,150 @@ struct ZlPlanner {
         L -= steps;
         if (ie != ZL_INF_STEPS) ie -= steps;
         st.env = st.sustain;
-        blocks_done = k + m;
         stats.source_bytes += blockBytes * (unsigned long long)m;
         stats.active_frames += (unsigned long long)steps;
         return m;
     }
 
-    // Plans block k (clock ck).  Must be called for k = 0, 1, ... in order.
-    ZL_HD void plan_block(const ZlBatch &A, int k, const ZlClock &ck, int force_slow)
+    // One iteration (see the struct comment).  clk0 is the clock of block kb; blocks below kend may be planned.
+    // Call while k < kend.
+    ZL_HD void iterate(const ZlBatch &A, int kend, const ZlClock *clk0, int kb, int force_slow)
     {
         const int N = A.N;
-        const size_t pidx = (size_t)k * A.V + v;
-        ZlBlockPlan pl;
-        zl_plan_clear(pl);
-        if (!(valid && st.playing)) return;                        // idle blocks are implied by ZlRunList::dead_from
-        blocks_done = k + 1;
-        pl.flags = ZL_PLAN_ACTIVE; pl.n_active = N; pl.env = st.sustain; pl.P0 = st.P;
-
-        if (st.next_loop_usecs == 0)                              // :179-182
-            st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
-
-        bool slow = force_slow || st.adsr_state != ZL_ADSR_SUSTAIN || (clockMode && ck.usecs_per_frame >= (1ull << 21));
-        // steady state: the current linear run covers the whole block and no loop / stop event falls in it
-        if (!slow && haveRun && L >= N && ie > N
-            && (!clockMode || ck.current_usecs + (uint64_t)(N - 1) * ck.usecs_per_frame < st.next_loop_usecs)) {
-            pl.nseg = 1; pl.step = s;
-            st.P = fma((double)N, s, st.P);
-            L -= N;
-            if (ie != ZL_INF_STEPS) ie -= N;
-            st.env = st.sustain;
-            zl_plan_store(A, pidx, pl);
-            stats.source_bytes += blockBytes;
-            stats.active_frames += (unsigned long long)N;
-            return;
-        }
-        if (!slow) {
-            // ---- fast block: linear segments ----
-            const ZlVoiceState st0 = st;
-            const double s0 = s; const int L0 = L, ie0 = ie; const bool haveRun0 = haveRun;
-            ZlSegment *segs = A.segs + pidx * (ZL_MAXSEG - 2);
-            int n = 0, nseg = 0;
-            bool needSeg = true;                                   // frame n is not covered by an emitted segment yet
-            while (n < N) {
-                if (!haveRun) {
-                    zl_linear_run(st.P, st.pitch_ratio, inv_r, s, L);
-                    haveRun = true;
-                    needSeg = true;
-                    ie = posMode ? zl_steps_to_reach(st.P, s, inv_r, L, X) : ZL_INF_STEPS;
-                }
-                if (needSeg) {
-                    if (nseg >= ZL_MAXSEG) { slow = true; break; }
-                    if (nseg == 0) { pl.P0 = st.P; pl.step = s; }
-                    else if (nseg == 1) { pl.n1 = n; pl.P1 = st.P; pl.step1 = s; }
-                    else { ZlSegment sg; sg.P0 = st.P; sg.step = s; sg.n0 = n; sg.pad = 0; segs[nseg - 2] = sg; }
-                    ++nseg;
-                    needSeg = false;
-                }
-                bool realStep = (L == 0);
-                if (!realStep) {
-                    const int room = N - n;
-                    const int m = L < room ? L : room;
-                    int iclk = ZL_INF_STEPS;
-                    if (clockMode) {
-                        const int fa = zl_clock_event_frame(ck, st.next_loop_usecs, n, N);
-                        if (fa < N) iclk = fa - n + 1;
-                    }
-                    const int iev = ie < iclk ? ie : iclk;
-                    if (iev > m) {
-                        st.P = fma((double)m, s, st.P);
-                        n += m; L -= m;
-                        if (ie != ZL_INF_STEPS) ie -= m;
-                        if (L != 0 || n >= N) { if (L == 0) haveRun = false; continue; }
-                        // run exhausted inside the block: frame n is still covered by the current segment (P0 + L*s);
-                        // leave the binade with one real addition, without opening a one-frame segment
-                        realStep = true;
-                    } else {
-                        n += iev;
-                        haveRun = false;
-                    }
-                }
-                if (realStep) {
-                    const double Pn = st.P + st.pitch_ratio;       // one real fp64 addition from frame n
-                    const bool ev = posMode ? (Pn >= X)
-                                            : (clockMode ? (zl_clock_event_frame(ck, st.next_loop_usecs, n, N) == n) : false);
-                    n += 1;
+        if (n == 0) {
+            // ---- start of block k ----
+            if (!(valid && st.playing)) { k = kend; return; }       // idle blocks are implied by ZlRunList::dead_from
+            {
+                const ZlClock &ck = clk0[k - kb];
+                if (st.next_loop_usecs == 0)                        // :179-182
+                    st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
+                const bool slow = force_slow || slowNext || st.adsr_state != ZL_ADSR_SUSTAIN
+                                  || (clockMode && ck.usecs_per_frame >= (1ull << 21));
+                if (slow) {
+                    // envelope transient, release tail (Q7), or a block whose segments did not fit: per-frame simulation
+                    const size_t pidx = (size_t)k * A.V + v;
+                    slowNext = false;
+                    zl_plan_clear(pl);
+                    pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW; pl.env = st.sustain; pl.P0 = st.P;
+                    pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
                     haveRun = false;
-                    if (!ev) { st.P = Pn; continue; }
+                    zl_plan_store(A, pidx, pl);
+                    stats.slow_blocks += 1;
+                    stats.source_bytes += blockBytes;
+                    stats.active_frames += (unsigned long long)pl.n_active;
+                    ++k; blocks_done = k;
+                    return;
                 }
+            }
+            if (haveRun) {
+                const int m = whole_blocks(A, kend, clk0 + (k - kb));
+                if (m > 0) {
+                    k += m; blocks_done = k;
+                    if (k >= kend) return;
+                    if (clockMode && clk0[k - kb].usecs_per_frame >= (1ull << 21)) return;   // next iteration simulates it
+                }
+            }
+            zl_plan_clear(pl);
+            pl.flags = ZL_PLAN_ACTIVE; pl.n_active = N; pl.env = st.sustain; pl.P0 = st.P;
+            nseg = 0; needSeg = true;                               // frame 0 is not covered by an emitted segment yet
+            tick0 = st.next_loop_tick; usecs0 = st.next_loop_usecs;
+        }
+        const ZlClock &ck = clk0[k - kb];
+        const size_t pidx = (size_t)k * A.V + v;
+
+        // ---- a new linear run when the previous one is used up ----
+        if (!haveRun) {
+            zl_linear_run(st.P, st.pitch_ratio, inv_r, s, L);
+            haveRun = true;
+            needSeg = true;
+            ie = posMode ? zl_steps_to_reach(st.P, s, inv_r, L, X) : ZL_INF_STEPS;
+        }
+        bool slow = false, ended = false;
+        if (needSeg) {
+            if (nseg >= ZL_MAXSEG) slow = true;
+            else {
+                if (nseg == 0) { pl.P0 = st.P; pl.step = s; }
+                else if (nseg == 1) { pl.n1 = n; pl.P1 = st.P; pl.step1 = s; }
+                else { ZlSegment sg; sg.P0 = st.P; sg.step = s; sg.n0 = n; sg.pad = 0; A.segs[pidx * (ZL_MAXSEG - 2) + (size_t)(nseg - 2)] = sg; }
+                ++nseg;
+                needSeg = false;
+            }
+        }
+        // ---- consume the run inside block k ----
+        if (!slow) {
+            bool event = false;
+            bool realStep = (L == 0);
+            if (!realStep) {
+                const int room = N - n;
+                const int m = L < room ? L : room;
+                int iclk = ZL_INF_STEPS;
+                if (clockMode) {
+                    const int fa = zl_clock_event_frame(ck, st.next_loop_usecs, n, N);
+                    if (fa < N) iclk = fa - n + 1;
+                }
+                const int iev = ie < iclk ? ie : iclk;
+                if (iev > m) {
+                    st.P = fma((double)m, s, st.P);
+                    n += m; L -= m;
+                    if (ie != ZL_INF_STEPS) ie -= m;
+                    if (L == 0) {
+                        // run exhausted: at the block end the next block starts a new run; inside the block frame n is
+                        // still covered by the current segment (P0 + L*s) and the binade is left with one real addition,
+                        // without opening a one-frame segment
+                        if (n < N) realStep = true; else haveRun = false;
+                    }
+                } else {
+                    n += iev;
+                    haveRun = false;
+                    event = true;
+                }
+            }
+            if (realStep) {
+                const double Pn = st.P + st.pitch_ratio;           // one real fp64 addition from frame n
+                const bool ev = posMode ? (Pn >= X)
+                                        : (clockMode ? (zl_clock_event_frame(ck, st.next_loop_usecs, n, N) == n) : false);
+                n += 1;
+                haveRun = false;
+                if (!ev) st.P = Pn; else event = true;
+            }
+            if (event) {
                 // ---- event after rendering frame n-1 ----
                 if (st.looping) {
                     zl_loop_restart(st, c, ck, clockMode);
                 } else if (st.release > 0.0f) {
                     slow = true;                                   // release tail starts inside this block (Q7)
-                    break;
                 } else {
                     pl.n_active = n;                               // :249-252, voice ends after frame n-1
                     zl_voice_hard_stop(st);
-                    break;
-                }
-            }
-            if (slow) {
-                st = st0; s = s0; L = L0; ie = ie0; haveRun = haveRun0;
-                pl.n1 = INT_MAX;
-            } else {
-                pl.nseg = nseg;
-                if (st.playing) st.env = st.sustain;               // the sustain branch assigns envelopeVal every frame
-                if (nseg > 2 && A.expand_list) {
-                    // K2 evaluates at most two segments per block: queue this one for K1b, which turns its
-                    // segments into per-frame control (lane-parallel) and marks the block ZL_PLAN_SLOW
-#if defined(__HIP_DEVICE_COMPILE__)
-                    const int slot = atomicAdd(A.expand_count, 1);
-#else
-                    const int slot = (*A.expand_count)++;
-#endif
-                    A.expand_list[slot] = (int32_t)pidx;
+                    ended = true;
                 }
             }
         }
         if (slow) {
-            pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW;
-            pl.nseg = 0;
-            pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
-            haveRun = false;
-            stats.slow_blocks += 1;
+            // back to the start of block k; the next iteration simulates it per frame
+            st.P = pl.P0; st.next_loop_tick = tick0; st.next_loop_usecs = usecs0;
+            haveRun = false; n = 0; slowNext = true;
+            return;
         }
-        zl_plan_store(A, pidx, pl);
-        stats.source_bytes += blockBytes;
-        stats.active_frames += (unsigned long long)pl.n_active;
+        if (n >= N || ended) {
+            // ---- block k is complete ----
+            pl.nseg = nseg;
+            if (st.playing) st.env = st.sustain;                   // the sustain branch assigns envelopeVal every frame
+            if (nseg > 2 && A.expand_list) {
+                // K2 evaluates at most two segments per block: queue this one for K1b, which turns its
+                // segments into per-frame control (lane-parallel) and marks the block ZL_PLAN_SLOW
+#if defined(__HIP_DEVICE_COMPILE__)
+                const int slot = atomicAdd(A.expand_count, 1);
+#else
+                const int slot = (*A.expand_count)++;
+#endif
+                A.expand_list[slot] = (int32_t)pidx;
+            }
+            zl_plan_store(A, pidx, pl);
+            stats.source_bytes += blockBytes;
+            stats.active_frames += (unsigned long long)pl.n_active;
+            ++k; n = 0; blocks_done = k;
+        }
     }
 
     ZL_HD void end(const ZlBatch &A)
@@ -622,12 +649,7 @@ ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanS
 {
     ZlPlanner pl;
     pl.begin(A, v);
-    for (int k = 0; k < A.K && pl.valid && pl.st.playing;) {
-        const int m = pl.fast_forward(A, k, A.K, A.clocks + k, force_slow);
-        if (m) { k += m; continue; }
-        pl.plan_block(A, k, A.clocks[k], force_slow);
-        ++k;
-    }
+    while (pl.k < A.K) pl.iterate(A, A.K, A.clocks, 0, force_slow);
     pl.end(A);
     stats = pl.stats;
     zl_expand_xruns(A, v, 0, A.K);

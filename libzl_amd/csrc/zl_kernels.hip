@@ -2,7 +2,8 @@
 //
 //   K0 zl_k0_apply_ops   device half of SamplerChannel::handleCommand (SamplerSynth.cpp:187-230)
 //   K1 zl_k1_plan        per-voice control plan of SamplerSynthVoice::process (:174-270), zl_plan.h
-//   K1b/K1c              multi-segment blocks -> per-frame control; overflow runs -> per-block plans
+//   K1c zl_k1c_assemble  segment streams -> per-block plan records (lane-parallel)
+//   K1b zl_k1b_expand    blocks with more than two segments -> per-frame control (lane-parallel)
 //   K2 zl_k2_render      gather + interpolate + gain/ADSR/pan + voice->bus sum (:198-221,
 //                        SamplerSynth.cpp:134-140); HBM-bound, no MFMA (about 22 flop per 8 bytes)
 //   K3 zl_k3_finalize    ordered sum of mix-group partials + AudioLevels block scan
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
         if (mine) {
             // idle voices leave at once (ZlRunList::dead_from); the others run the planner's state machine, whose
             // iterations are the same straight-line code for every lane (zl_plan.h)
-            while (pl.k < kb + nk) pl.iterate(A, kb + nk, s_clk, kb, force_slow);
+            while (pl.t < (kb + nk) * A.N) pl.iterate(A, kb + nk, s_clk, kb, force_slow);
         }
     }
     if (mine) {
@@ -66,36 +67,37 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
     }
 }
 
-// K1b: blocks with more than two position segments (the block after a loop restart at a small
-// position crosses ~log2(N) binades) are expanded, lane-parallel, into per-frame control so that K2
-// keeps a single pipelined code path.  One workgroup per queued block, grid-stride over the queue.
-__global__ void __launch_bounds__(256) zl_k1b_expand(const ZlBatch A)
-{
-    const int n = *A.expand_count;
-    for (int e = blockIdx.x; e < n; e += gridDim.x) {
-        const size_t pidx = (size_t)A.expand_list[e];
-        const ZlBlockPlan pl = zl_plan_load(A, pidx);
-        const ZlSegment *extra = A.segs + pidx * (ZL_MAXSEG - 2);
-        for (int f = threadIdx.x; f < A.N; f += blockDim.x) {
-            A.ctl_P[pidx * (size_t)A.N + f] = zl_expand_position(pl, extra, f < pl.n_active ? f : 0);
-            A.ctl_env[pidx * (size_t)A.N + f] = pl.env;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) A.plan_hdr[pidx].flags = pl.flags | ZL_PLAN_SLOW;
-        __syncthreads();
-    }
-}
-
-// K1c: overflow runs -> explicit per-block plans.  One lane per voice (coalesced 16-byte plan stores across the
-// wave), ZL_K1C_BLOCKS consecutive blocks per lane.
+// K1c: segment streams -> per-block plan records.  One lane per voice (coalesced 16-byte plan stores across the
+// wave), ZL_K1C_BLOCKS consecutive blocks per lane (one binary search, then a forward walk).
 #define ZL_K1C_BLOCKS 16
-__global__ void __launch_bounds__(64) zl_k1c_expand_runs(const ZlBatch A)
+__global__ void __launch_bounds__(64) zl_k1c_assemble(const ZlBatch A)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= A.V) return;
     const int kbeg = blockIdx.y * ZL_K1C_BLOCKS;
     const int kend = kbeg + ZL_K1C_BLOCKS < A.K ? kbeg + ZL_K1C_BLOCKS : A.K;
-    zl_expand_xruns(A, v, kbeg, kend);
+    zl_assemble_blocks(A, v, kbeg, kend);
+}
+
+// K1b: blocks with more than two position segments (the block after a loop restart at a small position crosses
+// ~log2(N) binades) are expanded, lane-parallel, into per-frame control so that K2 keeps a single pipelined code
+// path.  One workgroup per queued block, grid-stride over the queue.
+__global__ void __launch_bounds__(256) zl_k1b_expand(const ZlBatch A)
+{
+    const int n = *A.expand_count;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const ZlExpand e = A.expand_list[i];
+        const size_t pidx = (size_t)e.k * A.V + e.v;
+        const ZlPlanHdr h = A.plan_hdr[pidx];
+        const int nts = A.runs[e.v].nts;
+        for (int f = threadIdx.x; f < A.N; f += blockDim.x) {
+            A.ctl_P[pidx * (size_t)A.N + f] = zl_expand_frame(A, e, nts, f < h.n_active ? f : 0);
+            A.ctl_env[pidx * (size_t)A.N + f] = h.env;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) A.plan_hdr[pidx].flags = h.flags | ZL_PLAN_SLOW;
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -611,10 +613,9 @@ int zl_launch_expand(const ZlBatch &A, hipStream_t s)
     return 0;
 }
 
-int zl_launch_expand_runs(const ZlBatch &A, hipStream_t s)
+int zl_launch_assemble(const ZlBatch &A, hipStream_t s)
 {
-    if (!A.xruns) return 0;
-    hipLaunchKernelGGL(zl_k1c_expand_runs, dim3((A.V + 63) / 64, (A.K + ZL_K1C_BLOCKS - 1) / ZL_K1C_BLOCKS), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(zl_k1c_assemble, dim3((A.V + 63) / 64, (A.K + ZL_K1C_BLOCKS - 1) / ZL_K1C_BLOCKS), dim3(64), 0, s, A);
     ZL_LAUNCH_CHECK();
     return 0;
 }

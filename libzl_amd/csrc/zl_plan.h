@@ -1,16 +1,20 @@
-// zl_plan.h -- K1 "control plan": the per-voice, per-block control state of
-// SamplerSynthVoice::process (reference lib/SamplerSynthVoice.cpp:174-270) advanced WITHOUT walking
-// every frame, bit-exactly.
+// zl_plan.h -- K1 "control plan": the per-voice control state of SamplerSynthVoice::process (reference
+// lib/SamplerSynthVoice.cpp:174-270) advanced WITHOUT walking every frame, bit-exactly.
 //
 // The reference advances `sourceSamplePosition += pitchRatio` (fp64) once per frame (:223).  While
 // P stays inside one binade and the exact sum P + r does not leave it, every such addition rounds
 // to the same multiple of ulp(P), so the recurrence is an exact arithmetic progression
-// P_n = P_0 + n*s with s = round_to_ulp(r) (ties handled by mantissa parity).  A (voice, block) is
-// therefore described by a handful of "linear segments" {first frame, P at that frame, s}; K2's
-// lanes evaluate fma(f - n0, s, P0), which is exact.  Segment boundaries are binade crossings
-// (performed with one real fp64 addition) and the loop / stop events of :225-257.
+// P_n = P_0 + n*s with s = round_to_ulp(r) (ties handled by mantissa parity).  A voice is therefore
+// described by a stream of "linear segments" {first frame t, P at that frame, s} in window time; lanes
+// evaluate fma(frame - t, s, P), which is exact.  Segment boundaries are binade crossings (performed
+// with one real fp64 addition) and the loop / stop events of :225-257.
+//
+//   K1  (one lane per voice, sequential):   ZlPlanner -- one iteration per linear run, no per-block work
+//   K1c (one lane per voice x block chunk): zl_assemble_blocks -- segment stream -> per-block plan records
+//   K1b (one lane per frame):               zl_expand_frame -- blocks with > 2 segments -> per-frame control
+//
 // Blocks whose envelope is not in steady sustain (attack, decay, release tail of quirk Q7, note-off)
-// fall back to the per-frame simulation zl_sim_block(), which records (P, env) per frame for K2.
+// are simulated per frame by zl_sim_block(), which records (P, env) per frame for K2.
 //
 // Everything here is __host__ __device__ so the identical code is unit-tested on the CPU
 // (tests/cpu_harness) against the oracle; the product only ever runs it inside HIP kernels.
@@ -295,54 +299,56 @@ ZL_HD inline ZlBlockPlan zl_plan_load(const ZlBatch &A, size_t pidx)
     return pl;
 }
 
-// Plans the blocks of a batch for one voice and leaves the voice state as the reference would after rendering
-// them.  The planner is a flat state machine: one iterate() call = at most one new linear run (zl_linear_run +
-// the search for the loop / stop event inside it) and everything that run implies -- the rest of the open block,
-// the whole blocks after it (recorded as ONE ZlRun, not per block) and the head of the block in which it ends.
-// All lanes of a wavefront therefore execute the same straight-line code per iteration whatever their block
-// positions are (one lane per voice: a nested per-block / per-segment loop would serialise the lanes' loop
-// restarts, each of which crosses ~log2(N) binades).
+// floor(t / N) for 0 <= t < 2^31 without an integer division (invN = 1.0 / N)
+ZL_HD inline int zl_block_of(int t, int N, double invN)
+{
+    int k = (int)((double)t * invN);
+    if ((k + 1) * N <= t) ++k;
+    if (k * N > t) --k;
+    return k;
+}
+
+// Plans a window for one voice and leaves the voice state as the reference would after rendering it.
+// The planner is a flat state machine over window time t: one iterate() call = at most one new linear run
+// (zl_linear_run + the search for the loop / stop event inside it), emitted as ONE segment whatever number of
+// blocks it spans.  All lanes of a wavefront execute the same straight-line code per iteration whatever their
+// positions in the window are; everything per block is left to K1c / K1b, which are lane-parallel.
 struct ZlPlanner {
     ZlVoiceState st;
     ZlVoiceBatchConst c;
     ZlPlanStats stats;
     unsigned long long blockBytes;
     double X;                    // threshold of the position event that can occur in a fast (sustain) block
-    double inv_r;                // 1 / pitch_ratio
-    double s;                    // current linear run: step, steps left, steps to the position event
+    double inv_r, invN;          // 1 / pitch_ratio, 1 / N
+    double s;                    // current linear run: step, linear steps left, steps to the position event
     int L, ie;
-    int v, blocks_done;
-    bool valid, posMode, clockMode, haveRun;
-    // run list: the open run lives in registers and is stored when the next one opens (no private-memory array)
+    int v;
+    bool valid, posMode, clockMode, haveRun, slowNext, lastMarker;
+    int t;                       // next frame to plan (window time); its position is st.P
+    int nts;                     // segments emitted
+    int t_end;                   // frame at which the voice stopped (INT_MAX while it plays)
+    int dead_from;
+    // state at the start of the block that contains frame t (restored when that block has to be simulated after all)
+    double Pbs; uint64_t tick_bs, usecs_bs; int jbs;
+    // inline runs: the open one lives in registers and is stored when the next one opens
     ZlRun cur;
     int  nruns;
     bool haveCur;
-    // the block being planned: k, frames planned so far (n), its record under construction
-    int k, n, nseg;
-    bool needSeg, slowNext;
-    ZlBlockPlan pl;
-    uint64_t tick0, usecs0;      // loop clock at the start of the open block (restored when the block turns slow)
-
-    ZL_HD void flush_run(const ZlBatch &A)
-    {
-        if (nruns < ZL_MAXRUNS) A.runs[v].r[nruns] = cur;
-        else A.xruns[(size_t)v * ZL_XRUNS + (size_t)(nruns - ZL_MAXRUNS)] = cur;
-        ++nruns;
-    }
 
     ZL_HD void begin(const ZlBatch &A, int voice)
     {
         v = voice;
         st = A.voices[v];
         stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
-        blocks_done = 0;
         nruns = 0; haveCur = false; cur.P = 0.0; cur.step = 0.0; cur.k0 = 0; cur.k1 = 0;
-        s = 0.0; L = 0; ie = ZL_INF_STEPS; haveRun = false;
-        k = 0; n = 0; nseg = 0; needSeg = false; slowNext = false; tick0 = 0; usecs0 = 0;
-        zl_plan_clear(pl);
+        s = 0.0; L = 0; ie = ZL_INF_STEPS; haveRun = false; slowNext = false; lastMarker = false;
+        t = 0; nts = 0; t_end = INT_MAX; dead_from = 0;
+        Pbs = 0.0; tick_bs = 0; usecs_bs = 0; jbs = 0;
+        invN = 1.0 / (double)A.N;
         valid = st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0;
         posMode = false; clockMode = false; X = INFINITY; blockBytes = 0; inv_r = 0.0;
         if (!valid) return;
+        dead_from = A.K;
         inv_r = 1.0 / st.pitch_ratio;
         const ZlClip &cl = A.clips[st.clip];
         const ZlSound sd = A.sounds[st.clip];
@@ -377,197 +383,162 @@ struct ZlPlanner {
         posMode = posLoop || oneShot;
     }
 
-    // Steady state: while the current linear run covers whole blocks and no loop / stop event falls in them,
-    // consecutive blocks differ only in P0 and are recorded as ONE run (ZlRunList) instead of per-block plans.
-    // clk points at the clock of block k (beat-locked loops test every block's clock, SamplerSynthVoice.cpp:232).
-    // Covers blocks k .. k+m-1 (m <= kmax - k) and returns m.
-    ZL_HD int whole_blocks(const ZlBatch &A, int kmax, const ZlClock *clk)
+    // The block that starts at tb (= the block containing t) has to be simulated per frame after all: forget what
+    // was planned inside it.
+    ZL_HD void rollback_block(int tb)
     {
-        const int N = A.N;
-        int m = L / N;
-        if (ie != ZL_INF_STEPS) { const int me = (ie - 1) / N; m = me < m ? me : m; }
-        if (m > kmax - k) m = kmax - k;
-        if (m <= 0) return 0;
-        if (clockMode) {
-            int j = 0;
-            for (; j < m; ++j) {
-                const ZlClock &cj = clk[j];
-                if (cj.usecs_per_frame >= (1ull << 21)) break;
-                if (!(cj.current_usecs + (uint64_t)(N - 1) * cj.usecs_per_frame < st.next_loop_usecs)) break;   // restart inside block
-            }
-            m = j;
-            if (m <= 0) return 0;
+        if (t > tb) {
+            stats.active_frames -= (unsigned long long)(t - tb);
+            stats.source_bytes -= blockBytes;
+            st.P = Pbs; st.next_loop_tick = tick_bs; st.next_loop_usecs = usecs_bs;
+            nts = jbs;
+            t = tb;
         }
-        // record: extend the open run when this stretch continues it exactly, else close it and open a new one
-        bool recorded = false;
-        if (haveCur && cur.k1 == k && cur.step == s && fma((double)((k - cur.k0) * N), s, cur.P) == st.P) {
-            cur.k1 = k + m;
-            recorded = true;
-        } else if (nruns + (haveCur ? 1 : 0) < ZL_MAXRUNS + (A.xruns ? ZL_XRUNS : 0)) {
-            if (haveCur) flush_run(A);
-            cur.P = st.P; cur.step = s; cur.k0 = k; cur.k1 = k + m;
-            haveCur = true;
-            recorded = true;
-        }
-        if (!recorded) {
-            // run table full: fall back to explicit per-block plans
-            ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE; h.n_active = N; h.nseg = 1; h.env = st.sustain;
-            for (int j = 0; j < m; ++j) {
-                const size_t pidx = (size_t)(k + j) * A.V + v;
-                ZlPlanSeg0 s0; s0.P0 = fma((double)(j * N), s, st.P); s0.step = s;   // exact: inside the linear run
-                A.plan_hdr[pidx] = h;
-                A.plan_seg0[pidx] = s0;
-            }
-        }
-        const int steps = m * N;
-        st.P = fma((double)steps, s, st.P);
-        L -= steps;
-        if (ie != ZL_INF_STEPS) ie -= steps;
-        st.env = st.sustain;
-        stats.source_bytes += blockBytes * (unsigned long long)m;
-        stats.active_frames += (unsigned long long)steps;
-        return m;
+        haveRun = false;
+        slowNext = true;
     }
 
-    // One iteration (see the struct comment).  clk0 is the clock of block kb; blocks below kend may be planned.
-    // Call while k < kend.
+    // One iteration.  clk0 is the clock of block kb; frames below kend * N may be planned.  Call while t < kend * N.
     ZL_HD void iterate(const ZlBatch &A, int kend, const ZlClock *clk0, int kb, int force_slow)
     {
         const int N = A.N;
+        const int Tend = kend * N;
+        if (!(valid && st.playing)) { t = Tend; return; }          // idle blocks are implied by ZlRunList::dead_from
+        const int kcur = zl_block_of(t, N, invN);
+        const int tb = kcur * N;
+        const int n = t - tb;
+        ZlTSeg *ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
         if (n == 0) {
-            // ---- start of block k ----
-            if (!(valid && st.playing)) { k = kend; return; }       // idle blocks are implied by ZlRunList::dead_from
-            {
-                const ZlClock &ck = clk0[k - kb];
-                if (st.next_loop_usecs == 0)                        // :179-182
-                    st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
-                const bool slow = force_slow || slowNext || st.adsr_state != ZL_ADSR_SUSTAIN
-                                  || (clockMode && ck.usecs_per_frame >= (1ull << 21));
-                if (slow) {
-                    // envelope transient, release tail (Q7), or a block whose segments did not fit: per-frame simulation
-                    const size_t pidx = (size_t)k * A.V + v;
-                    slowNext = false;
-                    zl_plan_clear(pl);
-                    pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW; pl.env = st.sustain; pl.P0 = st.P;
-                    pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
-                    haveRun = false;
-                    zl_plan_store(A, pidx, pl);
-                    stats.slow_blocks += 1;
-                    stats.source_bytes += blockBytes;
-                    stats.active_frames += (unsigned long long)pl.n_active;
-                    ++k; blocks_done = k;
-                    return;
+            // ---- start of block kcur ----
+            const ZlClock &ck = clk0[kcur - kb];
+            if (st.next_loop_usecs == 0)                            // :179-182
+                st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
+            const bool slow = force_slow || slowNext || st.adsr_state != ZL_ADSR_SUSTAIN
+                              || (clockMode && ck.usecs_per_frame >= (1ull << 21)) || nts >= ZL_MAXTSEG - 1;
+            if (slow) {
+                // envelope transient, release tail (Q7) or a pathological clock: per-frame simulation of this block
+                const size_t pidx = (size_t)kcur * A.V + v;
+                slowNext = false;
+                if (!lastMarker && nts < ZL_MAXTSEG) {              // consecutive simulated blocks share one marker
+                    ZlTSeg m; m.P = st.P; m.step = 0.0; m.t = t; m.flags = ZL_TSEG_SLOW;
+                    ts[nts++] = m;
+                    lastMarker = true;
                 }
+                ZlBlockPlan pl;
+                zl_plan_clear(pl);
+                pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW; pl.env = st.sustain; pl.P0 = st.P;
+                pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
+                haveRun = false;
+                zl_plan_store(A, pidx, pl);
+                stats.slow_blocks += 1;
+                stats.source_bytes += blockBytes;
+                stats.active_frames += (unsigned long long)pl.n_active;
+                if (!st.playing) { t_end = t + pl.n_active; dead_from = kcur + 1; }
+                t += N;
+                return;
             }
-            if (haveRun) {
-                const int m = whole_blocks(A, kend, clk0 + (k - kb));
-                if (m > 0) {
-                    k += m; blocks_done = k;
-                    if (k >= kend) return;
-                    if (clockMode && clk0[k - kb].usecs_per_frame >= (1ull << 21)) return;   // next iteration simulates it
-                }
-            }
-            zl_plan_clear(pl);
-            pl.flags = ZL_PLAN_ACTIVE; pl.n_active = N; pl.env = st.sustain; pl.P0 = st.P;
-            nseg = 0; needSeg = true;                               // frame 0 is not covered by an emitted segment yet
-            tick0 = st.next_loop_tick; usecs0 = st.next_loop_usecs;
+            Pbs = st.P; tick_bs = st.next_loop_tick; usecs_bs = st.next_loop_usecs; jbs = nts;
         }
-        const ZlClock &ck = clk0[k - kb];
-        const size_t pidx = (size_t)k * A.V + v;
 
-        // ---- a new linear run when the previous one is used up ----
+        // ---- a new linear run (and its segment) when the previous one is used up ----
         if (!haveRun) {
+            if (nts >= ZL_MAXTSEG - 1) { rollback_block(tb); return; }   // table full (one slot is kept for a marker): simulate this block
             zl_linear_run(st.P, st.pitch_ratio, inv_r, s, L);
             haveRun = true;
-            needSeg = true;
-            ie = posMode ? zl_steps_to_reach(st.P, s, inv_r, L, X) : ZL_INF_STEPS;
-        }
-        bool slow = false, ended = false;
-        if (needSeg) {
-            if (nseg >= ZL_MAXSEG) slow = true;
-            else {
-                if (nseg == 0) { pl.P0 = st.P; pl.step = s; }
-                else if (nseg == 1) { pl.n1 = n; pl.P1 = st.P; pl.step1 = s; }
-                else { ZlSegment sg; sg.P0 = st.P; sg.step = s; sg.n0 = n; sg.pad = 0; A.segs[pidx * (ZL_MAXSEG - 2) + (size_t)(nseg - 2)] = sg; }
-                ++nseg;
-                needSeg = false;
+            // the event inside the run's L linear steps, else at the real addition that closes it (step L + 1)
+            ie = ZL_INF_STEPS;
+            if (posMode) {
+                ie = zl_steps_to_reach(st.P, s, inv_r, L, X);
+                if (ie == ZL_INF_STEPS && (fma((double)L, s, st.P) + st.pitch_ratio) >= X) ie = L + 1;
             }
+            ZlTSeg sg; sg.P = st.P; sg.step = s; sg.t = t; sg.flags = 0;
+            ts[nts++] = sg;
+            lastMarker = false;
         }
-        // ---- consume the run inside block k ----
-        if (!slow) {
-            bool event = false;
-            bool realStep = (L == 0);
-            if (!realStep) {
-                const int room = N - n;
-                const int m = L < room ? L : room;
-                int iclk = ZL_INF_STEPS;
-                if (clockMode) {
-                    const int fa = zl_clock_event_frame(ck, st.next_loop_usecs, n, N);
-                    if (fa < N) iclk = fa - n + 1;
-                }
-                const int iev = ie < iclk ? ie : iclk;
-                if (iev > m) {
-                    st.P = fma((double)m, s, st.P);
-                    n += m; L -= m;
-                    if (ie != ZL_INF_STEPS) ie -= m;
-                    if (L == 0) {
-                        // run exhausted: at the block end the next block starts a new run; inside the block frame n is
-                        // still covered by the current segment (P0 + L*s) and the binade is left with one real addition,
-                        // without opening a one-frame segment
-                        if (n < N) realStep = true; else haveRun = false;
-                    }
+
+        // ---- how far this iteration goes: the run (L linear steps + 1 real addition), an event, the end of the chunk ----
+        const int S = L + 1;
+        const int room = Tend - t;
+        const int maxsteps = S < room ? S : room;
+        int steps = maxsteps;
+        bool event = false;
+        int ke = kcur;                                              // block in which the event fires
+        if (posMode) {
+            if (ie <= maxsteps) {
+                if (!st.looping && st.release > 0.0f) {
+                    // the release tail starts after frame t + ie - 1 (Q7): that block is simulated from its start
+                    const int be = zl_block_of(t + ie - 1, N, invN) * N;
+                    if (be <= t) { rollback_block(be); return; }
+                    steps = be - t;
+                    slowNext = true;
                 } else {
-                    n += iev;
-                    haveRun = false;
+                    steps = ie;
                     event = true;
                 }
             }
-            if (realStep) {
-                const double Pn = st.P + st.pitch_ratio;           // one real fp64 addition from frame n
-                const bool ev = posMode ? (Pn >= X)
-                                        : (clockMode ? (zl_clock_event_frame(ck, st.next_loop_usecs, n, N) == n) : false);
-                n += 1;
-                haveRun = false;
-                if (!ev) st.P = Pn; else event = true;
-            }
-            if (event) {
-                // ---- event after rendering frame n-1 ----
-                if (st.looping) {
-                    zl_loop_restart(st, c, ck, clockMode);
-                } else if (st.release > 0.0f) {
-                    slow = true;                                   // release tail starts inside this block (Q7)
-                } else {
-                    pl.n_active = n;                               // :249-252, voice ends after frame n-1
-                    zl_voice_hard_stop(st);
-                    ended = true;
+        } else if (clockMode) {
+            // the frame after whose rendering the beat-locked test (:232) fires, block by block
+            const int tlimit = t + maxsteps;
+            int kk = kcur, nn = n;
+            for (int bs = tb; bs < tlimit; bs += N, ++kk, nn = 0) {
+                const ZlClock &cj = clk0[kk - kb];
+                if (nn == 0 && cj.usecs_per_frame >= (1ull << 21)) { steps = bs - t; break; }   // simulated block (bs > t)
+                const int fa = zl_clock_event_frame(cj, st.next_loop_usecs, nn, N);
+                if (fa < N) {
+                    if (bs + fa < tlimit) { steps = bs + fa - t + 1; event = true; ke = kk; }
+                    break;
                 }
             }
         }
-        if (slow) {
-            // back to the start of block k; the next iteration simulates it per frame
-            st.P = pl.P0; st.next_loop_tick = tick0; st.next_loop_usecs = usecs0;
-            haveRun = false; n = 0; slowNext = true;
-            return;
-        }
-        if (n >= N || ended) {
-            // ---- block k is complete ----
-            pl.nseg = nseg;
-            if (st.playing) st.env = st.sustain;                   // the sustain branch assigns envelopeVal every frame
-            if (nseg > 2 && A.expand_list) {
-                // K2 evaluates at most two segments per block: queue this one for K1b, which turns its
-                // segments into per-frame control (lane-parallel) and marks the block ZL_PLAN_SLOW
-#if defined(__HIP_DEVICE_COMPILE__)
-                const int slot = atomicAdd(A.expand_count, 1);
-#else
-                const int slot = (*A.expand_count)++;
-#endif
-                A.expand_list[slot] = (int32_t)pidx;
+
+        // ---- frames t .. t+steps-1 are rendered from the line P + i * s (steps <= L + 1) ----
+        const int t1 = t + steps;
+        const int k1 = zl_block_of(t1, N, invN);                    // block of the next frame
+        {
+            const int k0 = (n == 0) ? kcur : kcur + 1;              // whole blocks inside [t, t1)
+            stats.active_frames += (unsigned long long)steps;
+            const int started = zl_block_of(t1 - 1, N, invN) - kcur + (n == 0 ? 1 : 0);
+            stats.source_bytes += blockBytes * (unsigned long long)started;
+            if (k1 > k0) {
+                const double Pk0 = fma((double)(k0 * N - t), s, st.P);     // exact: on the line
+                if (haveCur && cur.k1 == k0 && cur.step == s && fma((double)((k0 - cur.k0) * N), s, cur.P) == Pk0) {
+                    cur.k1 = k1;                                    // the same run continued (chunk boundary)
+                } else if (nruns + (haveCur ? 1 : 0) < ZL_MAXRUNS) {
+                    if (haveCur) A.runs[v].r[nruns++] = cur;
+                    cur.P = Pk0; cur.step = s; cur.k0 = k0; cur.k1 = k1;
+                    haveCur = true;
+                }
             }
-            zl_plan_store(A, pidx, pl);
-            stats.source_bytes += blockBytes;
-            stats.active_frames += (unsigned long long)pl.n_active;
-            ++k; n = 0; blocks_done = k;
         }
+        const double Pold = st.P;
+        const uint64_t tickOld = st.next_loop_tick, usecsOld = st.next_loop_usecs;
+        if (event) {
+            // ---- event after rendering frame t1 - 1 ----
+            haveRun = false;
+            if (st.looping) {
+                zl_loop_restart(st, c, clk0[ke - kb], clockMode);
+            } else {
+                zl_voice_hard_stop(st);                             // :249-252, voice ends after frame t1 - 1
+                t_end = t1;
+                dead_from = zl_block_of(t1 - 1, N, invN) + 1;
+            }
+        } else if (steps == S) {
+            st.P = fma((double)L, s, st.P) + st.pitch_ratio;        // the real addition that leaves the binade
+            haveRun = false;
+        } else {
+            st.P = fma((double)steps, s, st.P);                     // stopped at the chunk end or before a simulated block
+            L -= steps;
+            if (ie != ZL_INF_STEPS) ie -= steps;
+        }
+        if (st.playing) st.env = st.sustain;                        // the sustain branch assigns envelopeVal every frame
+        // ---- state at the start of the block that now contains t1 ----
+        if (k1 * N > t) {
+            const int b = k1 * N;
+            if (b == t1) { Pbs = st.P; tick_bs = st.next_loop_tick; usecs_bs = st.next_loop_usecs; }
+            else         { Pbs = fma((double)(b - t), s, Pold); tick_bs = tickOld; usecs_bs = usecsOld; }   // the event (if any) comes after b
+            jbs = nts;
+        }
+        t = t1;
     }
 
     ZL_HD void end(const ZlBatch &A)
@@ -575,15 +546,17 @@ struct ZlPlanner {
         ZlReport rep;
         rep.playing = st.playing; rep.valid = 0; rep.peak_bits = 0; rep.progress = 0.0f; rep.clip = st.clip; rep.pad = 0; rep.P = st.P;
         // :265-267 -- the report of the last block exists only if the voice still has its clip
-        if (valid && st.playing && blocks_done == A.K) {
+        if (valid && st.playing && t >= A.K * A.N) {
             rep.valid = 1;
             rep.progress = (float)(st.P / st.src_len);
         }
         A.reports[v] = rep;
         A.voices[v] = st;
-        if (haveCur) flush_run(A);
+        if (haveCur) A.runs[v].r[nruns++] = cur;
         A.runs[v].n = nruns;
-        A.runs[v].dead_from = valid ? blocks_done : 0;             // blocks >= dead_from are idle (voice ended or never played)
+        A.runs[v].dead_from = dead_from;                           // blocks >= dead_from are idle (voice ended or never played)
+        A.runs[v].nts = nts;
+        A.runs[v].t_end = t_end;
     }
 };
 
@@ -611,48 +584,79 @@ ZL_HD inline ZlBlockPlan zl_plan_lookup(const ZlBatch &A, int k, int v, float ru
     return zl_plan_load(A, (size_t)k * A.V + v);
 }
 
-// K1c body for one voice: blocks [kbeg, kend) covered by an overflow run get their explicit plan record
-// (the inline runs stay implied).  Runs are sorted by block, so one binary search finds the first candidate.
-ZL_HD inline void zl_expand_xruns(const ZlBatch &A, int v, int kbeg, int kend)
+// K1c body: the explicit plan records of blocks [kbeg, kend) of voice v from its segment stream.  Blocks inside
+// an inline run, simulated blocks (K1 wrote their records) and idle blocks are left alone.
+ZL_HD inline void zl_assemble_blocks(const ZlBatch &A, int v, int kbeg, int kend)
 {
-    const int nx = A.runs[v].n - ZL_MAXRUNS;
-    if (nx <= 0 || !A.xruns) return;
-    const ZlRun *xr = A.xruns + (size_t)v * ZL_XRUNS;
-    int lo = 0, hi = nx;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (xr[mid].k1 <= kbeg) lo = mid + 1; else hi = mid; }
-    if (lo >= nx) return;
-    ZlRun r = xr[lo];
-    ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE; h.n_active = A.N; h.nseg = 1; h.env = A.vconst[v].env;
+    const ZlRunList rl = A.runs[v];
+    const int N = A.N;
+    if (kend > rl.dead_from) kend = rl.dead_from;
+    if (kbeg >= kend || rl.nts <= 0) return;
+    const ZlTSeg *ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
+    const int nts = rl.nts;
+    // last segment that starts at or before the first frame of block kbeg
+    int lo = 0, hi = nts;
+    const int T0 = kbeg * N;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid].t <= T0) lo = mid + 1; else hi = mid; }
+    int j = lo - 1;
+    if (j < 0) return;                                            // cannot happen: the stream starts at t = 0
+    const float env = A.vconst[v].env;
     for (int k = kbeg; k < kend; ++k) {
-        while (k >= r.k1) { if (++lo >= nx) return; r = xr[lo]; }
-        if (k < r.k0) continue;                                   // an explicitly planned block between two runs
+        const int T = k * N;
+        while (j + 1 < nts && ts[j + 1].t <= T) ++j;
+        const ZlTSeg a = ts[j];
+        if (a.flags & ZL_TSEG_SLOW) continue;
+        bool inrun = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < ZL_MAXRUNS; ++q) inrun = inrun || (q < rl.n && k >= rl.r[q].k0 && k < rl.r[q].k1);
+        if (inrun) continue;
+        const int n_active = (rl.t_end - T < N) ? rl.t_end - T : N;
+        int nseg = 1;
+        while (nseg < 3 && j + nseg < nts && ts[j + nseg].t < T + n_active) ++nseg;
         const size_t pidx = (size_t)k * A.V + v;
-        ZlPlanSeg0 s0; s0.P0 = fma((double)((k - r.k0) * A.N), r.step, r.P); s0.step = r.step;   // exact: inside the linear run
+        ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE; h.n_active = n_active; h.nseg = nseg; h.env = env;
+        ZlPlanSeg0 s0; s0.P0 = fma((double)(T - a.t), a.step, a.P); s0.step = a.step;      // exact: on the segment's line
         A.plan_hdr[pidx] = h;
         A.plan_seg0[pidx] = s0;
+        if (nseg >= 2) {
+            const ZlTSeg b = ts[j + 1];
+            ZlPlanSeg1 s1; s1.P1 = b.P; s1.step1 = b.step; s1.n1 = b.t - T; s1.pad = 0; s1.pad2 = 0.0;
+            A.plan_seg1[pidx] = s1;
+        }
+        if (nseg > 2 && A.expand_list) {
+            // K2 evaluates at most two segments per block: K1b turns this block's segments into per-frame control
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int slot = atomicAdd(A.expand_count, 1);
+#else
+            const int slot = (*A.expand_count)++;
+#endif
+            ZlExpand e; e.k = k; e.v = v; e.j0 = j; e.pad = 0;
+            A.expand_list[slot] = e;
+        }
     }
 }
 
-// K1b body for one frame of one queued block: the position of frame f from the block's segments.
-ZL_HD inline double zl_expand_position(const ZlBlockPlan &pl, const ZlSegment *extra, int f)
+// K1b body for one frame of one queued block: the position of frame f (< n_active) from the voice's segments.
+ZL_HD inline double zl_expand_frame(const ZlBatch &A, const ZlExpand &e, int nts, int f)
 {
-    double P0 = pl.P0, step = pl.step;
-    int n0 = 0;
-    if (f >= pl.n1) { P0 = pl.P1; step = pl.step1; n0 = pl.n1; }
-    for (int i = 0; i + 2 < pl.nseg; ++i)
-        if (f >= extra[i].n0) { P0 = extra[i].P0; step = extra[i].step; n0 = extra[i].n0; }
-    return fma((double)(f - n0), step, P0);                       // exact
+    const ZlTSeg *ts = A.tsegs + (size_t)e.v * ZL_MAXTSEG;
+    const int T = e.k * A.N + f;
+    int lo = e.j0 + 1, hi = nts;                                  // last segment with t <= T (segment j0 qualifies)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid].t <= T) lo = mid + 1; else hi = mid; }
+    const ZlTSeg a = ts[lo - 1];
+    return fma((double)(T - a.t), a.step, a.P);                   // exact
 }
 
-// Whole batch of one voice with the clocks read from A.clocks (host harness; the kernel stages them in LDS).
+// Whole window of one voice with the clocks read from A.clocks (host harness; the kernel stages them in LDS).
 ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanStats &stats)
 {
     ZlPlanner pl;
     pl.begin(A, v);
-    while (pl.k < A.K) pl.iterate(A, A.K, A.clocks, 0, force_slow);
+    while (pl.t < A.K * A.N) pl.iterate(A, A.K, A.clocks, 0, force_slow);
     pl.end(A);
     stats = pl.stats;
-    zl_expand_xruns(A, v, 0, A.K);
 }
 
 // ---- voice operations (device half of SamplerChannel::handleCommand, SamplerSynth.cpp:187-230) --

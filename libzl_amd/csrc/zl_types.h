@@ -8,7 +8,6 @@
 #define ZL_HD
 #endif
 
-#define ZL_MAXSEG        16     // linear position segments per (voice, block) before the per-frame path is used
 #define ZL_MAX_SLICES    128
 #define ZL_BEAT_SUBDIV   96
 
@@ -89,20 +88,25 @@ struct ZlVoiceConst {             // per voice, constant over a batch; 48 bytes 
 };
 
 enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2 };
-// Steady-state stretches of a voice inside a batch: blocks [k0, k1) are rendered whole, in sustain, from
-// one linear position run, so their plan is implied: P0(k) = P + (k - k0) * N * step (exact).  K1 records
-// a handful of these per voice instead of K per-block plans; only the blocks around loop restarts,
-// binade crossings and envelope transients get explicit plan records.
-// The first ZL_MAXRUNS runs of a voice are kept inline (K2 resolves them without touching the plan arrays: the
-// steady state of unpitched playback); further runs of the window go to the overflow table ZlBatch::xruns and are
-// turned into explicit per-block plans by K1c, lane-parallel (pitched voices open ~10 runs per loop pass, one per
-// binade).
+// K1's output per voice and plan window is a stream of linear position segments in window time: frames
+// [t, next segment's t) are rendered at P + (frame - t) * step, exactly (zl_plan.h).  A segment ends at a binade
+// crossing, a loop restart or the end of the voice.  K1c turns the stream into per-block plans, lane-parallel.
+// ZL_TSEG_SLOW marks the start of blocks that K1 simulated per frame itself (envelope transients, release tails).
+#define ZL_MAXTSEG   1024
+#define ZL_TSEG_SLOW 1
+struct ZlTSeg { double P, step; int32_t t, flags; };
+
+// Whole blocks inside one segment differ only in P0 and need no plan record at all: blocks [k0, k1) of a run
+// are rendered whole, in sustain, with P0(k) = P + (k - k0) * N * step (exact).  The first ZL_MAXRUNS such
+// stretches of a voice are kept inline (K2 resolves them without touching the plan arrays: all of the steady
+// state of playback at the source rate); every other block gets an explicit plan from K1c.
 #define ZL_MAXRUNS 6
-#define ZL_XRUNS   250
 struct ZlRun { double P, step; int32_t k0, k1; };
 struct ZlRunList {
-    int32_t n;                    // runs used: the first ZL_MAXRUNS inline, the rest in ZlBatch::xruns
+    int32_t n;                    // inline runs used
     int32_t dead_from;            // first block in which the voice no longer plays (K if it plays to the end; 0 = idle)
+    int32_t nts;                  // segments in ZlBatch::tsegs
+    int32_t t_end;                // frame (window time) at which the voice stopped; INT_MAX while it plays
     ZlRun   r[ZL_MAXRUNS];
 };
 
@@ -115,7 +119,7 @@ struct ZlPlanSeg1 { double P1, step1; int32_t n1, pad; double pad2; };
 struct ZlBlockPlan {              // per (block, voice); 64 bytes, the first two linear segments inline
     int32_t flags;
     int32_t n_active;             // frames rendered in this block (N unless the voice stopped inside it)
-    int32_t nseg;                 // >= 1 for fast blocks; segments beyond the second live in the side array
+    int32_t nseg;                 // 1 or 2 for fast blocks (blocks with more are expanded to per-frame control by K1b)
     float   env;                  // envelope value of every frame of a fast block (sustain)
     double  P0;                   // position of frame 0
     double  step;                 // exact per-frame increment inside the first segment
@@ -125,12 +129,7 @@ struct ZlBlockPlan {              // per (block, voice); 64 bytes, the first two
     double  step1;
     double  pad2;
 };
-struct ZlSegment {                // segments 3.. of a block: [block][voice][ZL_MAXSEG-2]
-    double  P0;
-    double  step;
-    int32_t n0;                   // first frame of the segment
-    int32_t pad;
-};
+struct ZlExpand { int32_t k, v, j0, pad; };   // a block with more than two segments, queued by K1c for K1b (j0 = its first segment)
 
 struct ZlReport {                 // device side of zlhip_voice_report
     int32_t playing, valid;
@@ -176,11 +175,10 @@ struct ZlBatch {
     const ZlOpRange    *op_ranges;
     ZlVoiceConst       *vconst;   // [V]
     ZlRunList          *runs;     // [V]
-    ZlRun              *xruns;    // [V][ZL_XRUNS] overflow runs (null: none, K1 falls back to per-block plans)
+    ZlTSeg             *tsegs;    // [V][ZL_MAXTSEG] segment stream of the window
     ZlPlanHdr          *plan_hdr; // [K][V] explicit plans (blocks not covered by a run)
     ZlPlanSeg0         *plan_seg0;// [K][V]
     ZlPlanSeg1         *plan_seg1;// [K][V] valid where nseg >= 2
-    ZlSegment          *segs;     // [K][V][ZL_MAXSEG-2]
     double             *ctl_P;    // [K][V][N]   per-frame control of slow blocks
     float              *ctl_env;  // [K][V][N]
     ZlReport           *reports;  // [V]
@@ -189,6 +187,6 @@ struct ZlBatch {
     ZlBlockLevels      *levels;   // [K][B]
     int32_t            *pos_trace;// [K][V][N] or null
     ZlBatchStats       *stats;
-    int32_t            *expand_list;  // [K*V] plan indices whose segments K1b expands into per-frame control
+    ZlExpand           *expand_list;  // [K*V] blocks whose segments K1b expands into per-frame control
     int32_t            *expand_count; // [1]
 };

@@ -22,9 +22,8 @@ struct ZlSim {
     std::vector<ZlSound> sounds;
     std::vector<ZlClip> clips;
     std::vector<ZlVoiceState> voices;
-    std::vector<ZlVoiceConst> vconst; std::vector<ZlRunList> runs; std::vector<ZlRun> xruns;
+    std::vector<ZlVoiceConst> vconst; std::vector<ZlRunList> runs; std::vector<ZlTSeg> tsegs;
     std::vector<ZlPlanHdr> planHdr; std::vector<ZlPlanSeg0> planSeg0; std::vector<ZlPlanSeg1> planSeg1;
-    std::vector<ZlSegment> segs;
     std::vector<double> ctlP; std::vector<float> ctlEnv;
     std::vector<ZlReport> reports;
     std::vector<int32_t> trace;
@@ -99,7 +98,7 @@ ZlSim *zlsim_create(int B, int VPB, int max_sounds, double fs, uint32_t mode, in
     S->sounds.assign((size_t)max_sounds, ZlSound{0, 0, 0, 0.0});
     S->clips.assign((size_t)max_sounds, ZlClip{});
     S->voices.assign((size_t)S->V, ZlVoiceState{});
-    S->vconst.assign((size_t)S->V, ZlVoiceConst{}); S->runs.assign((size_t)S->V, ZlRunList{}); S->xruns.assign((size_t)S->V * ZL_XRUNS, ZlRun{});
+    S->vconst.assign((size_t)S->V, ZlVoiceConst{}); S->runs.assign((size_t)S->V, ZlRunList{}); S->tsegs.assign((size_t)S->V * ZL_MAXTSEG, ZlTSeg{});
     S->reports.assign((size_t)S->V, ZlReport{});
     return S;
 }
@@ -152,7 +151,6 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     std::vector<ZlClock> ck((size_t)K);
     for (int k = 0; k < K; ++k) ZlHostControl::fill_clock(ck[(size_t)k], clocks[k], N);
     S->planHdr.assign((size_t)K * V, ZlPlanHdr{}); S->planSeg0.assign((size_t)K * V, ZlPlanSeg0{}); S->planSeg1.assign((size_t)K * V, ZlPlanSeg1{});
-    S->segs.assign((size_t)K * V * (ZL_MAXSEG - 2), ZlSegment{});
     S->ctlP.assign((size_t)K * V * N, 0.0); S->ctlEnv.assign((size_t)K * V * N, 0.0f);
     S->trace.assign((size_t)K * V * N, -1);
     S->levels.assign((size_t)K * S->B, ZlBlockLevels{});
@@ -163,7 +161,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     ZlBatch A; std::memset(&A, 0, sizeof A);
     A.V = S->V; A.B = S->B; A.VPB = S->VPB; A.K = K; A.N = N; A.k0 = 0; A.Ktot = K; A.G = S->G; A.groups = (S->VPB + S->G - 1) / S->G; A.mode = S->mode;
     A.clocks = ck.data(); A.sounds = S->sounds.data(); A.clips = S->clips.data(); A.arena = S->arena.data();
-    A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.xruns = S->xruns.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data(); A.segs = S->segs.data();
+    A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.tsegs = S->tsegs.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data();
     A.ctl_P = S->ctlP.data(); A.ctl_env = S->ctlEnv.data(); A.reports = S->reports.data();
 
     for (const ZlOpRange &rg : ranges) {                          // K0
@@ -171,7 +169,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
         for (int j = 0; j < rg.count; ++j) zl_apply_op(st, ops[(size_t)(rg.first + j)]);
         S->voices[(size_t)rg.voice] = st;
     }
-    std::vector<int32_t> expandList((size_t)K * V); int32_t expandCount = 0;
+    std::vector<ZlExpand> expandList((size_t)K * V); int32_t expandCount = 0;
     A.expand_list = expandList.data(); A.expand_count = &expandCount;
     S->stats = ZlPlanStats{0, 0, 0};
     for (int v = 0; v < S->V; ++v) {                              // K1
@@ -179,13 +177,15 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
         zl_plan_voice(A, v, force_slow, st);
         S->stats.source_bytes += st.source_bytes; S->stats.slow_blocks += st.slow_blocks; S->stats.active_frames += st.active_frames;
     }
+    for (int v = 0; v < S->V; ++v) zl_assemble_blocks(A, v, 0, K);          // K1c
     S->expanded = expandCount;
-    for (int e = 0; e < expandCount; ++e) {                       // K1b
-        const size_t pidx = (size_t)expandList[(size_t)e];
-        const ZlBlockPlan pl = zl_plan_load(A, pidx);
+    for (int i = 0; i < expandCount; ++i) {                       // K1b
+        const ZlExpand e = expandList[(size_t)i];
+        const size_t pidx = (size_t)e.k * V + (size_t)e.v;
+        const ZlPlanHdr h = S->planHdr[pidx];
         for (int f = 0; f < N; ++f) {
-            S->ctlP[pidx * (size_t)N + f] = zl_expand_position(pl, S->segs.data() + pidx * (ZL_MAXSEG - 2), f < pl.n_active ? f : 0);
-            S->ctlEnv[pidx * (size_t)N + f] = pl.env;
+            S->ctlP[pidx * (size_t)N + f] = zl_expand_frame(A, e, S->runs[(size_t)e.v].nts, f < h.n_active ? f : 0);
+            S->ctlEnv[pidx * (size_t)N + f] = h.env;
         }
         S->planHdr[pidx].flags |= ZL_PLAN_SLOW;
     }

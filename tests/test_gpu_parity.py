@@ -103,9 +103,9 @@ def test_plan_windows_overlap_planning_and_rendering(Engine, window):
 
 
 @pytest.mark.parametrize("window", [0, 512])
-def test_run_table_overflow(Engine, window):
-    """Short pitched loops over a long batch: inline runs, the overflow table expanded by K1c and, when that is
-    full too, per-block plans (one window of 1500 blocks; three windows of 256/512/512...)."""
+def test_segment_table_overflow(Engine, window):
+    """Short pitched loops over a long batch: thousands of segments per voice; a full segment table makes K1
+    simulate the rest of the window (one window of 1500 blocks; windows of 256/512/512...)."""
     sc = random_scene(510, nclips=8, min_len=700, max_len=1500, nblocks=1500, nframes=64, events=False)
     for ev in sc.events[0]:
         ev[1]["looping"] = 1

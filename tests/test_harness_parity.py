@@ -69,20 +69,19 @@ def test_steady_state_uses_runs_not_per_block_plans(Sim):
     compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
     assert syn.slow_blocks() == 0
     playing = [v for v in range(syn.num_voices) if rep[v].playing]
-    # 6 inline runs + the overflow table (pitched voices open one run per binade and loop pass)
-    assert playing and all(1 <= syn.l.zlsim_num_runs(syn.s, v) <= 40 for v in playing)
+    assert playing and all(1 <= syn.l.zlsim_num_runs(syn.s, v) <= 6 for v in playing)      # inline runs
 
 
-def test_run_table_overflow_falls_back_to_block_plans(Sim):
-    """Short pitched loops over one long batch: hundreds of runs per voice -- the inline runs, the overflow table
-    (K1c) and, once that is full, per-block plans must all give the oracle's audio."""
+def test_segment_table_overflow_falls_back_to_simulation(Sim):
+    """Short pitched loops over one long window: thousands of linear segments per voice.  When a voice's segment
+    table (ZL_MAXTSEG) is full the rest of its window is simulated per frame -- same audio as the oracle."""
     sc = random_scene(510, nclips=8, min_len=700, max_len=1500, nblocks=1500, nframes=64, events=False)
     for ev in sc.events[0]:
         ev[1]["looping"] = 1
     ref_bus, ref_rep, ref_syn = run_oracle(sc)
     bus, rep, syn, _ = run_backend(sc, Sim, batch=1500)
     compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
-    assert max(syn.l.zlsim_num_runs(syn.s, v) for v in range(syn.num_voices)) == 256      # 6 inline + 250 overflow
+    assert syn.slow_blocks() > 100                                # the fallback was exercised
 
 
 def test_no_free_voice_drops_command_like_reference(Sim):

@@ -181,7 +181,9 @@ def main():
 
     # the engine renders into a torch-owned device buffer so the RCCL reduce needs no copy
     bus = torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32)
-    stream = torch.cuda.current_stream(dev)
+    # an explicit (non-default) torch stream: the engine launches on it and, for N > 1, RCCL orders its reduce after
+    # the work queued on torch's *current* stream -- so this stream is made current for every step below
+    stream = torch.cuda.Stream(device=dev)
     sptr = stream.cuda_stream
     clock_sets = [synthetic_clocks(KB, N, args.fs, start_block=i * KB) for i in range(args.warmup + args.steps)]
 
@@ -212,6 +214,8 @@ def main():
         else:
             syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr)
 
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(stream)
     for i in range(args.warmup):
         step(i, False)
     torch.cuda.synchronize()

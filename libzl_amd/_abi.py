@@ -130,7 +130,8 @@ SIGNATURES = {
     "zlhip_device_name": (C.c_int, [_E, C.c_char_p, C.c_size_t]),
 }
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libzlhip.so")
+# ZLHIP_LIBRARY selects another build of the same library (A/B measurements of kernel variants); never a fallback
+LIB_PATH = os.environ.get("ZLHIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libzlhip.so")
 _lib = None
 
 

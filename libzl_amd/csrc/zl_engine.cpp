@@ -46,7 +46,7 @@ struct zlhip_engine {
     struct PlanSet {
         ZlVoiceConst *vconst = nullptr; ZlRunList *runs = nullptr; ZlTSeg *tsegs = nullptr;
         ZlPlanHdr *hdr = nullptr; ZlPlanSeg0 *seg0 = nullptr; ZlPlanSeg1 *seg1 = nullptr;
-        double *ctlP = nullptr; float *ctlEnv = nullptr; ZlExpand *expandList = nullptr; int32_t *expandCount = nullptr;
+        double *ctlP = nullptr; float *ctlEnv = nullptr;
         float *partials = nullptr;
         hipEvent_t planned = nullptr, rendered = nullptr;
     } ps[2];
@@ -149,7 +149,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
                     e->dOpRanges, e->dStats, e->dTrace, e->dPass };
     for (void *p : dev) if (p) (void)hipFree(p);
     for (auto &q : e->ps) {
-        void *pd[] = { q.vconst, q.runs, q.tsegs, q.hdr, q.seg0, q.seg1, q.ctlP, q.ctlEnv, q.expandList, q.expandCount, q.partials };
+        void *pd[] = { q.vconst, q.runs, q.tsegs, q.hdr, q.seg0, q.seg1, q.ctlP, q.ctlEnv, q.partials };
         for (void *p : pd) if (p) (void)hipFree(p);
         if (q.planned) (void)hipEventDestroy(q.planned);
         if (q.rendered) (void)hipEventDestroy(q.rendered);
@@ -225,8 +225,6 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             chk(dalloc(&q.seg1, W * V), "plan segment 1");
             chk(dalloc(&q.ctlP, W * V * N), "ctlP");
             chk(dalloc(&q.ctlEnv, W * V * N), "ctlEnv");
-            chk(dalloc(&q.expandList, W * V), "expand list");
-            chk(dalloc(&q.expandCount, 1), "expand count");
             chk(dalloc(&q.partials, e->maxGroups > 1 ? W * B * (size_t)e->maxGroups * 2 * N : 1), "partials");
         }
         const size_t nwin = (K + W - 1) / W + 16;                 // + the doubling windows at the start of a call
@@ -509,15 +507,13 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         Aw.levels = e->dLevels + (size_t)Aw.k0 * A.B;
         Aw.pos_trace = traceBase ? traceBase + (size_t)Aw.k0 * e->V * nframes : nullptr;
         Aw.vconst = q.vconst; Aw.runs = q.runs; Aw.tsegs = q.tsegs; Aw.plan_hdr = q.hdr; Aw.plan_seg0 = q.seg0; Aw.plan_seg1 = q.seg1;
-        Aw.ctl_P = q.ctlP; Aw.ctl_env = q.ctlEnv; Aw.expand_list = q.expandList; Aw.expand_count = q.expandCount; Aw.partials = q.partials;
+        Aw.ctl_P = q.ctlP; Aw.ctl_env = q.ctlEnv; Aw.partials = q.partials;
         if (w > 0) { Aw.n_op_ranges = 0; Aw.ops = nullptr; Aw.op_ranges = nullptr; }     // commands apply before the first block only
         // planning of window w may not overwrite the set while window w-2 is still being rendered from it
         if (overlap && w >= 2) ZL_HIP(e, hipStreamWaitEvent(ps, q.rendered, 0));
-        ZL_HIP(e, hipMemsetAsync(q.expandCount, 0, sizeof(int32_t), ps));
         ZL_KERNEL(e, zl_launch_apply_ops(Aw, ps));
         ZL_KERNEL(e, zl_launch_plan(Aw, e->forceSlow, ps));
         ZL_KERNEL(e, zl_launch_assemble(Aw, ps));
-        ZL_KERNEL(e, zl_launch_expand(Aw, ps));
         if (overlap) {
             ZL_HIP(e, hipEventRecord(q.planned, ps));
             ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));

@@ -5,7 +5,6 @@
 
 int zl_launch_apply_ops(const ZlBatch &A, hipStream_t s);
 int zl_launch_plan(const ZlBatch &A, int force_slow, hipStream_t s);
-int zl_launch_expand(const ZlBatch &A, hipStream_t s);
 int zl_launch_assemble(const ZlBatch &A, hipStream_t s);
 int zl_launch_render(const ZlBatch &A, hipStream_t s);
 int zl_launch_finalize(const ZlBatch &A, const float *bus_in, hipStream_t s);

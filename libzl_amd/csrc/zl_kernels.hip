@@ -2,8 +2,8 @@
 //
 //   K0 zl_k0_apply_ops   device half of SamplerChannel::handleCommand (SamplerSynth.cpp:187-230)
 //   K1 zl_k1_plan        per-voice control plan of SamplerSynthVoice::process (:174-270), zl_plan.h
-//   K1c zl_k1c_assemble  segment streams -> per-block plan records (lane-parallel)
-//   K1b zl_k1b_expand    blocks with more than two segments -> per-frame control (lane-parallel)
+//   K1c zl_k1c_assemble  segment streams -> per-block plan records, multi-segment blocks -> per-frame control
+//                        (lane-parallel)
 //   K2 zl_k2_render      gather + interpolate + gain/ADSR/pan + voice->bus sum (:198-221,
 //                        SamplerSynth.cpp:134-140); HBM-bound, no MFMA (about 22 flop per 8 bytes)
 //   K3 zl_k3_finalize    ordered sum of mix-group partials + AudioLevels block scan
@@ -68,35 +68,34 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
 }
 
 // K1c: segment streams -> per-block plan records.  One lane per voice (coalesced 16-byte plan stores across the
-// wave), ZL_K1C_BLOCKS consecutive blocks per lane (one binary search, then a forward walk).
+// wave), ZL_K1C_BLOCKS consecutive blocks per wave (one binary search per lane, then a forward walk).  Blocks with
+// more than two position segments (the block after a loop restart at a small position crosses ~log2(N) binades)
+// are expanded into per-frame control by the whole wave, lanes over frames, so that K2 keeps one pipelined path.
 #define ZL_K1C_BLOCKS 16
 __global__ void __launch_bounds__(64) zl_k1c_assemble(const ZlBatch A)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= A.V) return;
+    const int lane = threadIdx.x;
+    const bool mine = v < A.V;
     const int kbeg = blockIdx.y * ZL_K1C_BLOCKS;
     const int kend = kbeg + ZL_K1C_BLOCKS < A.K ? kbeg + ZL_K1C_BLOCKS : A.K;
-    zl_assemble_blocks(A, v, kbeg, kend);
-}
-
-// K1b: blocks with more than two position segments (the block after a loop restart at a small position crosses
-// ~log2(N) binades) are expanded, lane-parallel, into per-frame control so that K2 keeps a single pipelined code
-// path.  One workgroup per queued block, grid-stride over the queue.
-__global__ void __launch_bounds__(256) zl_k1b_expand(const ZlBatch A)
-{
-    const int n = *A.expand_count;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const ZlExpand e = A.expand_list[i];
-        const size_t pidx = (size_t)e.k * A.V + e.v;
-        const ZlPlanHdr h = A.plan_hdr[pidx];
-        const int nts = A.runs[e.v].nts;
-        for (int f = threadIdx.x; f < A.N; f += blockDim.x) {
-            A.ctl_P[pidx * (size_t)A.N + f] = zl_expand_frame(A, e, nts, f < h.n_active ? f : 0);
-            A.ctl_env[pidx * (size_t)A.N + f] = h.env;
+    ZlAssembler as;
+    as.begin(A, mine ? v : 0, kbeg, mine ? kend : kbeg);
+    for (int k = kbeg; k < kend; ++k) {
+        int j0 = 0, n_active = 0;
+        const int nseg = as.block(A, k, j0, n_active);
+        unsigned long long m = __ballot(nseg > 2);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int vv = __shfl(v, l, 64), jj = __shfl(j0, l, 64), na = __shfl(n_active, l, 64), nts = __shfl(as.rl.nts, l, 64);
+            const float env = __shfl(as.env, l, 64);
+            const size_t base = ((size_t)k * A.V + vv) * (size_t)A.N;
+            for (int f = lane; f < A.N; f += 64) {
+                A.ctl_P[base + f] = zl_expand_frame(A, vv, k, jj, nts, f < na ? f : 0);
+                A.ctl_env[base + f] = env;
+            }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) A.plan_hdr[pidx].flags = h.flags | ZL_PLAN_SLOW;
-        __syncthreads();
     }
 }
 
@@ -180,11 +179,21 @@ static __device__ __forceinline__ zl_f2 zl_mix_frame_pk(zl_f2 xm, zl_f2 x0, zl_f
     return pan * mSignal + (zl_f2){sSignal, -sSignal};           // :210-211
 }
 
+// ZL_K2_PK_LINEAR / ZL_K2_PK_HERMITE: evaluate the simple chunks with the packed float2 arithmetic above (1) or with
+// the scalar zl_mix_frame (0).  Same results bit for bit; the choice is a measured one.
+#ifndef ZL_K2_PK_LINEAR
+#define ZL_K2_PK_LINEAR 0
+#endif
+#ifndef ZL_K2_PK_HERMITE
+#define ZL_K2_PK_HERMITE 1
+#endif
+
 template <uint32_t MODE, bool SEG2, int U>
 static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
-                                                           int c0, int vfirst, int f, double fd, bool wantPeak, zl_f2 &acc)
+                                                           int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
 {
     constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
+    constexpr bool PK = HERM ? (ZL_K2_PK_HERMITE != 0) : (ZL_K2_PK_LINEAR != 0);
     zl_f4a4 d[U], e[HERM ? U : 1];
     float alpha[U];
     int   inbm = 0, widem = 0;
@@ -218,31 +227,51 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
         }
         inbm |= inb ? (1 << u) : 0;
     }
+    zl_f2 acc = {accL, accR};
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
-        zl_f2 xm, x0, x1, x2;
         const bool wide = (widem >> u) & 1;
-        if (HERM) {
-            xm = (zl_f2){d[u].x, d[u].y};
-            x0 = wide ? (zl_f2){d[u].z, d[u].w} : (zl_f2){d[u].x, d[u].y};
-            x1 = wide ? (zl_f2){e[u].x, e[u].y} : (zl_f2){d[u].z, d[u].w};
-            x2 = (zl_f2){e[u].z, e[u].w};
+        float l, r;
+        if (PK) {
+            zl_f2 xm, x0, x1, x2;
+            if (HERM) {
+                xm = (zl_f2){d[u].x, d[u].y};
+                x0 = wide ? (zl_f2){d[u].z, d[u].w} : (zl_f2){d[u].x, d[u].y};
+                x1 = wide ? (zl_f2){e[u].x, e[u].y} : (zl_f2){d[u].z, d[u].w};
+                x2 = (zl_f2){e[u].z, e[u].w};
+            } else {
+                x0 = (zl_f2){d[u].x, d[u].y}; x1 = (zl_f2){d[u].z, d[u].w};
+                xm = x0; x2 = x1;
+            }
+            const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, alpha[u], (inbm >> u) & 1, wide,
+                                                  (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
+                                                  (zl_f2){s_vc[i].lpan, s_vc[i].rpan});
+            acc += o;                                             // :218-221 (index shift applied at the store)
+            l = o.x; r = o.y;
         } else {
-            x0 = (zl_f2){d[u].x, d[u].y}; x1 = (zl_f2){d[u].z, d[u].w};
-            xm = x0; x2 = x1;
+            ZlTaps t;
+            if (HERM) {
+                t.xml = d[u].x; t.xmr = d[u].y;
+                t.x0l = wide ? d[u].z : d[u].x; t.x0r = wide ? d[u].w : d[u].y;
+                t.x1l = wide ? e[u].x : d[u].z; t.x1r = wide ? e[u].y : d[u].w;
+                t.x2l = e[u].z; t.x2r = e[u].w;
+            } else {
+                t.x0l = d[u].x; t.x0r = d[u].y; t.x1l = d[u].z; t.x1r = d[u].w;
+                t.xml = t.xmr = t.x2l = t.x2r = 0.0f;
+            }
+            zl_mix_frame<MODE>(t, alpha[u], (inbm >> u) & 1, wide, true, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env,
+                               s_vc[i].clip_volume, s_vc[i].lpan, s_vc[i].rpan, l, r);
+            accL += l; accR += r;                                 // :218-221 (index shift applied at the store)
         }
-        const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, alpha[u], (inbm >> u) & 1, wide,
-                                              (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
-                                              (zl_f2){s_vc[i].lpan, s_vc[i].rpan});
-        acc += o;                                                 // :218-221 (index shift applied at the store)
         if (wantPeak) {                                           // :213-216, signed peak from 0 (Q6)
-            const float ng = o.x + o.y;
+            const float ng = l + r;
             float pk = ng > 0.0f ? ng : 0.0f;
             pk = zl_wave_max(pk);
             if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[vfirst + i].peak_bits, __float_as_uint(pk));
         }
     }
+    if (PK) { accL = acc.x; accR = acc.y; }
 }
 
 template <uint32_t MODE, bool CTL, int U>
@@ -395,12 +424,9 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
 #ifdef ZL_STAMPS
             zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
 #endif
-            if (cc & 4) {
-                zl_f2 acc = {accL, accR};
-                if ((cc & 12) == 4) zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, acc);
-                else                zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, acc);
-                accL = acc.x; accR = acc.y;
-            } else {
+            if ((cc & 12) == 4)  zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else if (cc & 4) zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else {
                 // general chunks (events, second segments, mono sources, per-frame control) are rare: run them as
                 // two half-chunks so their extra per-voice registers do not set the kernel's register budget
                 constexpr int H = U / 2;
@@ -602,13 +628,6 @@ int zl_launch_apply_ops(const ZlBatch &A, hipStream_t s)
 int zl_launch_plan(const ZlBatch &A, int force_slow, hipStream_t s)
 {
     hipLaunchKernelGGL(zl_k1_plan, dim3((A.V + 63) / 64), dim3(64), 0, s, A, force_slow);
-    ZL_LAUNCH_CHECK();
-    return 0;
-}
-
-int zl_launch_expand(const ZlBatch &A, hipStream_t s)
-{
-    hipLaunchKernelGGL(zl_k1b_expand, dim3(512), dim3(A.N < 256 ? A.N : 256), 0, s, A);
     ZL_LAUNCH_CHECK();
     return 0;
 }

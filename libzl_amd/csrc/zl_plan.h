@@ -10,8 +10,8 @@
 // with one real fp64 addition) and the loop / stop events of :225-257.
 //
 //   K1  (one lane per voice, sequential):   ZlPlanner -- one iteration per linear run, no per-block work
-//   K1c (one lane per voice x block chunk): zl_assemble_blocks -- segment stream -> per-block plan records
-//   K1b (one lane per frame):               zl_expand_frame -- blocks with > 2 segments -> per-frame control
+//   K1c (one lane per voice x block chunk): ZlAssembler -- segment stream -> per-block plan records; blocks with
+//                                           more than two segments -> per-frame control, the wave's lanes over frames
 //
 // Blocks whose envelope is not in steady sustain (attack, decay, release tail of quirk Q7, note-off)
 // are simulated per frame by zl_sim_block(), which records (P, env) per frame for K2.
@@ -312,7 +312,7 @@ ZL_HD inline int zl_block_of(int t, int N, double invN)
 // The planner is a flat state machine over window time t: one iterate() call = at most one new linear run
 // (zl_linear_run + the search for the loop / stop event inside it), emitted as ONE segment whatever number of
 // blocks it spans.  All lanes of a wavefront execute the same straight-line code per iteration whatever their
-// positions in the window are; everything per block is left to K1c / K1b, which are lane-parallel.
+// positions in the window are; everything per block is left to K1c, which is lane-parallel.
 struct ZlPlanner {
     ZlVoiceState st;
     ZlVoiceBatchConst c;
@@ -584,66 +584,73 @@ ZL_HD inline ZlBlockPlan zl_plan_lookup(const ZlBatch &A, int k, int v, float ru
     return zl_plan_load(A, (size_t)k * A.V + v);
 }
 
-// K1c body: the explicit plan records of blocks [kbeg, kend) of voice v from its segment stream.  Blocks inside
-// an inline run, simulated blocks (K1 wrote their records) and idle blocks are left alone.
-ZL_HD inline void zl_assemble_blocks(const ZlBatch &A, int v, int kbeg, int kend)
-{
-    const ZlRunList rl = A.runs[v];
-    const int N = A.N;
-    if (kend > rl.dead_from) kend = rl.dead_from;
-    if (kbeg >= kend || rl.nts <= 0) return;
-    const ZlTSeg *ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
-    const int nts = rl.nts;
-    // last segment that starts at or before the first frame of block kbeg
-    int lo = 0, hi = nts;
-    const int T0 = kbeg * N;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid].t <= T0) lo = mid + 1; else hi = mid; }
-    int j = lo - 1;
-    if (j < 0) return;                                            // cannot happen: the stream starts at t = 0
-    const float env = A.vconst[v].env;
-    for (int k = kbeg; k < kend; ++k) {
+// K1c body: the explicit plan record of one block of voice v from its segment stream.  Blocks inside an inline run,
+// simulated blocks (K1 wrote their records) and idle blocks are left alone.  begin() positions the walker on block
+// kbeg; block() must then be called for k = kbeg, kbeg + 1, ...
+struct ZlAssembler {
+    ZlRunList rl;
+    const ZlTSeg *ts;
+    int v, j, kend;
+    float env;
+
+    ZL_HD void begin(const ZlBatch &A, int voice, int kbeg, int kend_)
+    {
+        v = voice;
+        rl = A.runs[v];
+        ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
+        kend = kend_ < rl.dead_from ? kend_ : rl.dead_from;
+        env = A.vconst[v].env;
+        j = -1;
+        if (kbeg >= kend || rl.nts <= 0) { kend = kbeg; return; }
+        // last segment that starts at or before the first frame of block kbeg
+        int lo = 0, hi = rl.nts;
+        const int T0 = kbeg * A.N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid].t <= T0) lo = mid + 1; else hi = mid; }
+        j = lo - 1;
+        if (j < 0) kend = kbeg;                                   // cannot happen: the stream starts at t = 0
+    }
+
+    // Returns the number of position segments of block k (0: nothing to write).  A block with more than two is marked
+    // ZL_PLAN_SLOW and the caller fills its per-frame control with zl_expand_frame(j0, ...) for frames < n_active.
+    ZL_HD int block(const ZlBatch &A, int k, int &j0, int &n_active)
+    {
+        if (k >= kend) return 0;
+        const int N = A.N, nts = rl.nts;
         const int T = k * N;
         while (j + 1 < nts && ts[j + 1].t <= T) ++j;
         const ZlTSeg a = ts[j];
-        if (a.flags & ZL_TSEG_SLOW) continue;
+        if (a.flags & ZL_TSEG_SLOW) return 0;
         bool inrun = false;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
         for (int q = 0; q < ZL_MAXRUNS; ++q) inrun = inrun || (q < rl.n && k >= rl.r[q].k0 && k < rl.r[q].k1);
-        if (inrun) continue;
-        const int n_active = (rl.t_end - T < N) ? rl.t_end - T : N;
+        if (inrun) return 0;
+        n_active = (rl.t_end - T < N) ? rl.t_end - T : N;
         int nseg = 1;
         while (nseg < 3 && j + nseg < nts && ts[j + nseg].t < T + n_active) ++nseg;
         const size_t pidx = (size_t)k * A.V + v;
-        ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE; h.n_active = n_active; h.nseg = nseg; h.env = env;
+        ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE | (nseg > 2 ? ZL_PLAN_SLOW : 0); h.n_active = n_active; h.nseg = nseg; h.env = env;
         ZlPlanSeg0 s0; s0.P0 = fma((double)(T - a.t), a.step, a.P); s0.step = a.step;      // exact: on the segment's line
         A.plan_hdr[pidx] = h;
         A.plan_seg0[pidx] = s0;
-        if (nseg >= 2) {
+        if (nseg == 2) {
             const ZlTSeg b = ts[j + 1];
             ZlPlanSeg1 s1; s1.P1 = b.P; s1.step1 = b.step; s1.n1 = b.t - T; s1.pad = 0; s1.pad2 = 0.0;
             A.plan_seg1[pidx] = s1;
         }
-        if (nseg > 2 && A.expand_list) {
-            // K2 evaluates at most two segments per block: K1b turns this block's segments into per-frame control
-#if defined(__HIP_DEVICE_COMPILE__)
-            const int slot = atomicAdd(A.expand_count, 1);
-#else
-            const int slot = (*A.expand_count)++;
-#endif
-            ZlExpand e; e.k = k; e.v = v; e.j0 = j; e.pad = 0;
-            A.expand_list[slot] = e;
-        }
+        j0 = j;
+        return nseg;
     }
-}
+};
 
-// K1b body for one frame of one queued block: the position of frame f (< n_active) from the voice's segments.
-ZL_HD inline double zl_expand_frame(const ZlBatch &A, const ZlExpand &e, int nts, int f)
+// Per-frame control of a block with more than two segments: the position of frame f (< n_active) of block k of
+// voice v; j0 = the segment that covers the block's first frame, nts = the voice's segment count.
+ZL_HD inline double zl_expand_frame(const ZlBatch &A, int v, int k, int j0, int nts, int f)
 {
-    const ZlTSeg *ts = A.tsegs + (size_t)e.v * ZL_MAXTSEG;
-    const int T = e.k * A.N + f;
-    int lo = e.j0 + 1, hi = nts;                                  // last segment with t <= T (segment j0 qualifies)
+    const ZlTSeg *ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
+    const int T = k * A.N + f;
+    int lo = j0 + 1, hi = nts;                                    // last segment with t <= T (segment j0 qualifies)
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid].t <= T) lo = mid + 1; else hi = mid; }
     const ZlTSeg a = ts[lo - 1];
     return fma((double)(T - a.t), a.step, a.P);                   // exact

@@ -119,7 +119,7 @@ struct ZlPlanSeg1 { double P1, step1; int32_t n1, pad; double pad2; };
 struct ZlBlockPlan {              // per (block, voice); 64 bytes, the first two linear segments inline
     int32_t flags;
     int32_t n_active;             // frames rendered in this block (N unless the voice stopped inside it)
-    int32_t nseg;                 // 1 or 2 for fast blocks (blocks with more are expanded to per-frame control by K1b)
+    int32_t nseg;                 // 1 or 2 for fast blocks (blocks with more are expanded to per-frame control by K1c)
     float   env;                  // envelope value of every frame of a fast block (sustain)
     double  P0;                   // position of frame 0
     double  step;                 // exact per-frame increment inside the first segment
@@ -129,8 +129,6 @@ struct ZlBlockPlan {              // per (block, voice); 64 bytes, the first two
     double  step1;
     double  pad2;
 };
-struct ZlExpand { int32_t k, v, j0, pad; };   // a block with more than two segments, queued by K1c for K1b (j0 = its first segment)
-
 struct ZlReport {                 // device side of zlhip_voice_report
     int32_t playing, valid;
     uint32_t peak_bits;           // max over the last block of (l'+r'), as float bits (>= 0)
@@ -187,6 +185,4 @@ struct ZlBatch {
     ZlBlockLevels      *levels;   // [K][B]
     int32_t            *pos_trace;// [K][V][N] or null
     ZlBatchStats       *stats;
-    ZlExpand           *expand_list;  // [K*V] blocks whose segments K1b expands into per-frame control
-    int32_t            *expand_count; // [1]
 };

@@ -169,25 +169,26 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
         for (int j = 0; j < rg.count; ++j) zl_apply_op(st, ops[(size_t)(rg.first + j)]);
         S->voices[(size_t)rg.voice] = st;
     }
-    std::vector<ZlExpand> expandList((size_t)K * V); int32_t expandCount = 0;
-    A.expand_list = expandList.data(); A.expand_count = &expandCount;
     S->stats = ZlPlanStats{0, 0, 0};
     for (int v = 0; v < S->V; ++v) {                              // K1
         ZlPlanStats st;
         zl_plan_voice(A, v, force_slow, st);
         S->stats.source_bytes += st.source_bytes; S->stats.slow_blocks += st.slow_blocks; S->stats.active_frames += st.active_frames;
     }
-    for (int v = 0; v < S->V; ++v) zl_assemble_blocks(A, v, 0, K);          // K1c
-    S->expanded = expandCount;
-    for (int i = 0; i < expandCount; ++i) {                       // K1b
-        const ZlExpand e = expandList[(size_t)i];
-        const size_t pidx = (size_t)e.k * V + (size_t)e.v;
-        const ZlPlanHdr h = S->planHdr[pidx];
-        for (int f = 0; f < N; ++f) {
-            S->ctlP[pidx * (size_t)N + f] = zl_expand_frame(A, e, S->runs[(size_t)e.v].nts, f < h.n_active ? f : 0);
-            S->ctlEnv[pidx * (size_t)N + f] = h.env;
+    S->expanded = 0;
+    for (int v = 0; v < S->V; ++v) {                              // K1c
+        ZlAssembler as;
+        as.begin(A, v, 0, K);
+        for (int k = 0; k < K; ++k) {
+            int j0 = 0, n_active = 0;
+            if (as.block(A, k, j0, n_active) <= 2) continue;
+            ++S->expanded;
+            const size_t pidx = (size_t)k * V + (size_t)v;
+            for (int f = 0; f < N; ++f) {
+                S->ctlP[pidx * (size_t)N + f] = zl_expand_frame(A, v, k, j0, as.rl.nts, f < n_active ? f : 0);
+                S->ctlEnv[pidx * (size_t)N + f] = as.env;
+            }
         }
-        S->planHdr[pidx].flags |= ZL_PLAN_SLOW;
     }
     switch (S->mode & 7u) {                                       // K2 + K3
 #define C(M) case M: render_all<M>(*S, A, bus); break;

@@ -110,8 +110,13 @@ def cpu_baseline(args, seed):
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds:
             break
+    # the same oracle on one thread (a short sample): the reference renders a channel's voices on one RT thread
+    t1 = time.perf_counter()
+    osyn.render_batch(8, args.frames, clocks, threads=1, want_reports=False)
+    single = V * 8 * args.frames / (time.perf_counter() - t1)
     return {
         "value": V * done * args.frames / dt, "unit": "voice-samples/s", "cores": threads, "kind": "port",
+        "single_thread_value": single,
         "sample": f"{V} stereo voices (128 buses x 8, the reference's voices per channel) x {done} blocks x {args.frames} frames, "
                   f"0.5 s loops, ratio 1, faithful mode, oracle/zl_oracle.c built -O3 -march=native, {threads} threads "
                   f"(buses partitioned, one thread per JACK client as in the reference), {dt:.1f} s wall; {cores} host cores visible",
@@ -177,7 +182,7 @@ def main():
                        sound_arena_bytes=arena, voices_per_task=args.voices_per_task, plan_window_blocks=args.plan_window, device=local_rank)
     seed = 0x5A17 + 2 + 1000 * rank
     build_scene(syn, torch, dev, vpb, B, args.fs, loop_frames, seed, notes=notes, source_rate=source_rate)
-    syn.set_profiling(True)
+    syn.set_profiling(not os.environ.get('ZL_BENCH_NOPROF'))      # diagnostic switch: cost of the per-launch HIP events
 
     # the engine renders into a torch-owned device buffer so the RCCL reduce needs no copy
     bus = torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32)
@@ -219,20 +224,15 @@ def main():
     for i in range(args.warmup):
         step(i, False)
     torch.cuda.synchronize()
+    syn.profile_totals(reset=True)                                   # HIP-event sums start with the timed region
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # the steps are queued back to back: consecutive zlhip_render_batch calls pipeline (the planning of step i+1
+    # overlaps the rendering of step i); the per-kernel HIP events of every step are read once, after the region
     for i in range(args.steps):
         step(args.warmup + i, True)
-        if True:
-            # per-kernel HIP-event timings of this step (events were recorded on the launch stream);
-            # reading them waits for the step, which render_batch would do anyway before reusing its staging
-            t = syn.last_timings()
-            render_ms.append(t.render_ms); plan_ms.append(t.plan_ms); fin_ms.append(t.finalize_ms)
-            src_bytes = t.source_bytes
-            slow = t.slow_blocks
-            launches = max(1, t.render_launches)
     if overlapped is not None:
         overlapped.flush(stream=sptr)                                # the last reduces + level scans are inside the timed region
     torch.cuda.synchronize()
@@ -240,10 +240,28 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tot, ncalls = syn.profile_totals()                               # sums of the HIP-event timings of the timed steps
+    ncalls = max(1, ncalls)
+    render_ms = [tot.render_ms / ncalls]; plan_ms = [tot.plan_ms / ncalls]; fin_ms = [tot.finalize_ms / ncalls]
+    src_bytes = tot.source_bytes // ncalls
+    slow = tot.slow_blocks
+    launches = max(1, tot.render_launches // ncalls)
     if distributed:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # practical ceiling of this box: a device-to-device copy (read + write bytes / time), measured after the timed region
+    copy_gbs = None
+    if rank == 0:
+        a = torch.empty(1 << 28, device=dev, dtype=torch.float32); b = torch.empty_like(a)      # 1 GiB each
+        b.copy_(a); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5): b.copy_(a)
+        e1.record(stream); torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
 
     total_vs = float(V) * world * KB * N * args.steps
     value = total_vs / dt
@@ -274,9 +292,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "zl_k2_render", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "device_copy_GBs": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                 "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_avg_ms, "launches_per_step": launches,
                 "bytes_per_voice_sample": k2_bytes_step / (V * KB * N),
-                "other_ms_per_step": {"planning_not_hidden (K0+K1+K1b of the first window)": float(np.mean(plan_ms)),
+                "other_ms_per_step": {"planning_not_hidden (K0+K1+K1c of the first window; overlaps the previous step)": float(np.mean(plan_ms)),
                                       "K3 finalize + reports + launch gaps": float(np.mean(fin_ms))},
                 "state_and_levels_bytes_per_step": state_bytes, "slow_blocks": int(slow),
                 "note": "sources are 2 s loops re-read every 375 blocks: inside a plan window part of the re-reads is served by the "

@@ -133,7 +133,7 @@ typedef struct zlhip_passthrough_params {
 
 /* profiling counters of the last zlhip_render_batch (HIP events on the engine's stream) */
 typedef struct zlhip_timings {
-    float plan_ms;        /* planning (K0+K1+K1b) not hidden behind rendering: first launch to first K2 */
+    float plan_ms;        /* planning (K0+K1+K1c) not hidden behind rendering: start of the call on its stream to first K2 */
     float render_ms;      /* gather-interp-mix kernel (K2), the dominant one: sum over the call's launches */
     float finalize_ms;    /* total - render - plan: K3 (bus reduce + levels), reports, gaps between launches */
     float total_ms;       /* first launch to last completion */
@@ -216,6 +216,10 @@ int zlhip_passthrough_process(zlhip_engine *e, const zlhip_passthrough_params *p
 /* ---- introspection / measurement ------------------------------------------------------------ */
 int zlhip_set_profiling(zlhip_engine *e, int enable);
 int zlhip_last_timings(zlhip_engine *e, zlhip_timings *out);
+/* Sums of the timings of every profiled zlhip_render_batch call since the last reset (and their number): lets a caller
+ * queue calls back to back -- consecutive calls pipeline, the planning of call i+1 overlaps the rendering of call i --
+ * and read the kernel times once at the end.  Waits for outstanding calls. */
+int zlhip_profile_totals(zlhip_engine *e, zlhip_timings *totals, int32_t *calls, int reset);
 float *zlhip_bus_device_ptr(zlhip_engine *e);                   /* internal [B][2][Kmax*Nmax] buffer */
 int zlhip_device_name(zlhip_engine *e, char *buf, size_t len);
 

@@ -126,6 +126,7 @@ SIGNATURES = {
     "zlhip_passthrough_process": (C.c_int, [_E, C.POINTER(PassthroughParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "zlhip_set_profiling": (C.c_int, [_E, C.c_int]),
     "zlhip_last_timings": (C.c_int, [_E, C.POINTER(Timings)]),
+    "zlhip_profile_totals": (C.c_int, [_E, C.POINTER(Timings), C.POINTER(C.c_int32), C.c_int]),
     "zlhip_bus_device_ptr": (C.c_void_p, [_E]),
     "zlhip_device_name": (C.c_int, [_E, C.c_char_p, C.c_size_t]),
 }

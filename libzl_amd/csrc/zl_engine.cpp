@@ -49,22 +49,38 @@ struct zlhip_engine {
         double *ctlP = nullptr; float *ctlEnv = nullptr;
         float *partials = nullptr;
         hipEvent_t planned = nullptr, rendered = nullptr;
+        bool used = false;               // `rendered` has been recorded at least once
     } ps[2];
     int window = 0;                      // blocks per plan window
     hipStream_t planStream = nullptr;
-    hipEvent_t evStart = nullptr;
-    std::vector<hipEvent_t> evK2;        // [2 * max windows] start/end of every K2 launch (profiling)
-    ZlReport *dReports = nullptr; float *dGain = nullptr;
+    std::vector<std::pair<int, int>> wins;
+    // Per-call resources, double buffered so that consecutive zlhip_render_batch calls pipeline: the host prepares
+    // (and the planning stream plans) call i+1 while call i still renders; a slot is reused by call i+2.
+    struct CallSlot {
+        ZlClock *hClocks = nullptr, *dClocks = nullptr;
+        ZlReport *hReports = nullptr, *dReports = nullptr;
+        float *hGain = nullptr;
+        ZlBatchStats *hStats = nullptr, *dStats = nullptr;
+        ZlReport *hReportsDev = nullptr; float *hGainDev = nullptr; ZlBatchStats *hStatsDev = nullptr;   // device views of the host buffers
+        hipEvent_t evBegin = nullptr, evEnd = nullptr, done = nullptr;
+        std::vector<hipEvent_t> evK2;    // [2 * max windows] start/end of every K2 launch (profiling)
+        int windows = 0;
+        bool inflight = false, profiled = false;
+    } slots[2];
+    unsigned callIndex = 0, setPhase = 0;
+    CallSlot *latest = nullptr;          // slot of the most recent call
+    zlhip_timings totals{}; int totalCalls = 0;   // sums over harvested calls (zlhip_profile_totals)
+    float *dGain = nullptr;
     float *dBus = nullptr;
     ZlBlockLevels *dLevels = nullptr; ZlLevelsState *dLevelState = nullptr;
-    ZlClock *dClocks = nullptr; ZlVoiceOp *dOps = nullptr; ZlOpRange *dOpRanges = nullptr;
-    ZlBatchStats *dStats = nullptr; int32_t *dTrace = nullptr; PassParamsDev *dPass = nullptr;
+    ZlVoiceOp *dOps = nullptr; ZlOpRange *dOpRanges = nullptr;
+    int32_t *dTrace = nullptr; PassParamsDev *dPass = nullptr;
     size_t opsCap = 0, rangesCap = 0, traceInts = 0;
     int maxGroups = 1;
 
     // pinned host staging
-    ZlClock *hClocks = nullptr; ZlReport *hReports = nullptr; float *hGain = nullptr; float *hBus = nullptr;
-    ZlLevelsState *hLevelState = nullptr; ZlBatchStats *hStats = nullptr;
+    float *hBus = nullptr;
+    ZlLevelsState *hLevelState = nullptr;
 
     // host mirrors
     ZlHostControl hc;                    // voices / sounds / clip parameters / pending ops (zl_host.h)
@@ -76,7 +92,7 @@ struct zlhip_engine {
     int forceSlow = 0;
 
     // profiling
-    bool profiling = false; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool profiling = false; hipEvent_t evJoin = nullptr;
     zlhip_timings timings{};
 };
 
@@ -145,8 +161,8 @@ void zlhip_engine_destroy(zlhip_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->planStream) (void)hipStreamSynchronize(e->planStream);
-    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dReports, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dClocks, e->dOps,
-                    e->dOpRanges, e->dStats, e->dTrace, e->dPass };
+    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dOps,
+                    e->dOpRanges, e->dTrace, e->dPass };
     for (void *p : dev) if (p) (void)hipFree(p);
     for (auto &q : e->ps) {
         void *pd[] = { q.vconst, q.runs, q.tsegs, q.hdr, q.seg0, q.seg1, q.ctlP, q.ctlEnv, q.partials };
@@ -154,12 +170,19 @@ void zlhip_engine_destroy(zlhip_engine *e)
         if (q.planned) (void)hipEventDestroy(q.planned);
         if (q.rendered) (void)hipEventDestroy(q.rendered);
     }
-    for (auto &x : e->evK2) if (x) (void)hipEventDestroy(x);
-    if (e->evStart) (void)hipEventDestroy(e->evStart);
+    for (auto &c : e->slots) {
+        void *cd[] = { c.dClocks, c.dReports, c.dStats };
+        for (void *p : cd) if (p) (void)hipFree(p);
+        void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats };
+        for (void *p : ch) if (p) (void)hipHostFree(p);
+        for (auto &x : c.evK2) if (x) (void)hipEventDestroy(x);
+        hipEvent_t evs[] = { c.evBegin, c.evEnd, c.done };
+        for (hipEvent_t x : evs) if (x) (void)hipEventDestroy(x);
+    }
     if (e->planStream) (void)hipStreamDestroy(e->planStream);
-    void *host[] = { e->hClocks, e->hReports, e->hGain, e->hBus, e->hLevelState, e->hStats };
+    void *host[] = { e->hBus, e->hLevelState };
     for (void *p : host) if (p) (void)hipHostFree(p);
-    for (auto &x : e->ev) if (x) (void)hipEventDestroy(x);
+    if (e->evJoin) (void)hipEventDestroy(e->evJoin);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -210,7 +233,6 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             chk(hipStreamCreateWithPriority(&e->planStream, hipStreamNonBlocking, hi), "plan stream");
         }
-        chk(hipEventCreateWithFlags(&e->evStart, hipEventDisableTiming), "event");
         const int nsets = (cfg->max_batch_blocks > w) ? 2 : 1;
         for (int i = 0; i < 2; ++i) {
             zlhip_engine::PlanSet &q = e->ps[i];
@@ -228,30 +250,41 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             chk(dalloc(&q.partials, e->maxGroups > 1 ? W * B * (size_t)e->maxGroups * 2 * N : 1), "partials");
         }
         const size_t nwin = (K + W - 1) / W + 16;                 // + the doubling windows at the start of a call
-        e->evK2.assign(2 * nwin, nullptr);
-        for (auto &x : e->evK2) chk(hipEventCreate(&x), "hipEventCreate");
+        e->wins.reserve(nwin);
+        for (auto &c : e->slots) {
+            c.evK2.assign(2 * nwin, nullptr);
+            for (auto &x : c.evK2) chk(hipEventCreate(&x), "hipEventCreate");
+            chk(hipEventCreate(&c.evBegin), "hipEventCreate");
+            chk(hipEventCreate(&c.evEnd), "hipEventCreate");
+            chk(hipEventCreateWithFlags(&c.done, hipEventDisableTiming), "hipEventCreate");
+            chk(dalloc(&c.dClocks, K), "clocks");
+            chk(dalloc(&c.dReports, V), "reports");
+            chk(dalloc(&c.dStats, 1), "stats");
+            chk(hipHostMalloc((void **)&c.hClocks, K * sizeof(ZlClock)), "hClocks");
+            chk(hipHostMalloc((void **)&c.hReports, V * sizeof(ZlReport)), "hReports");
+            chk(hipHostMalloc((void **)&c.hGain, V * sizeof(float)), "hGain");
+            chk(hipHostMalloc((void **)&c.hStats, sizeof(ZlBatchStats)), "hStats");
+            if (rc == ZLHIP_OK) {
+                chk(hipHostGetDevicePointer((void **)&c.hReportsDev, c.hReports, 0), "map hReports");
+                chk(hipHostGetDevicePointer((void **)&c.hGainDev, c.hGain, 0), "map hGain");
+                chk(hipHostGetDevicePointer((void **)&c.hStatsDev, c.hStats, 0), "map hStats");
+            }
+        }
     }
-    chk(dalloc(&e->dReports, V), "reports");
     chk(dalloc(&e->dGain, V), "gain");
     chk(dalloc(&e->dBus, B * 2 * K * N), "bus");
     chk(dalloc(&e->dLevels, K * B), "levels");
     chk(dalloc(&e->dLevelState, B), "levelState");
-    chk(dalloc(&e->dClocks, K), "clocks");
-    chk(dalloc(&e->dStats, 1), "stats");
     chk(dalloc(&e->dPass, B), "passthrough params");
-    chk(hipHostMalloc((void **)&e->hClocks, K * sizeof(ZlClock)), "hClocks");
-    chk(hipHostMalloc((void **)&e->hReports, V * sizeof(ZlReport)), "hReports");
-    chk(hipHostMalloc((void **)&e->hGain, V * sizeof(float)), "hGain");
     chk(hipHostMalloc((void **)&e->hBus, B * 2 * N * sizeof(float)), "hBus");
     chk(hipHostMalloc((void **)&e->hLevelState, B * sizeof(ZlLevelsState)), "hLevelState");
-    chk(hipHostMalloc((void **)&e->hStats, sizeof(ZlBatchStats)), "hStats");
-    for (auto &x : e->ev) chk(hipEventCreate(&x), "hipEventCreate");
+    chk(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming), "hipEventCreate");
     if (rc == ZLHIP_OK) {
         chk(hipMemsetAsync(e->dSounds, 0, (size_t)cfg->max_sounds * sizeof(ZlSound), e->stream), "memset sounds");
         chk(hipMemsetAsync(e->dClips, 0, (size_t)cfg->max_sounds * sizeof(ZlClip), e->stream), "memset clips");
         chk(hipMemsetAsync(e->dVoices, 0, V * sizeof(ZlVoiceState), e->stream), "memset voices");
         chk(hipMemsetAsync(e->dLevelState, 0, B * sizeof(ZlLevelsState), e->stream), "memset levels");
-        chk(hipMemsetAsync(e->dReports, 0, V * sizeof(ZlReport), e->stream), "memset reports");
+        for (auto &c : e->slots) chk(hipMemsetAsync(c.dReports, 0, V * sizeof(ZlReport), e->stream), "memset reports");
         chk(hipMemsetAsync(e->dBus, 0, B * 2 * K * N * sizeof(float), e->stream), "memset bus");
         chk(hipStreamSynchronize(e->stream), "sync");
     }
@@ -261,7 +294,8 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         return rc;
     }
     e->hc.init(cfg->num_buses, cfg->voices_per_bus, cfg->max_sounds, cfg->playback_sample_rate);
-    std::memset(e->hReports, 0, V * sizeof(ZlReport));
+    for (auto &c : e->slots) { std::memset(c.hReports, 0, V * sizeof(ZlReport)); std::memset(c.hStats, 0, sizeof(ZlBatchStats)); }
+    e->latest = &e->slots[0];
     *out = e;
     return ZLHIP_OK;
 }
@@ -374,7 +408,7 @@ static int refresh_host_voices(zlhip_engine *e)
         e->outstanding = false;
     }
     if (e->reportsFresh) {
-        e->hc.absorb_reports(e->hReports);
+        e->hc.absorb_reports(e->latest->hReports);
         e->reportsFresh = false;
     }
     return ZLHIP_OK;
@@ -430,6 +464,35 @@ static int upload_ops(zlhip_engine *e, ZlBatch &A, hipStream_t s)
     return ZLHIP_OK;
 }
 
+// HIP-event timings of a finished call -> e->timings (the last call) and e->totals (sums)
+static int harvest_slot(zlhip_engine *e, zlhip_engine::CallSlot &c)
+{
+    if (!c.profiled) return ZLHIP_OK;
+    c.profiled = false;
+    zlhip_timings t; std::memset(&t, 0, sizeof t);
+    ZL_HIP(e, hipEventSynchronize(c.evEnd));
+    ZL_HIP(e, hipEventElapsedTime(&t.total_ms, c.evBegin, c.evEnd));
+    float k2 = 0.0f;
+    for (int w = 0; w < c.windows; ++w) {
+        float x = 0.0f;
+        ZL_HIP(e, hipEventElapsedTime(&x, c.evK2[2 * (size_t)w], c.evK2[2 * (size_t)w + 1]));
+        k2 += x;
+    }
+    t.render_ms = k2;                                              // sum over the K2 launches of the call
+    float first = 0.0f;
+    ZL_HIP(e, hipEventElapsedTime(&first, c.evBegin, c.evK2[0]));
+    t.plan_ms = first;                                             // planning that is NOT hidden behind rendering
+    t.finalize_ms = t.total_ms - k2 - first;                       // K3 + reports + gaps between launches
+    t.render_launches = c.windows;
+    t.source_bytes = c.hStats->source_bytes; t.slow_blocks = c.hStats->slow_blocks; t.active_voice_frames = c.hStats->active_frames;
+    e->timings = t;
+    e->totals.plan_ms += t.plan_ms; e->totals.render_ms += t.render_ms; e->totals.finalize_ms += t.finalize_ms; e->totals.total_ms += t.total_ms;
+    e->totals.render_launches += t.render_launches; e->totals.source_bytes += t.source_bytes; e->totals.slow_blocks += t.slow_blocks;
+    e->totals.active_voice_frames += t.active_voice_frames;
+    e->totalCalls += 1;
+    return ZLHIP_OK;
+}
+
 int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks, float *bus_out_dev, void *stream)
 {
     if (!e || !clocks) return ZLHIP_ERR_INVALID;
@@ -437,14 +500,17 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     if (nframes < 64 || nframes > e->cfg.max_frames || (nframes % 64) != 0 || (nframes > 256 && (nframes % 256) != 0))
         return fail(e, ZLHIP_ERR_INVALID, "nframes must be a multiple of 64 (of 256 above 256) and <= max_frames");
     ZL_HIP(e, hipSetDevice(e->device));
-    int rc = refresh_host_voices(e);                               // also waits for the previous batch: staging buffers are reused
-    if (rc != ZLHIP_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
 
-    for (int k = 0; k < nblocks; ++k) {
-        ZlHostControl::fill_clock(e->hClocks[k], clocks[k], nframes);
+    // this call's slot: wait for the call that used it two calls ago (the previous call may still be rendering)
+    zlhip_engine::CallSlot &c = e->slots[e->callIndex & 1u];
+    if (c.inflight) {
+        ZL_HIP(e, hipEventSynchronize(c.done));
+        c.inflight = false;
+        int hrc = harvest_slot(e, c);
+        if (hrc != ZLHIP_OK) return hrc;
     }
-    ZL_HIP(e, hipMemcpyAsync(e->dClocks, e->hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, s));
+    for (int k = 0; k < nblocks; ++k) ZlHostControl::fill_clock(c.hClocks[k], clocks[k], nframes);
 
     ZlBatch A; std::memset(&A, 0, sizeof A);
     A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.N = nframes; A.Ktot = nblocks;
@@ -452,8 +518,8 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     A.groups = (A.VPB + A.G - 1) / A.G;
     A.mode = e->cfg.mode;
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
-    A.voices = e->dVoices; A.reports = e->dReports;
-    A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.stats = e->dStats;
+    A.voices = e->dVoices; A.reports = c.dReports;
+    A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.stats = c.dStats;
     A.trace = 0; A.pos_trace = nullptr;
     int32_t *traceBase = nullptr;
     if (e->trace) {
@@ -469,17 +535,19 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         A.trace = 0;       // diagnostic build: the trace buffer receives per-workgroup timestamps instead
 #endif
     }
-    rc = upload_ops(e, A, s);
-    if (rc != ZLHIP_OK) return rc;
-    ZL_HIP(e, hipMemsetAsync(e->dStats, 0, sizeof(ZlBatchStats), s));
 
-    // ---- plan windows: K0/K1/K1b of window i+1 run on the planning stream while K2/K3 of window i render ----
+    // ---- plan windows: K0/K1/K1c of window i+1 run on the planning stream while K2/K3 of window i render ----
     // Window layout: large windows keep K2 launches long (their ramp-up and drain are a fixed cost per launch), but
     // planning window i+1 must fit behind rendering window i, and the planning of the first window is hidden by
-    // nothing: windows start at 256 blocks and double up to the configured size.
+    // nothing but the previous call: windows start at 256 blocks and double up to the configured size.
     const int W = e->window;
-    std::vector<std::pair<int, int>> wins;                         // (first block, blocks)
-    if (nblocks <= W || e->ps[1].hdr == nullptr) {
+    std::vector<std::pair<int, int>> &wins = e->wins;              // (first block, blocks); member: no allocation per call
+    wins.clear();
+    // when the previous call is still in flight its rendering hides the planning of this call's first window: no
+    // need to start small (fewer, longer K2 launches)
+    zlhip_engine::CallSlot &prev = e->slots[(e->callIndex + 1u) & 1u];
+    const bool behindPrev = prev.inflight && hipEventQuery(prev.done) == hipErrorNotReady;
+    if (nblocks <= W || e->ps[1].hdr == nullptr || behindPrev) {
         for (int k0 = 0; k0 < nblocks; k0 += W) wins.push_back({k0, std::min(W, nblocks - k0)});
     } else {
         int size = std::min(W, 256);
@@ -491,52 +559,60 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         }
     }
     const int nwin = (int)wins.size();
-    const bool overlap = nwin > 1 && e->ps[1].hdr != nullptr;
+    const bool overlap = e->ps[1].hdr != nullptr && (nwin > 1 || behindPrev);
     hipStream_t ps = overlap ? e->planStream : s;
-    if (overlap) {
-        ZL_HIP(e, hipEventRecord(e->evStart, s));                  // clocks / ops / memsets above
-        ZL_HIP(e, hipStreamWaitEvent(ps, e->evStart, 0));
-    }
-    if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[0], s));
+    // The call's inputs (clocks, voice operations, cleared statistics) go to the planning stream itself: it is in order
+    // with the planning of the previous call, so window 0 of this call is planned while the previous call still renders.
+    ZL_HIP(e, hipMemcpyAsync(c.dClocks, c.hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, ps));
+    int rc = upload_ops(e, A, ps);
+    if (rc != ZLHIP_OK) return rc;
+    ZL_HIP(e, hipMemsetAsync(c.dStats, 0, sizeof(ZlBatchStats), ps));
+    if (e->profiling) ZL_HIP(e, hipEventRecord(c.evBegin, s));
+    // the record sets alternate across calls too, so that the first window of this call is not planned into the set
+    // the previous call's last window still renders from
+    const unsigned phase = e->ps[1].hdr != nullptr ? e->setPhase : 0u;
     for (int w = 0; w < nwin; ++w) {
-        zlhip_engine::PlanSet &q = e->ps[overlap ? (w & 1) : 0];
+        zlhip_engine::PlanSet &q = e->ps[(phase + (unsigned)w) & 1u];
         ZlBatch Aw = A;
         Aw.k0 = wins[(size_t)w].first;
         Aw.K = wins[(size_t)w].second;
-        Aw.clocks = e->dClocks + Aw.k0;
+        Aw.clocks = c.dClocks + Aw.k0;
         Aw.levels = e->dLevels + (size_t)Aw.k0 * A.B;
         Aw.pos_trace = traceBase ? traceBase + (size_t)Aw.k0 * e->V * nframes : nullptr;
         Aw.vconst = q.vconst; Aw.runs = q.runs; Aw.tsegs = q.tsegs; Aw.plan_hdr = q.hdr; Aw.plan_seg0 = q.seg0; Aw.plan_seg1 = q.seg1;
         Aw.ctl_P = q.ctlP; Aw.ctl_env = q.ctlEnv; Aw.partials = q.partials;
         if (w > 0) { Aw.n_op_ranges = 0; Aw.ops = nullptr; Aw.op_ranges = nullptr; }     // commands apply before the first block only
-        // planning of window w may not overwrite the set while window w-2 is still being rendered from it
-        if (overlap && w >= 2) ZL_HIP(e, hipStreamWaitEvent(ps, q.rendered, 0));
+        // planning may not overwrite a record set while an earlier window (of this or the previous call) still renders from it
+        if (ps != s && q.used) ZL_HIP(e, hipStreamWaitEvent(ps, q.rendered, 0));
         ZL_KERNEL(e, zl_launch_apply_ops(Aw, ps));
         ZL_KERNEL(e, zl_launch_plan(Aw, e->forceSlow, ps));
         ZL_KERNEL(e, zl_launch_assemble(Aw, ps));
-        if (overlap) {
+        if (ps != s) {
             ZL_HIP(e, hipEventRecord(q.planned, ps));
             ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
         }
-        if (e->profiling) ZL_HIP(e, hipEventRecord(e->evK2[2 * (size_t)w], s));
+        if (e->profiling) ZL_HIP(e, hipEventRecord(c.evK2[2 * (size_t)w], s));
         ZL_KERNEL(e, zl_launch_render(Aw, s));
-        if (e->profiling) ZL_HIP(e, hipEventRecord(e->evK2[2 * (size_t)w + 1], s));
+        if (e->profiling) ZL_HIP(e, hipEventRecord(c.evK2[2 * (size_t)w + 1], s));
         // K2 scans the block for AudioLevels itself when one workgroup holds the whole block of the final mix
         if (!(Aw.groups == 1 && nframes <= 256)) ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
-        if (overlap) ZL_HIP(e, hipEventRecord(q.rendered, s));
+        ZL_HIP(e, hipEventRecord(q.rendered, s));
+        q.used = true;
     }
-    e->lastWindows = nwin;
-    ZL_KERNEL(e, zl_launch_reports(e->dReports, e->V, e->dGain, s));
-    if (e->profiling) ZL_HIP(e, hipEventRecord(e->ev[3], s));
-    ZL_HIP(e, hipMemcpyAsync(e->hReports, e->dReports, (size_t)e->V * sizeof(ZlReport), hipMemcpyDeviceToHost, s));
-    ZL_HIP(e, hipMemcpyAsync(e->hGain, e->dGain, (size_t)e->V * sizeof(float), hipMemcpyDeviceToHost, s));
-    ZL_HIP(e, hipMemcpyAsync(e->hStats, e->dStats, sizeof(ZlBatchStats), hipMemcpyDeviceToHost, s));
+    c.windows = nwin;
+    if (e->ps[1].hdr != nullptr) e->setPhase = (phase + (unsigned)nwin) & 1u;
+    // results go straight to mapped host memory (a copy command here would make the runtime wait for the stream)
+    ZL_KERNEL(e, zl_launch_reports(c.dReports, e->V, e->dGain, c.hReportsDev, c.hGainDev, c.dStats, c.hStatsDev, s));
+    if (e->profiling) { ZL_HIP(e, hipEventRecord(c.evEnd, s)); c.profiled = true; }
+    ZL_HIP(e, hipEventRecord(c.done, s));
+    c.inflight = true;
     if (s != e->stream) {
         // later engine-stream work (levels, read-back) must see this batch
-        ZL_HIP(e, hipEventRecord(e->ev[4], s));
-        ZL_HIP(e, hipStreamWaitEvent(e->stream, e->ev[4], 0));
+        ZL_HIP(e, hipStreamWaitEvent(e->stream, c.done, 0));
     }
-    e->lastK = nblocks; e->lastN = nframes; e->lastBus = A.bus;
+    e->latest = &c;
+    e->callIndex += 1;
+    e->lastK = nblocks; e->lastN = nframes; e->lastBus = A.bus; e->lastWindows = nwin;
     e->outstanding = true; e->reportsFresh = true;
     return ZLHIP_OK;
 }
@@ -545,7 +621,7 @@ int zlhip_synchronize(zlhip_engine *e)
 {
     if (!e) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    ZL_HIP(e, hipStreamSynchronize(e->stream));                    // joined to caller-provided streams through CallSlot::done
     e->outstanding = false;
     return ZLHIP_OK;
 }
@@ -586,9 +662,9 @@ int zlhip_voice_reports(zlhip_engine *e, zlhip_voice_report *out, int32_t count)
     ZL_HIP(e, hipSetDevice(e->device));
     if (e->outstanding) { ZL_HIP(e, hipStreamSynchronize(e->stream)); e->outstanding = false; }
     for (int v = 0; v < e->V; ++v) {
-        const ZlReport &r = e->hReports[v];
+        const ZlReport &r = e->latest->hReports[v];
         zlhip_voice_report &o = out[v];
-        o.playing = r.playing; o.valid = r.valid; o.gain = r.valid ? e->hGain[v] : 0.0f; o.progress = r.progress;
+        o.playing = r.playing; o.valid = r.valid; o.gain = r.valid ? e->latest->hGain[v] : 0.0f; o.progress = r.progress;
         o.clip = r.clip; o.reserved = 0; o.source_sample_position = r.P;
     }
     return ZLHIP_OK;
@@ -689,7 +765,7 @@ int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblo
     A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.Ktot = nblocks; A.k0 = 0; A.N = nframes; A.G = A.VPB; A.groups = 1;
     A.levels = e->dLevels; A.bus = nullptr;
     ZL_KERNEL(e, zl_launch_finalize(A, bus_dev, s));
-    if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->ev[4], s)); ZL_HIP(e, hipStreamWaitEvent(e->stream, e->ev[4], 0)); }
+    if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->evJoin, s)); ZL_HIP(e, hipStreamWaitEvent(e->stream, e->evJoin, 0)); }
     e->lastK = nblocks; e->lastN = nframes;
     e->outstanding = true;
     return ZLHIP_OK;
@@ -730,25 +806,29 @@ int zlhip_last_timings(zlhip_engine *e, zlhip_timings *out)
     ZL_HIP(e, hipSetDevice(e->device));
     ZL_HIP(e, hipStreamSynchronize(e->stream));
     e->outstanding = false;
-    if (e->profiling && e->lastK > 0) {
-        ZL_HIP(e, hipEventSynchronize(e->ev[3]));
-        ZL_HIP(e, hipEventElapsedTime(&out->total_ms, e->ev[0], e->ev[3]));
-        float k2 = 0.0f;
-        for (int w = 0; w < e->lastWindows; ++w) {
-            float t = 0.0f;
-            ZL_HIP(e, hipEventElapsedTime(&t, e->evK2[2 * (size_t)w], e->evK2[2 * (size_t)w + 1]));
-            k2 += t;
-        }
-        out->render_ms = k2;                                       // sum over the K2 launches of the call
-        float first = 0.0f;
-        ZL_HIP(e, hipEventElapsedTime(&first, e->ev[0], e->evK2[0]));
-        out->plan_ms = first;                                      // planning that is NOT hidden behind rendering (first window)
-        out->finalize_ms = out->total_ms - k2 - first;             // K3 + reports + gaps between launches
+    // harvest in call order: the older slot first
+    for (unsigned i = 0; i < 2; ++i) {
+        zlhip_engine::CallSlot &c = e->slots[(e->callIndex + i) & 1u];
+        int rc = harvest_slot(e, c);
+        if (rc != ZLHIP_OK) return rc;
     }
+    *out = e->timings;
     out->render_launches = e->lastWindows;
-    out->source_bytes = e->hStats->source_bytes;
-    out->slow_blocks = e->hStats->slow_blocks;
-    out->active_voice_frames = e->hStats->active_frames;
+    out->source_bytes = e->latest->hStats->source_bytes;
+    out->slow_blocks = e->latest->hStats->slow_blocks;
+    out->active_voice_frames = e->latest->hStats->active_frames;
+    return ZLHIP_OK;
+}
+
+int zlhip_profile_totals(zlhip_engine *e, zlhip_timings *totals, int32_t *calls, int reset)
+{
+    if (!e) return ZLHIP_ERR_INVALID;
+    zlhip_timings last;
+    int rc = zlhip_last_timings(e, &last);                         // waits for the outstanding calls and harvests them
+    if (rc != ZLHIP_OK) return rc;
+    if (totals) *totals = e->totals;
+    if (calls) *calls = e->totalCalls;
+    if (reset) { std::memset(&e->totals, 0, sizeof e->totals); e->totalCalls = 0; }
     return ZLHIP_OK;
 }
 

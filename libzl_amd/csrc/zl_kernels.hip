@@ -381,37 +381,41 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     float accL = 0.0f, accR = 0.0f;
     for (int vb = v0; vb < v1; vb += ZL_K2_CHUNK) {
         const int nv = (v1 - vb < ZL_K2_CHUNK) ? v1 - vb : ZL_K2_CHUNK;
-        // ---- stage the per-voice records of this pass in LDS (coalesced; one round trip per workgroup,
-        //      a second one only for voices whose block has a second position segment)
+        // ---- stage the per-voice records of this pass in LDS: one lane per voice issues every load it may need at
+        //      once (voice constants, run list; plan header + first segment when no run covers the block), so the
+        //      prologue is one memory round trip (two for blocks with a second segment) and one barrier
         __syncthreads();
-        {
-            const uint4 *gc = reinterpret_cast<const uint4 *>(A.vconst + vb);
-            uint4 *sc = reinterpret_cast<uint4 *>(s_vc);
-            for (int i = threadIdx.x; i < nv * (int)(sizeof(ZlVoiceConst) / 16); i += blockDim.x) sc[i] = gc[i];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < ZL_K2_CHUNK; i += blockDim.x) {
+        for (int i = threadIdx.x; i < ZL_K2_CHUNK; i += blockDim.x) {      // whole waves: blockDim.x is a multiple of 64
+            ZlVoiceConst vc;
             ZlBlockPlan pl;
             zl_plan_clear(pl);
-            if (i < nv) pl = zl_plan_lookup(A, k, vb + i, s_vc[i].env);    // implied by a run, explicit, or idle
-            s_plan[i] = pl;                       // idle slots: a harmless record with no active frame
+            vc.src_offset = 0; vc.sample_duration = 0; vc.channels = 2;
+            vc.lgain = vc.rgain = vc.clip_volume = vc.lpan = vc.rpan = vc.env = 0.0f; vc.pad[0] = vc.pad[1] = 0;
+            if (i < nv) {
+                vc = A.vconst[vb + i];
+                pl = zl_plan_lookup(A, k, vb + i, vc.env);        // implied by a run, explicit, or idle
+            }
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
             // 4 = "simple": whole block, sustain, stereo (and no debug trace); 8 = it has a second position segment
-            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && s_vc[i].channels == 2 && !A.trace)
+            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && vc.channels == 2 && !A.trace)
                 cls |= 4 | (pl.nseg == 2 ? 8 : 0);
-            s_cls[i] = cls;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < ZL_K2_CHUNK; i += blockDim.x) {
-            if (!(s_cls[i] & 1)) {                // idle slot: neutral voice constants for the branch-free chunk code
-                s_vc[i].src_offset = 0; s_vc[i].sample_duration = 0; s_vc[i].channels = 2;
-                s_vc[i].lgain = s_vc[i].rgain = s_vc[i].clip_volume = s_vc[i].lpan = s_vc[i].rpan = 0.0f;
+            if (!(cls & 1)) {                     // idle slot: neutral voice constants for the branch-free chunk code
+                vc.src_offset = 0; vc.sample_duration = 0; vc.channels = 2;
+                vc.lgain = vc.rgain = vc.clip_volume = vc.lpan = vc.rpan = 0.0f;
             }
-        }
-        for (int c = threadIdx.x; c < ZL_K2_CHUNK / U; c += blockDim.x) {
-            int cc = 0, all = 4;
-            for (int u = 0; u < U; ++u) { cc |= s_cls[c * U + u]; all &= s_cls[c * U + u]; }
-            s_chunk[c] = (cc & 11) | all;
+            s_vc[i] = vc;
+            s_plan[i] = pl;                       // idle slots: a harmless record with no active frame
+            s_cls[i] = cls;
+            // class of each chunk of U voices: OR of bits 1, 2, 8 and AND of bit 4 (ballots over the wave's 64 voices)
+            const unsigned long long m1 = __ballot(cls & 1), m2 = __ballot(cls & 2), m4 = __ballot(cls & 4), m8 = __ballot(cls & 8);
+            const int lane = i & 63;
+            if (lane < 64 / U) {
+                const unsigned long long full = (1ull << U) - 1ull;
+                const int sh = lane * U;
+                const int cc = (((m1 >> sh) & full) ? 1 : 0) | (((m2 >> sh) & full) ? 2 : 0) | (((m8 >> sh) & full) ? 8 : 0)
+                             | ((((m4 >> sh) & full) == full) ? 4 : 0);
+                s_chunk[(i >> 6) * (64 / U) + lane] = cc;
+            }
         }
         __syncthreads();
 #ifdef ZL_STAMPS
@@ -568,12 +572,18 @@ __global__ void zl_k_levels_tick(ZlLevelsState *state, const ZlBlockLevels *leve
     state[b] = s;
 }
 
-// report finalisation: gain = peakGain * 0.5f (SamplerSynthVoice.cpp:266)
-__global__ void zl_k_reports(const ZlReport *reports, int V, float *gain_out)
+// report finalisation: gain = peakGain * 0.5f (SamplerSynthVoice.cpp:266).  The call's results (reports, gains,
+// statistics) are written straight into mapped host memory: no copy command sits between two calls on the stream.
+__global__ void zl_k_reports(const ZlReport *reports, int V, float *gain_out, ZlReport *host_reports, float *host_gain,
+                             const ZlBatchStats *stats, ZlBatchStats *host_stats)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v == 0 && host_stats) *host_stats = *stats;
     if (v >= V) return;
-    gain_out[v] = __uint_as_float(reports[v].peak_bits) * 0.5f;
+    const ZlReport r = reports[v];
+    const float g = __uint_as_float(r.peak_bits) * 0.5f;
+    gain_out[v] = g;
+    if (host_reports) { host_reports[v] = r; host_gain[v] = g; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -659,9 +669,10 @@ int zl_launch_finalize(const ZlBatch &A, const float *bus_in, hipStream_t s)
     return 0;
 }
 
-int zl_launch_reports(const ZlReport *reports, int V, float *gain_out, hipStream_t s)
+int zl_launch_reports(const ZlReport *reports, int V, float *gain_out, ZlReport *host_reports, float *host_gain,
+                      const ZlBatchStats *stats, ZlBatchStats *host_stats, hipStream_t s)
 {
-    hipLaunchKernelGGL(zl_k_reports, dim3((V + 255) / 256), dim3(256), 0, s, reports, V, gain_out);
+    hipLaunchKernelGGL(zl_k_reports, dim3((V + 255) / 256), dim3(256), 0, s, reports, V, gain_out, host_reports, host_gain, stats, host_stats);
     ZL_LAUNCH_CHECK();
     return 0;
 }

@@ -288,9 +288,10 @@ ZL_HD inline ZlBlockPlan zl_plan_load(const ZlBatch &A, size_t pidx)
 {
     ZlBlockPlan pl;
     zl_plan_clear(pl);
+    // header and first segment are independent loads (one round trip); the second segment only where there is one
     const ZlPlanHdr h = A.plan_hdr[pidx];
-    pl.flags = h.flags; pl.n_active = h.n_active; pl.nseg = h.nseg; pl.env = h.env;
     const ZlPlanSeg0 s0 = A.plan_seg0[pidx];
+    pl.flags = h.flags; pl.n_active = h.n_active; pl.nseg = h.nseg; pl.env = h.env;
     pl.P0 = s0.P0; pl.step = s0.step;
     if (h.nseg >= 2 && !(h.flags & ZL_PLAN_SLOW)) {
         const ZlPlanSeg1 s1 = A.plan_seg1[pidx];

@@ -219,5 +219,12 @@ class SamplerSynth:
         self._ck(self._lib.zlhip_last_timings(self._e, C.byref(t)), "last_timings")
         return t
 
+    def profile_totals(self, reset: bool = False):
+        """(sums of the timings of the profiled calls since the last reset, number of calls); waits for them."""
+        t = Timings()
+        n = C.c_int32(0)
+        self._ck(self._lib.zlhip_profile_totals(self._e, C.byref(t), C.byref(n), 1 if reset else 0), "profile_totals")
+        return t, n.value
+
     def bus_device_ptr(self) -> int:
         return self._lib.zlhip_bus_device_ptr(self._e)

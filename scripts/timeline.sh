@@ -13,7 +13,7 @@ f = glob.glob("$RAW/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "zl_k" in r["Kernel_Name"] and "interleave" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last step = last block of launches after the last big gap
-last = rows[-40:]
+last = rows[-int("${TL_ROWS:-40}"):]
 t0 = int(last[0]["Start_Timestamp"])
 out = []
 for r in last:

@@ -130,8 +130,11 @@ def run_oracle(scene: Scene, batch: int = 1 << 30, threads: int = 1, fast: bool 
     return np.concatenate(buses, axis=2), reports, osyn
 
 
-def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bool = False, force_slow: bool = False, **factory_kw):
-    """factory(**kwargs) -> object with the libzl_amd.SamplerSynth surface (engine or CPU harness)."""
+def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bool = False, force_slow: bool = False,
+                pipelined: bool = False, **factory_kw):
+    """factory(**kwargs) -> object with the libzl_amd.SamplerSynth surface (engine or CPU harness).
+    pipelined (GPU engine only): every call renders into its own device buffer on one HIP stream and nothing is read
+    back or synchronised until the end, so consecutive zlhip_render_batch calls overlap."""
     # the oracle's setters are the single source of clip parameters for both sides
     ref = zo.OracleSynth(1, 1, scene.fs, scene.mode, max_sounds=max(8, len(scene.sounds)))
     syn = factory(num_buses=scene.num_buses, voices_per_bus=scene.voices_per_bus, mode=scene.mode,
@@ -148,6 +151,9 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
     if trace or force_slow:
         syn.enable_trace(True, force_slow=force_slow)
     buses, traces = [], []
+    if pipelined:
+        import torch
+        stream = torch.cuda.Stream()
     for (k0, n) in _segments(scene, batch):
         for ev in scene.events.get(k0, []):
             if ev[0] == "cmd":
@@ -157,10 +163,19 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
             elif ev[0] == "clip":
                 ev[2](ref.lib, ref.clips[ev[1]])
                 syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))
+        if pipelined:
+            out = torch.zeros((scene.num_buses, 2, n * scene.nframes), device="cuda", dtype=torch.float32)
+            syn.render_batch(n, scene.nframes, scene.make_clocks(k0, n), bus_out_dev=out.data_ptr(), stream=stream.cuda_stream)
+            buses.append(out)
+            continue
         syn.render_batch(n, scene.nframes, scene.make_clocks(k0, n))
         buses.append(np.array(syn.read_bus(), copy=True))
         if trace:
             traces.append(syn.read_trace())
+    if pipelined:
+        syn.synchronize()
+        torch.cuda.synchronize()
+        buses = [b.cpu().numpy() for b in buses]
     reports = syn.voice_reports()
     return np.concatenate(buses, axis=2), reports, syn, (np.concatenate(traces, axis=0) if traces else None)
 

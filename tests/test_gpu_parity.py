@@ -115,6 +115,33 @@ def test_segment_table_overflow(Engine, window):
     syn.close()
 
 
+@pytest.mark.parametrize("seed,events", [(4100, False), (4101, True), (4102, False)])
+def test_back_to_back_calls_pipeline(Engine, seed, events):
+    """Consecutive zlhip_render_batch calls queued without host synchronisation in between (call i+1 is planned while
+    call i renders; per-call clocks / reports / statistics are double buffered) give the oracle's audio and reports.
+    With events, the commands between calls synchronise (they need the voice table) -- also the oracle's result."""
+    sc = random_scene(seed, nframes=128, nblocks=40, events=events)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=8, pipelined=True, plan_window_blocks=3)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    syn.set_profiling(True)
+    syn.close()
+
+
+def test_profile_totals_sum_over_pipelined_calls(Engine):
+    from libzl_amd.engine import synthetic_clocks
+    sc = random_scene(4103, nframes=128, nblocks=8, events=False)
+    _, _, syn, _ = run_backend(sc, Engine, batch=8, plan_window_blocks=3)
+    syn.set_profiling(True)
+    syn.profile_totals(reset=True)
+    for i in range(5):
+        syn.render_batch(8, 128, synthetic_clocks(8, 128, sc.fs, start_block=8 * (i + 1)))
+    tot, ncalls = syn.profile_totals(reset=True)
+    assert ncalls == 5 and tot.render_launches == 15 and tot.render_ms > 0.0 and tot.total_ms >= tot.render_ms
+    assert syn.profile_totals()[1] == 0
+    syn.close()
+
+
 def test_realtime_process_equals_batch(Engine):
     """zlhip_render (one JACK cycle, host buffers) gives the same bits as the batched path."""
     from libzl_amd.engine import synthetic_clocks

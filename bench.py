@@ -26,6 +26,10 @@ import os
 import sys
 import time
 
+# One hardware queue per HIP stream in use (caller's stream, the engine's planning stream, RCCL's stream, the null
+# stream): streams that share a hardware queue serialise behind each other.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -93,6 +93,7 @@ struct zlhip_engine {
 
     // profiling
     bool profiling = false; hipEvent_t evJoin = nullptr;
+    hipEvent_t joins[2] = {nullptr, nullptr};   // events on caller streams the host still has to wait for (engine_wait)
     zlhip_timings timings{};
 };
 
@@ -119,6 +120,20 @@ static int fail(zlhip_engine *e, int code, const char *msg)
     if (e) e->err = msg;
     return code;
 }
+
+// Host-side wait for everything the engine has queued, on its own stream and on caller-provided streams.  (Work on
+// a caller's stream is joined through events waited for on the host, not by queueing a wait on the engine's stream:
+// an idle HIP stream holds no hardware queue, and the process has few of them.)
+static int engine_wait(zlhip_engine *e)
+{
+    for (hipEvent_t &ev : e->joins) {
+        if (ev) { ZL_HIP(e, hipEventSynchronize(ev)); ev = nullptr; }
+    }
+    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    e->outstanding = false;
+    return ZLHIP_OK;
+}
+
 
 extern "C" {
 
@@ -337,7 +352,7 @@ static int publish_sound(zlhip_engine *e, int id)
     ZL_HIP(e, hipMemcpyAsync(e->dSounds + id, &e->hc.sounds[id], sizeof(ZlSound), hipMemcpyHostToDevice, e->stream));
     zlhip_clip_params p;
     zlhip_clip_params_default(&p, (float)(e->hc.sounds[id].length / e->hc.sounds[id].sample_rate));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     return zlhip_clip_set(e, id, &p);
 }
 
@@ -365,7 +380,7 @@ int zlhip_sound_upload(zlhip_engine *e, const float *left, const float *right, i
     if (right) for (int32_t i = 0; i < length; ++i) { tmp[2 * (size_t)i] = left[i]; tmp[2 * (size_t)i + 1] = right[i]; }
     else std::memcpy(tmp.data(), left, (size_t)length * sizeof(float));
     ZL_HIP(e, hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     return publish_sound(e, *out_id);
 }
 
@@ -373,10 +388,11 @@ int zlhip_sound_release(zlhip_engine *e, int32_t id)
 {
     if (!e || id < 0 || id >= e->cfg.max_sounds || !e->hc.soundUsed[id]) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
+    if (e->outstanding) { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }     // queued batches still read the table
     e->hc.soundUsed[id] = 0;
     e->hc.sounds[id] = ZlSound{0, 0, 0, 0.0};
     ZL_HIP(e, hipMemcpyAsync(e->dSounds + id, &e->hc.sounds[id], sizeof(ZlSound), hipMemcpyHostToDevice, e->stream));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     return ZLHIP_OK;
 }
 
@@ -385,11 +401,12 @@ int zlhip_clip_set(zlhip_engine *e, int32_t id, const zlhip_clip_params *p)
     if (!e || !p || id < 0 || id >= e->cfg.max_sounds || !e->hc.soundUsed[id]) return ZLHIP_ERR_INVALID;
     if (p->num_slice_positions < 0 || p->num_slice_positions > ZLHIP_MAX_SLICES) return fail(e, ZLHIP_ERR_INVALID, "too many slices");
     ZL_HIP(e, hipSetDevice(e->device));
+    if (e->outstanding) { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }     // queued batches still read the parameters
     e->hc.clipParams[id] = *p;
     ZlClip c;
     ZlHostControl::fill_clip(c, *p);
     ZL_HIP(e, hipMemcpyAsync(e->dClips + id, &c, sizeof c, hipMemcpyHostToDevice, e->stream));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     return ZLHIP_OK;
 }
 
@@ -404,8 +421,8 @@ static int refresh_host_voices(zlhip_engine *e)
 {
     if (e->outstanding) {
         ZL_HIP(e, hipSetDevice(e->device));
-        ZL_HIP(e, hipStreamSynchronize(e->stream));
-        e->outstanding = false;
+        int rc = engine_wait(e);
+        if (rc != ZLHIP_OK) return rc;
     }
     if (e->reportsFresh) {
         e->hc.absorb_reports(e->latest->hReports);
@@ -606,10 +623,7 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     if (e->profiling) { ZL_HIP(e, hipEventRecord(c.evEnd, s)); c.profiled = true; }
     ZL_HIP(e, hipEventRecord(c.done, s));
     c.inflight = true;
-    if (s != e->stream) {
-        // later engine-stream work (levels, read-back) must see this batch
-        ZL_HIP(e, hipStreamWaitEvent(e->stream, c.done, 0));
-    }
+    if (s != e->stream) e->joins[0] = c.done;                      // later engine work (levels, read-back) waits for it on the host
     e->latest = &c;
     e->callIndex += 1;
     e->lastK = nblocks; e->lastN = nframes; e->lastBus = A.bus; e->lastWindows = nwin;
@@ -621,7 +635,7 @@ int zlhip_synchronize(zlhip_engine *e)
 {
     if (!e) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));                    // joined to caller-provided streams through CallSlot::done
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     e->outstanding = false;
     return ZLHIP_OK;
 }
@@ -633,7 +647,7 @@ int zlhip_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, flo
     if (rc != ZLHIP_OK) return rc;
     const size_t B = (size_t)e->cfg.num_buses, N = (size_t)nframes;
     ZL_HIP(e, hipMemcpyAsync(e->hBus, e->dBus, B * 2 * N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     e->outstanding = false;
     for (size_t b = 0; b < B; ++b) {
         std::memcpy(out_left + b * N, e->hBus + (b * 2) * N, N * sizeof(float));
@@ -649,10 +663,10 @@ int zlhip_read_bus(zlhip_engine *e, float *out, size_t out_floats)
     const size_t need = (size_t)e->cfg.num_buses * 2 * (size_t)e->lastK * (size_t)e->lastN;
     if (out_floats < need) return fail(e, ZLHIP_ERR_INVALID, "output buffer too small");
     ZL_HIP(e, hipSetDevice(e->device));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     e->outstanding = false;
     ZL_HIP(e, hipMemcpyAsync(out, e->lastBus, need * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     return ZLHIP_OK;
 }
 
@@ -660,7 +674,7 @@ int zlhip_voice_reports(zlhip_engine *e, zlhip_voice_report *out, int32_t count)
 {
     if (!e || !out || count < e->V) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
-    if (e->outstanding) { ZL_HIP(e, hipStreamSynchronize(e->stream)); e->outstanding = false; }
+    if (e->outstanding) { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     for (int v = 0; v < e->V; ++v) {
         const ZlReport &r = e->latest->hReports[v];
         zlhip_voice_report &o = out[v];
@@ -685,9 +699,9 @@ int zlhip_debug_read_trace(zlhip_engine *e, int32_t *out, size_t out_ints)
     if (!e->dTrace || need == 0) return fail(e, ZLHIP_ERR_STATE, "no trace recorded");
     if (out_ints < need) return fail(e, ZLHIP_ERR_INVALID, "trace buffer too small");
     ZL_HIP(e, hipSetDevice(e->device));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     ZL_HIP(e, hipMemcpyAsync(out, e->dTrace, need * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     return ZLHIP_OK;
 }
 
@@ -722,7 +736,7 @@ int zlhip_levels_tick(zlhip_engine *e, int32_t block_index, int32_t with_hold_bu
     const int B = e->cfg.num_buses;
     ZL_KERNEL(e, zl_launch_levels_tick(e->dLevelState, lv, B, e->lastN, with_hold_bus, e->stream));
     ZL_HIP(e, hipMemcpyAsync(e->hLevelState, e->dLevelState, (size_t)B * sizeof(ZlLevelsState), hipMemcpyDeviceToHost, e->stream));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     e->outstanding = false;
     static const float intToFloatMultiplier = 0.00000152587f;     // AudioLevels.cpp:349
     for (int b = 0; b < B; ++b) {
@@ -747,11 +761,11 @@ int zlhip_block_peaks(zlhip_engine *e, int32_t *out, size_t out_ints)
     if (n == 0) return fail(e, ZLHIP_ERR_STATE, "no batch rendered yet");
     if (out_ints < n * 2) return fail(e, ZLHIP_ERR_INVALID, "output buffer too small");
     ZL_HIP(e, hipSetDevice(e->device));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     e->outstanding = false;
     std::vector<ZlBlockLevels> tmp(n);
     ZL_HIP(e, hipMemcpyAsync(tmp.data(), e->dLevels, n * sizeof(ZlBlockLevels), hipMemcpyDeviceToHost, e->stream));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     for (size_t i = 0; i < n; ++i) { out[2 * i] = tmp[i].peak_l; out[2 * i + 1] = tmp[i].peak_r; }
     return ZLHIP_OK;
 }
@@ -765,7 +779,7 @@ int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblo
     A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.Ktot = nblocks; A.k0 = 0; A.N = nframes; A.G = A.VPB; A.groups = 1;
     A.levels = e->dLevels; A.bus = nullptr;
     ZL_KERNEL(e, zl_launch_finalize(A, bus_dev, s));
-    if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->evJoin, s)); ZL_HIP(e, hipStreamWaitEvent(e->stream, e->evJoin, 0)); }
+    if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->evJoin, s)); e->joins[1] = e->evJoin; }
     e->lastK = nblocks; e->lastN = nframes;
     e->outstanding = true;
     return ZLHIP_OK;
@@ -804,7 +818,7 @@ int zlhip_last_timings(zlhip_engine *e, zlhip_timings *out)
     if (!e || !out) return ZLHIP_ERR_INVALID;
     std::memset(out, 0, sizeof *out);
     ZL_HIP(e, hipSetDevice(e->device));
-    ZL_HIP(e, hipStreamSynchronize(e->stream));
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     e->outstanding = false;
     // harvest in call order: the older slot first
     for (unsigned i = 0; i < 2; ++i) {

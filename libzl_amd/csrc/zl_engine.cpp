@@ -48,11 +48,12 @@ struct zlhip_engine {
         ZlPlanHdr *hdr = nullptr; ZlPlanSeg0 *seg0 = nullptr; ZlPlanSeg1 *seg1 = nullptr;
         double *ctlP = nullptr; float *ctlEnv = nullptr;
         float *partials = nullptr;
-        hipEvent_t planned = nullptr, rendered = nullptr;
+        hipEvent_t planned = nullptr, rendered = nullptr, k1done = nullptr;
         bool used = false;               // `rendered` has been recorded at least once
     } ps[2];
     int window = 0;                      // blocks per plan window
-    hipStream_t planStream = nullptr;
+    hipStream_t planStream = nullptr;    // K0 + K1 (sequential per voice)
+    hipStream_t asmStream = nullptr;     // K1c of window w runs here, next to K1 of window w+1
     std::vector<std::pair<int, int>> wins;
     // Per-call resources, double buffered so that consecutive zlhip_render_batch calls pipeline: the host prepares
     // (and the planning stream plans) call i+1 while call i still renders; a slot is reused by call i+2.
@@ -176,6 +177,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->planStream) (void)hipStreamSynchronize(e->planStream);
+    if (e->asmStream) (void)hipStreamSynchronize(e->asmStream);
     void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dOps,
                     e->dOpRanges, e->dTrace, e->dPass };
     for (void *p : dev) if (p) (void)hipFree(p);
@@ -184,6 +186,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
         for (void *p : pd) if (p) (void)hipFree(p);
         if (q.planned) (void)hipEventDestroy(q.planned);
         if (q.rendered) (void)hipEventDestroy(q.rendered);
+        if (q.k1done) (void)hipEventDestroy(q.k1done);
     }
     for (auto &c : e->slots) {
         void *cd[] = { c.dClocks, c.dReports, c.dStats };
@@ -195,6 +198,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
         for (hipEvent_t x : evs) if (x) (void)hipEventDestroy(x);
     }
     if (e->planStream) (void)hipStreamDestroy(e->planStream);
+    if (e->asmStream) (void)hipStreamDestroy(e->asmStream);
     void *host[] = { e->hBus, e->hLevelState };
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (e->evJoin) (void)hipEventDestroy(e->evJoin);
@@ -247,12 +251,17 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             chk(hipStreamCreateWithPriority(&e->planStream, hipStreamNonBlocking, hi), "plan stream");
+            // a second planning stream pays only when it gets a hardware queue of its own (the runtime's default is 4
+            // per process: two streams sharing one serialise behind each other's kernels)
+            const char *hwq = std::getenv("GPU_MAX_HW_QUEUES");
+            if (hwq && std::atoi(hwq) >= 6) chk(hipStreamCreateWithPriority(&e->asmStream, hipStreamNonBlocking, hi), "assemble stream");
         }
         const int nsets = (cfg->max_batch_blocks > w) ? 2 : 1;
         for (int i = 0; i < 2; ++i) {
             zlhip_engine::PlanSet &q = e->ps[i];
             chk(hipEventCreateWithFlags(&q.planned, hipEventDisableTiming), "event");
             chk(hipEventCreateWithFlags(&q.rendered, hipEventDisableTiming), "event");
+            chk(hipEventCreateWithFlags(&q.k1done, hipEventDisableTiming), "event");
             if (i >= nsets) continue;
             chk(dalloc(&q.vconst, V), "vconst");
             chk(dalloc(&q.runs, V), "run lists");
@@ -603,10 +612,19 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         if (ps != s && q.used) ZL_HIP(e, hipStreamWaitEvent(ps, q.rendered, 0));
         ZL_KERNEL(e, zl_launch_apply_ops(Aw, ps));
         ZL_KERNEL(e, zl_launch_plan(Aw, e->forceSlow, ps));
-        ZL_KERNEL(e, zl_launch_assemble(Aw, ps));
-        if (ps != s) {
+        if (ps != s && e->asmStream) {
+            // K1c (lane-parallel) on its own stream: it runs next to K1 of the following window, which writes the other set
+            ZL_HIP(e, hipEventRecord(q.k1done, ps));
+            ZL_HIP(e, hipStreamWaitEvent(e->asmStream, q.k1done, 0));
+            ZL_KERNEL(e, zl_launch_assemble(Aw, e->asmStream));
+            ZL_HIP(e, hipEventRecord(q.planned, e->asmStream));
+            ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
+        } else if (ps != s) {
+            ZL_KERNEL(e, zl_launch_assemble(Aw, ps));
             ZL_HIP(e, hipEventRecord(q.planned, ps));
             ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
+        } else {
+            ZL_KERNEL(e, zl_launch_assemble(Aw, s));
         }
         if (e->profiling) ZL_HIP(e, hipEventRecord(c.evK2[2 * (size_t)w], s));
         ZL_KERNEL(e, zl_launch_render(Aw, s));

@@ -279,6 +279,14 @@ def main():
     k2_bytes = k2_bytes_step / launches
     achieved = k2_bytes / (k2_avg_ms * 1e-3) / 1e9 if k2_avg_ms > 0 else 0.0
 
+    # HBM traffic of K2 per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process):
+    # traffic / algorithmic measured on this workload, applied to this run's algorithmic bytes; null for other workloads
+    traffic = None
+    default_workload = (V, B, N, KB, args.loop_seconds, notes, args.hermite, source_rate) == (1024, 8, 256, 8192, 2.0, (60, 60), False, args.fs)
+    pmc_file = os.path.join(ROOT, "profiles", "round1_c_pmc.json")
+    if default_workload and os.path.exists(pmc_file):
+        traffic = json.load(open(pmc_file))["traffic_over_algorithmic"] * k2_bytes
+
     if rank == 0:
         out = {
             "metric": "voice-samples/sec at 1024 voices x 256-frame blocks; % HBM roofline",
@@ -295,7 +303,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "zl_k2_render", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/round1_c_pmc.json: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic = 1.061 on this workload" if traffic else None,
                 "device_copy_GBs": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                 "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_avg_ms, "launches_per_step": launches,
                 "bytes_per_voice_sample": k2_bytes_step / (V * KB * N),

@@ -51,7 +51,9 @@ struct zlhip_engine {
         hipEvent_t planned = nullptr, rendered = nullptr, k1done = nullptr;
         bool used = false;               // `rendered` has been recorded at least once
     } ps[2];
-    int window = 0;                      // blocks per plan window
+    int windowBlocks = 0;                // plan_window_blocks when given (a fixed number of blocks per plan window)
+    size_t windowFrames = 0;             // else a window is this many frames: 2048 blocks of 256 frames, more blocks when they are shorter
+    int windowCap = 0;                   // blocks the K1 -> K2 record arrays hold
     hipStream_t planStream = nullptr;    // K0 + K1 (sequential per voice)
     hipStream_t asmStream = nullptr;     // K1c of window w runs here, next to K1 of window w+1
     std::vector<std::pair<int, int>> wins;
@@ -240,11 +242,16 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     chk(dalloc(&e->dClips, (size_t)cfg->max_sounds), "clips");
     chk(dalloc(&e->dVoices, V), "voices");
     {
-        // plan window: K1 -> K2 records are sized for `window` blocks and double buffered; plan_window_blocks
-        // overrides the default of min(512, max_batch_blocks) blocks
-        int w = cfg->plan_window_blocks > 0 ? cfg->plan_window_blocks : 2048;
+        // plan window: a call is cut into windows of ~512 Ki frames (2048 blocks of 256 frames; K2 launches of that
+        // size reach the kernel's steady-state bandwidth) or of plan_window_blocks blocks when that is given; the
+        // K1 -> K2 records are sized for one window and double buffered
+        e->windowBlocks = cfg->plan_window_blocks > 0 ? cfg->plan_window_blocks : 0;
+        e->windowFrames = (size_t)2048 * 256;
+        int w = e->windowBlocks > 0 ? e->windowBlocks : (int)(e->windowFrames / 64);
         if (w > cfg->max_batch_blocks) w = cfg->max_batch_blocks;
-        e->window = w;
+        e->windowCap = w;
+        size_t ctlFrames = e->windowBlocks > 0 ? (size_t)e->windowBlocks * N : std::max(e->windowFrames, N);
+        ctlFrames = std::min(ctlFrames, K * N);
         const size_t W = (size_t)w;
         {
             // planning is a small latency-bound kernel that rendering waits for: give its stream the highest priority
@@ -256,7 +263,10 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             const char *hwq = std::getenv("GPU_MAX_HW_QUEUES");
             if (hwq && std::atoi(hwq) >= 6) chk(hipStreamCreateWithPriority(&e->asmStream, hipStreamNonBlocking, hi), "assemble stream");
         }
-        const int nsets = (cfg->max_batch_blocks > w) ? 2 : 1;
+        const size_t minWindow = e->windowBlocks > 0 ? (size_t)e->windowBlocks : std::max<size_t>(1, e->windowFrames / N);
+        // two record sets: windows of one call, and consecutive calls, are planned while the previous one renders
+        // (engines for single real-time blocks keep one)
+        const int nsets = (K > minWindow || K * N >= 65536) ? 2 : 1;
         for (int i = 0; i < 2; ++i) {
             zlhip_engine::PlanSet &q = e->ps[i];
             chk(hipEventCreateWithFlags(&q.planned, hipEventDisableTiming), "event");
@@ -269,11 +279,11 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             chk(dalloc(&q.hdr, W * V), "plan headers");
             chk(dalloc(&q.seg0, W * V), "plan segment 0");
             chk(dalloc(&q.seg1, W * V), "plan segment 1");
-            chk(dalloc(&q.ctlP, W * V * N), "ctlP");
-            chk(dalloc(&q.ctlEnv, W * V * N), "ctlEnv");
-            chk(dalloc(&q.partials, e->maxGroups > 1 ? W * B * (size_t)e->maxGroups * 2 * N : 1), "partials");
+            chk(dalloc(&q.ctlP, ctlFrames * V), "ctlP");
+            chk(dalloc(&q.ctlEnv, ctlFrames * V), "ctlEnv");
+            chk(dalloc(&q.partials, e->maxGroups > 1 ? ctlFrames * B * (size_t)e->maxGroups * 2 : 1), "partials");
         }
-        const size_t nwin = (K + W - 1) / W + 16;                 // + the doubling windows at the start of a call
+        const size_t nwin = (K + minWindow - 1) / minWindow + 16; // + the doubling windows at the start of a call
         e->wins.reserve(nwin);
         for (auto &c : e->slots) {
             c.evK2.assign(2 * nwin, nullptr);
@@ -566,7 +576,8 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     // Window layout: large windows keep K2 launches long (their ramp-up and drain are a fixed cost per launch), but
     // planning window i+1 must fit behind rendering window i, and the planning of the first window is hidden by
     // nothing but the previous call: windows start at 256 blocks and double up to the configured size.
-    const int W = e->window;
+    int W = e->windowBlocks > 0 ? e->windowBlocks : (int)std::max<size_t>(1, e->windowFrames / (size_t)nframes);
+    W = std::min(W, e->windowCap);
     std::vector<std::pair<int, int>> &wins = e->wins;              // (first block, blocks); member: no allocation per call
     wins.clear();
     // when the previous call is still in flight its rendering hides the planning of this call's first window: no
@@ -576,7 +587,7 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     if (nblocks <= W || e->ps[1].hdr == nullptr || behindPrev) {
         for (int k0 = 0; k0 < nblocks; k0 += W) wins.push_back({k0, std::min(W, nblocks - k0)});
     } else {
-        int size = std::min(W, 256);
+        int size = std::min(W, std::max(1, 65536 / nframes));         // first window: 64 Ki frames
         for (int k0 = 0; k0 < nblocks;) {
             const int n = std::min(size, nblocks - k0);
             wins.push_back({k0, n});

@@ -355,24 +355,32 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
     }
 }
 
-template <uint32_t MODE>
+// BPW = blocks per workgroup.  Blocks shorter than 256 frames are rendered 256 / N at a time (BPW = 2 or 4: the 256
+// threads are BPW groups of N frames), so the per-workgroup fixed costs -- launch, staging of the voice records -- are
+// paid once per 256 frames whatever the block size is.  A wavefront never straddles two blocks (N is a multiple of 64).
+template <uint32_t MODE, int BPW>
 __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
 {
     constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U / 2 : ZL_K2_U;
-    __shared__ ZlBlockPlan  s_plan[ZL_K2_CHUNK];
+    __shared__ ZlBlockPlan  s_plan_[BPW][ZL_K2_CHUNK];
     __shared__ ZlVoiceConst s_vc[ZL_K2_CHUNK];
-    __shared__ int s_cls[ZL_K2_CHUNK];            // per voice: 1 = plays this block, 2 = per-frame control
-    __shared__ int s_chunk[ZL_K2_CHUNK / U];      // OR of s_cls over each chunk of U voices
+    __shared__ int s_cls_[BPW][ZL_K2_CHUNK];          // per voice: 1 = plays this block, 2 = per-frame control
+    __shared__ int s_chunk_[BPW][ZL_K2_CHUNK / U];    // class of each chunk of U voices
 
     const int N = A.N, V = A.V;
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;          // frame inside the block
-    const int k = blockIdx.y;
+    const int blk = (BPW > 1) ? (int)threadIdx.x / N : 0;          // which of the workgroup's blocks this lane renders
+    const int f = (BPW > 1) ? (int)threadIdx.x - blk * N : (int)(blockIdx.x * blockDim.x + threadIdx.x);   // frame inside the block
+    const int k = blockIdx.y * BPW + blk;
+    const bool live = k < A.K;                                     // the last workgroup may hold fewer than BPW blocks
+    const ZlBlockPlan *s_plan = s_plan_[blk];
+    const int *s_cls = s_cls_[blk];
+    const int *s_chunk = s_chunk_[blk];
     const int bus = blockIdx.z / A.groups;
     const int g   = blockIdx.z - bus * A.groups;
     const int v0 = bus * A.VPB + g * A.G;
     const int vend = (bus + 1) * A.VPB;
     const int v1 = (v0 + A.G < vend) ? v0 + A.G : vend;
-    const bool wantPeak = (A.k0 + k == A.Ktot - 1);               // the report covers the last block of the call
+    const bool wantPeak = live && (A.k0 + k == A.Ktot - 1);        // the report covers the last block of the call
     const double fd = (double)f;
 #ifdef ZL_STAMPS
     unsigned long long zl_t0 = __builtin_amdgcn_s_memrealtime(), zl_t1 = 0, zl_paths = 0;
@@ -381,31 +389,29 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     float accL = 0.0f, accR = 0.0f;
     for (int vb = v0; vb < v1; vb += ZL_K2_CHUNK) {
         const int nv = (v1 - vb < ZL_K2_CHUNK) ? v1 - vb : ZL_K2_CHUNK;
-        // ---- stage the per-voice records of this pass in LDS: one lane per voice issues every load it may need at
-        //      once (voice constants, run list; plan header + first segment when no run covers the block), so the
-        //      prologue is one memory round trip (two for blocks with a second segment) and one barrier
+        // ---- stage the per-voice records of this pass in LDS: one lane per (block, voice) issues every load it may
+        //      need at once (voice constants, run list; plan header + first segment when no run covers the block), so
+        //      the prologue is one memory round trip (two for blocks with a second segment) and one barrier
         __syncthreads();
-        for (int i = threadIdx.x; i < ZL_K2_CHUNK; i += blockDim.x) {      // whole waves: blockDim.x is a multiple of 64
+        for (int idx = threadIdx.x; idx < BPW * ZL_K2_CHUNK; idx += blockDim.x) {   // whole waves: blockDim.x is a multiple of 64
+            const int b = idx / ZL_K2_CHUNK, i = idx - b * ZL_K2_CHUNK;
+            const int kk = blockIdx.y * BPW + b;
             ZlVoiceConst vc;
             ZlBlockPlan pl;
             zl_plan_clear(pl);
             vc.src_offset = 0; vc.sample_duration = 0; vc.channels = 2;
             vc.lgain = vc.rgain = vc.clip_volume = vc.lpan = vc.rpan = vc.env = 0.0f; vc.pad[0] = vc.pad[1] = 0;
             if (i < nv) {
-                vc = A.vconst[vb + i];
-                pl = zl_plan_lookup(A, k, vb + i, vc.env);        // implied by a run, explicit, or idle
+                vc = A.vconst[vb + i];                             // K1 leaves a neutral record for voices that do not play
+                if (kk < A.K) pl = zl_plan_lookup(A, kk, vb + i, vc.env);   // implied by a run, explicit, or idle
             }
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
             // 4 = "simple": whole block, sustain, stereo (and no debug trace); 8 = it has a second position segment
             if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && vc.channels == 2 && !A.trace)
                 cls |= 4 | (pl.nseg == 2 ? 8 : 0);
-            if (!(cls & 1)) {                     // idle slot: neutral voice constants for the branch-free chunk code
-                vc.src_offset = 0; vc.sample_duration = 0; vc.channels = 2;
-                vc.lgain = vc.rgain = vc.clip_volume = vc.lpan = vc.rpan = 0.0f;
-            }
-            s_vc[i] = vc;
-            s_plan[i] = pl;                       // idle slots: a harmless record with no active frame
-            s_cls[i] = cls;
+            if (b == 0) s_vc[i] = vc;
+            s_plan_[b][i] = pl;                   // idle slots: a harmless record with no active frame
+            s_cls_[b][i] = cls;
             // class of each chunk of U voices: OR of bits 1, 2, 8 and AND of bit 4 (ballots over the wave's 64 voices)
             const unsigned long long m1 = __ballot(cls & 1), m2 = __ballot(cls & 2), m4 = __ballot(cls & 4), m8 = __ballot(cls & 8);
             const int lane = i & 63;
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
                 const int sh = lane * U;
                 const int cc = (((m1 >> sh) & full) ? 1 : 0) | (((m2 >> sh) & full) ? 2 : 0) | (((m8 >> sh) & full) ? 8 : 0)
                              | ((((m4 >> sh) & full) == full) ? 4 : 0);
-                s_chunk[(i >> 6) * (64 / U) + lane] = cc;
+                s_chunk_[b][(i >> 6) * (64 / U) + lane] = cc;
             }
         }
         __syncthreads();
@@ -458,19 +464,21 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
         outL = A.partials + ((((size_t)k * A.B + bus) * A.groups + g) * 2) * (size_t)N;
         outR = outL + N;
     }
-    bool written;
-    if (MODE & ZL_MODE_FIX_DELAY) {
-        outL[f] = accL; outR[f] = accR;
-        written = true;
-    } else {
-        // quirk Q2: the reference pre-increments its output pointers, so frame f lands in out[f+1],
-        // out[0] stays 0 and the sample of the last frame falls outside the buffer (dropped)
-        written = f + 1 < N;
-        if (written) { outL[f + 1] = accL; outR[f + 1] = accR; }
-        if (f == 0)  { outL[0] = 0.0f;    outR[0] = 0.0f; }
+    bool written = false;
+    if (live) {
+        if (MODE & ZL_MODE_FIX_DELAY) {
+            outL[f] = accL; outR[f] = accR;
+            written = true;
+        } else {
+            // quirk Q2: the reference pre-increments its output pointers, so frame f lands in out[f+1],
+            // out[0] stays 0 and the sample of the last frame falls outside the buffer (dropped)
+            written = f + 1 < N;
+            if (written) { outL[f + 1] = accL; outR[f + 1] = accR; }
+            if (f == 0)  { outL[0] = 0.0f;    outR[0] = 0.0f; }
+        }
     }
-    // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of the
-    //      whole block (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
+    // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of its
+    //      whole block(s) (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
     if (A.groups == 1 && gridDim.x == 1 && A.levels) {
         __shared__ int   s_pk[2][4];
         __shared__ float s_sq[2][4];
@@ -485,10 +493,12 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
         const int w = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) { s_pk[0][w] = pkL; s_pk[1][w] = pkR; s_sq[0][w] = sqL; s_sq[1][w] = sqR; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const int nw = (blockDim.x + 63) >> 6;
+        if (f == 0 && live) {
+            // the waves of this lane's block: all of the workgroup's (BPW == 1) or N / 64 of them
+            const int w0 = (BPW > 1) ? blk * (N >> 6) : 0;
+            const int nw = (BPW > 1) ? (N >> 6) : (int)((blockDim.x + 63) >> 6);
             ZlBlockLevels lv; lv.peak_l = 0; lv.peak_r = 0; lv.sumsq_l = 0.0f; lv.sumsq_r = 0.0f;
-            for (int i = 0; i < nw; ++i) {
+            for (int i = w0; i < w0 + nw; ++i) {
                 lv.peak_l = s_pk[0][i] > lv.peak_l ? s_pk[0][i] : lv.peak_l;
                 lv.peak_r = s_pk[1][i] > lv.peak_r ? s_pk[1][i] : lv.peak_r;
                 lv.sumsq_l += s_sq[0][i]; lv.sumsq_r += s_sq[1][i];
@@ -651,10 +661,16 @@ int zl_launch_assemble(const ZlBatch &A, hipStream_t s)
 
 int zl_launch_render(const ZlBatch &A, hipStream_t s)
 {
-    const int tpb = A.N < 256 ? A.N : 256;
-    const dim3 grid(A.N / tpb, A.K, A.B * A.groups), block(tpb);
+    // blocks shorter than 256 frames: 256 / N blocks per workgroup (batches only; a single block keeps its small workgroup)
+    const int bpw = (A.N < 256 && 256 % A.N == 0 && A.K > 1) ? 256 / A.N : 1;
+    const int tpb = bpw > 1 ? 256 : (A.N < 256 ? A.N : 256);
+    const dim3 grid(bpw > 1 ? 1 : A.N / tpb, (A.K + bpw - 1) / bpw, A.B * A.groups), block(tpb);
     switch (A.mode & 7u) {
-#define ZL_CASE(M) case M: hipLaunchKernelGGL(zl_k2_render<M>, grid, block, 0, s, A); break;
+#define ZL_CASE(M) case M: \
+        if (bpw == 4)      hipLaunchKernelGGL((zl_k2_render<M, 4>), grid, block, 0, s, A); \
+        else if (bpw == 2) hipLaunchKernelGGL((zl_k2_render<M, 2>), grid, block, 0, s, A); \
+        else               hipLaunchKernelGGL((zl_k2_render<M, 1>), grid, block, 0, s, A); \
+        break;
         ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
 #undef ZL_CASE
     }

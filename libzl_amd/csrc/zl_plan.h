@@ -348,7 +348,14 @@ struct ZlPlanner {
         invN = 1.0 / (double)A.N;
         valid = st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0;
         posMode = false; clockMode = false; X = INFINITY; blockBytes = 0; inv_r = 0.0;
-        if (!valid) return;
+        if (!valid) {
+            // a neutral record: K2 stages every voice slot of a bus and must find addressable constants in it
+            ZlVoiceConst vc;
+            vc.src_offset = 0; vc.sample_duration = 0; vc.channels = 2;
+            vc.lgain = vc.rgain = vc.clip_volume = vc.lpan = vc.rpan = vc.env = 0.0f; vc.pad[0] = vc.pad[1] = 0;
+            A.vconst[v] = vc;
+            return;
+        }
         dead_from = A.K;
         inv_r = 1.0 / st.pitch_ratio;
         const ZlClip &cl = A.clips[st.clip];

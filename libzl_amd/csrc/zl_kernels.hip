@@ -196,7 +196,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
     constexpr bool PK = HERM ? (ZL_K2_PK_HERMITE != 0) : (ZL_K2_PK_LINEAR != 0);
     zl_f4a4 d[U], e[HERM ? U : 1];
     float alpha[U];
-    int   inbm = 0, widem = 0;
+    int   widem = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
@@ -207,11 +207,15 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
         } else {
             P = fma(fd, s_plan[i].step, s_plan[i].P0);            // exact, see zl_plan.h
         }
-        int pos;
-        zl_split_position(P, pos, alpha[u]);                      // :198-199
+        // :198-199 -- P >= 0 here, so pos = floor(P) and alpha = (float)(P - pos) = (float)fract(P), both exact
+        const int pos = (int)P;
+        alpha[u] = (float)__builtin_amdgcn_fract(P);
         const int dur = s_vc[i].sample_duration;
-        const bool inb = dur > pos;                               // :204 guard (Q5); P >= 0 so pos >= 0
-        int p = inb ? pos : 0;
+        const bool inb = dur > pos;                               // :204 guard (Q5)
+        // out of range: gather the zero padding behind the source (8 frames, written by zl_k_interleave), so that
+        // l = r = 0 falls out of the arithmetic (0 * finite = +-0, +0 + -0 = +0) without a select per channel;
+        // voices with a non-finite gain are not "simple"
+        int p = inb ? pos : dur + 1;
         const uint64_t so = s_vc[i].src_offset;
         const float *src = A.arena + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(so >> 32)) << 32)
                                       | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)so));
@@ -225,9 +229,30 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
         } else {
             d[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p);
         }
-        inbm |= inb ? (1 << u) : 0;
     }
     zl_f2 acc = {accL, accR};
+    // every lane of the wave has all four Hermite taps inside its source (true except in the blocks at a loop's ends):
+    // the wave-uniform fast form needs no tap selects and no linear alternative
+    const bool allWide = HERM && PK && __all(widem == (1 << U) - 1);
+    if (allWide) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = c0 + u;
+            const zl_f2 o = zl_mix_frame_pk<MODE>((zl_f2){d[u].x, d[u].y}, (zl_f2){d[u].z, d[u].w}, (zl_f2){e[HERM ? u : 0].x, e[HERM ? u : 0].y},
+                                                  (zl_f2){e[HERM ? u : 0].z, e[HERM ? u : 0].w}, alpha[u], true, true,
+                                                  (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
+                                                  (zl_f2){s_vc[i].lpan, s_vc[i].rpan});
+            acc += o;
+            if (wantPeak) {
+                const float ng = o.x + o.y;
+                float pk = ng > 0.0f ? ng : 0.0f;
+                pk = zl_wave_max(pk);
+                if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[vfirst + i].peak_bits, __float_as_uint(pk));
+            }
+        }
+        accL = acc.x; accR = acc.y;
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
@@ -244,7 +269,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
                 x0 = (zl_f2){d[u].x, d[u].y}; x1 = (zl_f2){d[u].z, d[u].w};
                 xm = x0; x2 = x1;
             }
-            const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, alpha[u], (inbm >> u) & 1, wide,
+            const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, alpha[u], true, wide,
                                                   (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
                                                   (zl_f2){s_vc[i].lpan, s_vc[i].rpan});
             acc += o;                                             // :218-221 (index shift applied at the store)
@@ -260,7 +285,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
                 t.x0l = d[u].x; t.x0r = d[u].y; t.x1l = d[u].z; t.x1r = d[u].w;
                 t.xml = t.xmr = t.x2l = t.x2r = 0.0f;
             }
-            zl_mix_frame<MODE>(t, alpha[u], (inbm >> u) & 1, wide, true, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env,
+            zl_mix_frame<MODE>(t, alpha[u], true, wide, true, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env,
                                s_vc[i].clip_volume, s_vc[i].lpan, s_vc[i].rpan, l, r);
             accL += l; accR += r;                                 // :218-221 (index shift applied at the store)
         }
@@ -407,7 +432,8 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
             }
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
             // 4 = "simple": whole block, sustain, stereo (and no debug trace); 8 = it has a second position segment
-            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && vc.channels == 2 && !A.trace)
+            const float gprod = vc.lgain * vc.rgain * vc.clip_volume * pl.env;     // finite iff every factor is (or one is 0 * inf = NaN)
+            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && vc.channels == 2 && !A.trace && (gprod - gprod) == 0.0f)
                 cls |= 4 | (pl.nseg == 2 ? 8 : 0);
             if (b == 0) s_vc[i] = vc;
             s_plan_[b][i] = pl;                   // idle slots: a harmless record with no active frame

@@ -115,6 +115,23 @@ def test_segment_table_overflow(Engine, window):
     syn.close()
 
 
+@pytest.mark.parametrize("nframes", [64, 128, 192, 256, 512, 1024])
+@pytest.mark.parametrize("batch", [1, 5, 1 << 30])
+def test_block_sizes(Engine, nframes, batch):
+    """Every supported block size: 64 / 128 frames render 4 / 2 blocks per workgroup in batches, 192 and 256 one, 512 and
+    1024 use several frame tiles per block and the separate level scan (K3); single blocks keep their own workgroup."""
+    sc = random_scene(5000 + nframes, nframes=nframes, nblocks=11, events=True, min_len=900, max_len=9000)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=batch)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    peaks = syn.block_peaks()                                        # integer peaks of the last call's blocks
+    k_last = peaks.shape[0]
+    tail = ref_bus[:, :, ref_bus.shape[2] - k_last * nframes:].reshape(sc.num_buses, 2, k_last, nframes)
+    want = np.abs(np.float32(131072.0) * tail).astype(np.int64).max(axis=3).transpose(2, 0, 1)
+    assert np.array_equal(peaks.astype(np.int64), want)
+    syn.close()
+
+
 @pytest.mark.parametrize("seed,events", [(4100, False), (4101, True), (4102, False)])
 def test_back_to_back_calls_pipeline(Engine, seed, events):
     """Consecutive zlhip_render_batch calls queued without host synchronisation in between (call i+1 is planned while

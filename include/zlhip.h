@@ -191,7 +191,7 @@ int zlhip_read_bus(zlhip_engine *e, float *out, size_t out_floats);
 int zlhip_voice_reports(zlhip_engine *e, zlhip_voice_report *out, int32_t count);
 /* debug: per-frame (int)sourceSamplePosition of every voice for the blocks of the NEXT batches,
  * kept on device and read back with zlhip_debug_read_trace: out [nblocks][voices][nframes] int32 */
-int zlhip_debug_enable_trace(zlhip_engine *e, int enable);
+int zlhip_debug_enable_trace(zlhip_engine *e, int enable);   /* bit 0: trace; bits 1, 2: planner test hooks */
 int zlhip_debug_read_trace(zlhip_engine *e, int32_t *out, size_t out_ints);
 
 /* ---- levels -------------------------------------------------------------------------------- */

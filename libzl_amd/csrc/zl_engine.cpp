@@ -177,6 +177,8 @@ void zlhip_engine_destroy(zlhip_engine *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    for (auto &c : e->slots) if (c.inflight && c.done) (void)hipEventSynchronize(c.done);   // calls queued on a caller's stream
+    for (hipEvent_t ev : e->joins) if (ev) (void)hipEventSynchronize(ev);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->planStream) (void)hipStreamSynchronize(e->planStream);
     if (e->asmStream) (void)hipStreamSynchronize(e->asmStream);
@@ -716,8 +718,9 @@ int zlhip_voice_reports(zlhip_engine *e, zlhip_voice_report *out, int32_t count)
 int zlhip_debug_enable_trace(zlhip_engine *e, int enable)
 {
     if (!e) return ZLHIP_ERR_INVALID;
-    e->trace = enable != 0;
-    e->forceSlow = (enable & 2) ? 1 : 0;       // bit 1: route every block through the per-frame control path (test hook)
+    e->trace = (enable & 1) != 0;
+    // test hooks: bit 1 routes every block through the per-frame control path, bit 2 plans periodic loops pass by pass
+    e->forceSlow = ((enable & 2) ? 1 : 0) | ((enable & 4) ? 2 : 0);
     return ZLHIP_OK;
 }
 

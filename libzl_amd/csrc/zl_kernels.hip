@@ -82,17 +82,19 @@ __global__ void __launch_bounds__(64) zl_k1c_assemble(const ZlBatch A)
     ZlAssembler as;
     as.begin(A, mine ? v : 0, kbeg, mine ? kend : kbeg);
     for (int k = kbeg; k < kend; ++k) {
-        int j0 = 0, n_active = 0;
-        const int nseg = as.block(A, k, j0, n_active);
+        int idx0 = 0, base0 = 0, n_active = 0;
+        const int nseg = as.block(A, k, idx0, base0, n_active);
         unsigned long long m = __ballot(nseg > 2);
         while (m) {
             const int l = __builtin_ctzll(m);
             m &= m - 1;
-            const int vv = __shfl(v, l, 64), jj = __shfl(j0, l, 64), na = __shfl(n_active, l, 64), nts = __shfl(as.rl.nts, l, 64);
+            const int vv = __shfl(v, l, 64), ii = __shfl(idx0, l, 64), bb = __shfl(base0, l, 64), na = __shfl(n_active, l, 64);
             const float env = __shfl(as.env, l, 64);
+            ZlSegStream ss;
+            ss.init(A, vv, A.runs[vv]);
             const size_t base = ((size_t)k * A.V + vv) * (size_t)A.N;
             for (int f = lane; f < A.N; f += 64) {
-                A.ctl_P[base + f] = zl_expand_frame(A, vv, k, jj, nts, f < na ? f : 0);
+                A.ctl_P[base + f] = zl_expand_frame(ss, A.N, k, ii, bb, f < na ? f : 0);
                 A.ctl_env[base + f] = env;
             }
         }

@@ -335,10 +335,15 @@ struct ZlPlanner {
     ZlRun cur;
     int  nruns;
     bool haveCur;
+    // periodic sample-space loops: 0 = waiting for a restart, 1 = capturing the pass that started at tcap (segment
+    // jcap), 2 = done / given up
+    int perState, tcap, jcap;
+    int per_t0, per_M, per_j0, per_n;
 
     ZL_HD void begin(const ZlBatch &A, int voice)
     {
         v = voice;
+        perState = 0; tcap = 0; jcap = 0; per_t0 = 0; per_M = 0; per_j0 = 0; per_n = 0;
         st = A.voices[v];
         stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
         nruns = 0; haveCur = false; cur.P = 0.0; cur.step = 0.0; cur.k0 = 0; cur.k1 = 0;
@@ -402,11 +407,13 @@ struct ZlPlanner {
             nts = jbs;
             t = tb;
         }
+        if (perState == 1) perState = 2;
         haveRun = false;
         slowNext = true;
     }
 
     // One iteration.  clk0 is the clock of block kb; frames below kend * N may be planned.  Call while t < kend * N.
+    // force_slow: bit 0 = simulate every block per frame, bit 1 = do not use the periodicity of loops (test hooks).
     ZL_HD void iterate(const ZlBatch &A, int kend, const ZlClock *clk0, int kb, int force_slow)
     {
         const int N = A.N;
@@ -421,12 +428,13 @@ struct ZlPlanner {
             const ZlClock &ck = clk0[kcur - kb];
             if (st.next_loop_usecs == 0)                            // :179-182
                 st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
-            const bool slow = force_slow || slowNext || st.adsr_state != ZL_ADSR_SUSTAIN
+            const bool slow = (force_slow & 1) || slowNext || st.adsr_state != ZL_ADSR_SUSTAIN
                               || (clockMode && ck.usecs_per_frame >= (1ull << 21)) || nts >= ZL_MAXTSEG - 1;
             if (slow) {
                 // envelope transient, release tail (Q7) or a pathological clock: per-frame simulation of this block
                 const size_t pidx = (size_t)kcur * A.V + v;
                 slowNext = false;
+                if (perState == 1) perState = 2;                    // a simulated block inside the pass being captured
                 if (!lastMarker && nts < ZL_MAXTSEG) {              // consecutive simulated blocks share one marker
                     ZlTSeg m; m.P = st.P; m.step = 0.0; m.t = t; m.flags = ZL_TSEG_SLOW;
                     ts[nts++] = m;
@@ -520,11 +528,23 @@ struct ZlPlanner {
         }
         const double Pold = st.P;
         const uint64_t tickOld = st.next_loop_tick, usecsOld = st.next_loop_usecs;
+        bool jump = false;
         if (event) {
             // ---- event after rendering frame t1 - 1 ----
             haveRun = false;
             if (st.looping) {
                 zl_loop_restart(st, c, clk0[ke - kb], clockMode);
+                if (posMode && !force_slow) {                       // (force_slow bit 1: test hook, plan every pass)
+                    // sample-space loop: the pass that begins now repeats exactly (same integer start, same ratio)
+                    if (perState == 0) { perState = 1; tcap = t1; jcap = nts; }
+                    else if (perState == 1) {
+                        perState = 2;
+                        if (nts - jcap >= 3 && nts - jcap <= 64) {  // passes of one or two segments are cheaper as inline runs
+                            per_t0 = tcap; per_M = t1 - tcap; per_j0 = jcap; per_n = nts - jcap;
+                            jump = true;
+                        }
+                    }
+                }
             } else {
                 zl_voice_hard_stop(st);                             // :249-252, voice ends after frame t1 - 1
                 t_end = t1;
@@ -547,6 +567,19 @@ struct ZlPlanner {
             jbs = nts;
         }
         t = t1;
+        if (jump) {
+            // ---- the rest of the window is whole repetitions of the captured pass: go straight to its end ----
+            const int TW = A.K * N;
+            const int Rm = TW - t1;                                 // frames left; frame t1 is offset 0 of a pass
+            const int q = Rm / per_M, rem = Rm - q * per_M;
+            int j = per_j0 + per_n - 1;                             // the pass segment that covers offset rem
+            while (j > per_j0 && ts[j].t - per_t0 > rem) --j;
+            st.P = fma((double)(rem - (ts[j].t - per_t0)), ts[j].step, ts[j].P);   // exact: on the segment's line
+            haveRun = false;
+            stats.active_frames += (unsigned long long)Rm;
+            stats.source_bytes += blockBytes * (unsigned long long)(A.K - (k1 + (t1 > k1 * N ? 1 : 0)));
+            t = TW;
+        }
     }
 
     ZL_HD void end(const ZlBatch &A)
@@ -565,6 +598,7 @@ struct ZlPlanner {
         A.runs[v].dead_from = dead_from;                           // blocks >= dead_from are idle (voice ended or never played)
         A.runs[v].nts = nts;
         A.runs[v].t_end = t_end;
+        A.runs[v].per_t0 = per_t0; A.runs[v].per_M = per_M; A.runs[v].per_j0 = per_j0; A.runs[v].per_n = per_n;
     }
 };
 
@@ -592,41 +626,79 @@ ZL_HD inline ZlBlockPlan zl_plan_lookup(const ZlBatch &A, int k, int v, float ru
     return zl_plan_load(A, (size_t)k * A.V + v);
 }
 
+// A voice's segment stream as K1c reads it: the stored entries, then -- for a periodic loop -- the captured pass
+// repeated every per_M frames.  A position in the stream is (idx, base): entry ts[idx] shifted by base frames.
+struct ZlSegStream {
+    const ZlTSeg *ts;
+    int nts, per_t0, per_M, per_j0, per_n;
+
+    ZL_HD void init(const ZlBatch &A, int v, const ZlRunList &rl)
+    {
+        ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
+        nts = rl.nts; per_t0 = rl.per_t0; per_M = rl.per_M; per_j0 = rl.per_j0; per_n = rl.per_n;
+    }
+    // the following entry; false at the end of the stream
+    ZL_HD bool next(int &idx, int &base) const
+    {
+        if (per_n > 0 && idx + 1 == per_j0 + per_n) { idx = per_j0; base += per_M; return true; }
+        if (idx + 1 >= nts) return false;
+        ++idx;
+        return true;
+    }
+    // the last entry that starts at or before frame T (false: none)
+    ZL_HD bool locate(int T, int &idx, int &base) const
+    {
+        int lo, hi, off = T;
+        base = 0;
+        if (per_n > 0 && T >= per_t0 + per_M) {                   // in a repetition of the pass
+            const int q = (T - per_t0) / per_M;
+            base = q * per_M;
+            off = T - base;
+            lo = per_j0; hi = per_j0 + per_n;
+        } else {
+            lo = 0; hi = nts;
+        }
+        const int lo0 = lo;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid].t <= off) lo = mid + 1; else hi = mid; }
+        idx = lo - 1;
+        return idx >= lo0;
+    }
+};
+
 // K1c body: the explicit plan record of one block of voice v from its segment stream.  Blocks inside an inline run,
 // simulated blocks (K1 wrote their records) and idle blocks are left alone.  begin() positions the walker on block
 // kbeg; block() must then be called for k = kbeg, kbeg + 1, ...
 struct ZlAssembler {
     ZlRunList rl;
-    const ZlTSeg *ts;
-    int v, j, kend;
+    ZlSegStream ss;
+    int v, idx, base, kend;
     float env;
 
     ZL_HD void begin(const ZlBatch &A, int voice, int kbeg, int kend_)
     {
         v = voice;
         rl = A.runs[v];
-        ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
+        ss.init(A, v, rl);
         kend = kend_ < rl.dead_from ? kend_ : rl.dead_from;
         env = A.vconst[v].env;
-        j = -1;
+        idx = -1; base = 0;
         if (kbeg >= kend || rl.nts <= 0) { kend = kbeg; return; }
-        // last segment that starts at or before the first frame of block kbeg
-        int lo = 0, hi = rl.nts;
-        const int T0 = kbeg * A.N;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid].t <= T0) lo = mid + 1; else hi = mid; }
-        j = lo - 1;
-        if (j < 0) kend = kbeg;                                   // cannot happen: the stream starts at t = 0
+        if (!ss.locate(kbeg * A.N, idx, base)) kend = kbeg;       // cannot happen: the stream starts at t = 0
     }
 
     // Returns the number of position segments of block k (0: nothing to write).  A block with more than two is marked
-    // ZL_PLAN_SLOW and the caller fills its per-frame control with zl_expand_frame(j0, ...) for frames < n_active.
-    ZL_HD int block(const ZlBatch &A, int k, int &j0, int &n_active)
+    // ZL_PLAN_SLOW and the caller fills its per-frame control with zl_expand_frame(idx0, base0, ...) for frames < n_active.
+    ZL_HD int block(const ZlBatch &A, int k, int &idx0, int &base0, int &n_active)
     {
         if (k >= kend) return 0;
-        const int N = A.N, nts = rl.nts;
+        const int N = A.N;
         const int T = k * N;
-        while (j + 1 < nts && ts[j + 1].t <= T) ++j;
-        const ZlTSeg a = ts[j];
+        for (;;) {                                                // walk to the last entry that starts at or before T
+            int i2 = idx, b2 = base;
+            if (!ss.next(i2, b2) || ss.ts[i2].t + b2 > T) break;
+            idx = i2; base = b2;
+        }
+        const ZlTSeg a = ss.ts[idx];
         if (a.flags & ZL_TSEG_SLOW) return 0;
         bool inrun = false;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -635,33 +707,45 @@ struct ZlAssembler {
         for (int q = 0; q < ZL_MAXRUNS; ++q) inrun = inrun || (q < rl.n && k >= rl.r[q].k0 && k < rl.r[q].k1);
         if (inrun) return 0;
         n_active = (rl.t_end - T < N) ? rl.t_end - T : N;
-        int nseg = 1;
-        while (nseg < 3 && j + nseg < nts && ts[j + nseg].t < T + n_active) ++nseg;
+        // the entries that start inside the block (up to two are looked at)
+        int nseg = 1, i1 = idx, b1 = base;
+        ZlTSeg b; b.P = 0.0; b.step = 0.0; b.t = 0; b.flags = 0;
+        int bt = 0;
+        {
+            int i2 = idx, b2 = base;
+            while (nseg < 3 && ss.next(i2, b2) && ss.ts[i2].t + b2 < T + n_active) {
+                if (nseg == 1) { i1 = i2; b1 = b2; }
+                ++nseg;
+            }
+            if (nseg >= 2) { b = ss.ts[i1]; bt = b.t + b1; }
+        }
         const size_t pidx = (size_t)k * A.V + v;
         ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE | (nseg > 2 ? ZL_PLAN_SLOW : 0); h.n_active = n_active; h.nseg = nseg; h.env = env;
-        ZlPlanSeg0 s0; s0.P0 = fma((double)(T - a.t), a.step, a.P); s0.step = a.step;      // exact: on the segment's line
+        ZlPlanSeg0 s0; s0.P0 = fma((double)(T - (a.t + base)), a.step, a.P); s0.step = a.step;   // exact: on the segment's line
         A.plan_hdr[pidx] = h;
         A.plan_seg0[pidx] = s0;
         if (nseg == 2) {
-            const ZlTSeg b = ts[j + 1];
-            ZlPlanSeg1 s1; s1.P1 = b.P; s1.step1 = b.step; s1.n1 = b.t - T; s1.pad = 0; s1.pad2 = 0.0;
+            ZlPlanSeg1 s1; s1.P1 = b.P; s1.step1 = b.step; s1.n1 = bt - T; s1.pad = 0; s1.pad2 = 0.0;
             A.plan_seg1[pidx] = s1;
         }
-        j0 = j;
+        idx0 = idx; base0 = base;
         return nseg;
     }
 };
 
-// Per-frame control of a block with more than two segments: the position of frame f (< n_active) of block k of
-// voice v; j0 = the segment that covers the block's first frame, nts = the voice's segment count.
-ZL_HD inline double zl_expand_frame(const ZlBatch &A, int v, int k, int j0, int nts, int f)
+// Per-frame control of a block with more than two segments: the position of frame f (< n_active) of block k;
+// (idx0, base0) = the stream position that covers the block's first frame.
+ZL_HD inline double zl_expand_frame(const ZlSegStream &ss, int N, int k, int idx0, int base0, int f)
 {
-    const ZlTSeg *ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
-    const int T = k * A.N + f;
-    int lo = j0 + 1, hi = nts;                                    // last segment with t <= T (segment j0 qualifies)
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid].t <= T) lo = mid + 1; else hi = mid; }
-    const ZlTSeg a = ts[lo - 1];
-    return fma((double)(T - a.t), a.step, a.P);                   // exact
+    const int T = k * N + f;
+    int idx = idx0, base = base0;
+    for (;;) {
+        int i2 = idx, b2 = base;
+        if (!ss.next(i2, b2) || ss.ts[i2].t + b2 > T) break;
+        idx = i2; base = b2;
+    }
+    const ZlTSeg a = ss.ts[idx];
+    return fma((double)(T - (a.t + base)), a.step, a.P);          // exact
 }
 
 // Whole window of one voice with the clocks read from A.clocks (host harness; the kernel stages them in LDS).

@@ -108,6 +108,10 @@ struct ZlRunList {
     int32_t nts;                  // segments in ZlBatch::tsegs
     int32_t t_end;                // frame (window time) at which the voice stopped; INT_MAX while it plays
     ZlRun   r[ZL_MAXRUNS];
+    // A sample-space loop in sustain is exactly periodic (every restart sets the same integer position): K1 plans one
+    // full pass -- segments [per_j0, per_j0 + per_n) of the stream, starting at frame per_t0 -- and the stream then
+    // repeats every per_M frames up to the end of the window.  per_n == 0: no periodic part.
+    int32_t per_t0, per_M, per_j0, per_n;
 };
 
 // The plan of one (block, voice).  In HBM it is split into three arrays so that K1 (one lane per voice)

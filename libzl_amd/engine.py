@@ -180,8 +180,8 @@ class SamplerSynth:
         self._ck(self._lib.zlhip_voice_reports(self._e, arr, self.num_voices), "voice_reports")
         return arr
 
-    def enable_trace(self, enable: bool = True, force_slow: bool = False):
-        self._ck(self._lib.zlhip_debug_enable_trace(self._e, (1 if enable else 0) | (2 if force_slow else 0)), "enable_trace")
+    def enable_trace(self, enable: bool = True, force_slow: bool = False, no_periodic: bool = False):
+        self._ck(self._lib.zlhip_debug_enable_trace(self._e, (1 if enable else 0) | (2 if force_slow else 0) | (4 if no_periodic else 0)), "enable_trace")
 
     def read_trace(self) -> np.ndarray:
         K, N = self._last

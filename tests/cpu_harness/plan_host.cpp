@@ -180,12 +180,12 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
         ZlAssembler as;
         as.begin(A, v, 0, K);
         for (int k = 0; k < K; ++k) {
-            int j0 = 0, n_active = 0;
-            if (as.block(A, k, j0, n_active) <= 2) continue;
+            int idx0 = 0, base0 = 0, n_active = 0;
+            if (as.block(A, k, idx0, base0, n_active) <= 2) continue;
             ++S->expanded;
             const size_t pidx = (size_t)k * V + (size_t)v;
             for (int f = 0; f < N; ++f) {
-                S->ctlP[pidx * (size_t)N + f] = zl_expand_frame(A, v, k, j0, as.rl.nts, f < n_active ? f : 0);
+                S->ctlP[pidx * (size_t)N + f] = zl_expand_frame(as.ss, N, k, idx0, base0, f < n_active ? f : 0);
                 S->ctlEnv[pidx * (size_t)N + f] = as.env;
             }
         }
@@ -222,6 +222,8 @@ unsigned long long zlsim_source_bytes(ZlSim *S) { return S->stats.source_bytes; 
 // segments used by (block, voice) of the last batch (0 for slow / inactive blocks)
 int zlsim_nseg(ZlSim *S, int k, int v) { return S->planHdr[(size_t)k * S->V + v].nseg; }
 int zlsim_num_runs(ZlSim *S, int v) { return S->runs[(size_t)v].n; }
+int zlsim_num_tsegs(ZlSim *S, int v) { return S->runs[(size_t)v].nts; }
+int zlsim_periodic_segments(ZlSim *S, int v) { return S->runs[(size_t)v].per_n; }
 int zlsim_plan_flags(ZlSim *S, int k, int v) { return S->planHdr[(size_t)k * S->V + v].flags; }
 
 // ---- direct fuzz of the exact-linear-run machinery against the naive recurrence -----------------

@@ -52,6 +52,7 @@ class SimSynth:
         self.s = C.c_void_p(self.l.zlsim_create(num_buses, voices_per_bus, max_sounds, playback_sample_rate, mode, voices_per_task))
         self._last = (0, 0)
         self.force_slow = False
+        self.no_periodic = False
 
     def close(self):
         if self.s:
@@ -79,7 +80,7 @@ class SimSynth:
 
     def render_batch(self, nblocks, nframes, clocks, bus_out_dev=None, stream=None):
         self._bus = np.zeros((self.num_buses, 2, nblocks * nframes), dtype=np.float32)
-        self.l.zlsim_render_batch(self.s, nblocks, nframes, clocks, self._bus.ctypes.data, 1 if self.force_slow else 0)
+        self.l.zlsim_render_batch(self.s, nblocks, nframes, clocks, self._bus.ctypes.data, (1 if self.force_slow else 0) | (2 if self.no_periodic else 0))
         self._last = (nblocks, nframes)
         if bus_out_dev:                                  # "device" buffer of the caller = host memory in this harness
             C.memmove(bus_out_dev, self._bus.ctypes.data, self._bus.nbytes)
@@ -98,8 +99,9 @@ class SimSynth:
         self.l.zlsim_reports(self.s, arr)
         return arr
 
-    def enable_trace(self, enable=True, force_slow=False):
+    def enable_trace(self, enable=True, force_slow=False, no_periodic=False):
         self.force_slow = force_slow
+        self.no_periodic = no_periodic
 
     def read_trace(self):
         K, N = self._last

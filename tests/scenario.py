@@ -131,7 +131,7 @@ def run_oracle(scene: Scene, batch: int = 1 << 30, threads: int = 1, fast: bool 
 
 
 def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bool = False, force_slow: bool = False,
-                pipelined: bool = False, **factory_kw):
+                pipelined: bool = False, no_periodic: bool = False, **factory_kw):
     """factory(**kwargs) -> object with the libzl_amd.SamplerSynth surface (engine or CPU harness).
     pipelined (GPU engine only): every call renders into its own device buffer on one HIP stream and nothing is read
     back or synchronised until the end, so consecutive zlhip_render_batch calls overlap."""
@@ -148,8 +148,8 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
         if i in scene.clip_setup:
             scene.clip_setup[i](ref.lib, ref.clips[i])
         syn.set_clip_params(i, snapshot_clip(ref.clips[i]))
-    if trace or force_slow:
-        syn.enable_trace(True, force_slow=force_slow)
+    if trace or force_slow or no_periodic:
+        syn.enable_trace(trace or force_slow, force_slow=force_slow, no_periodic=no_periodic)
     buses, traces = [], []
     if pipelined:
         import torch

@@ -110,7 +110,10 @@ def test_segment_table_overflow(Engine, window):
     for ev in sc.events[0]:
         ev[1]["looping"] = 1
     ref_bus, ref_rep, ref_syn = run_oracle(sc)
-    bus, rep, syn, _ = run_backend(sc, Engine, batch=1500, plan_window_blocks=window)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=1500, plan_window_blocks=window, no_periodic=True)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    syn.close()
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=1500, plan_window_blocks=window)          # periodic loops: one pass planned per window
     compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
     syn.close()
 

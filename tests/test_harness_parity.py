@@ -72,16 +72,38 @@ def test_steady_state_uses_runs_not_per_block_plans(Sim):
     assert playing and all(1 <= syn.l.zlsim_num_runs(syn.s, v) <= 6 for v in playing)      # inline runs
 
 
-def test_segment_table_overflow_falls_back_to_simulation(Sim):
-    """Short pitched loops over one long window: thousands of linear segments per voice.  When a voice's segment
-    table (ZL_MAXTSEG) is full the rest of its window is simulated per frame -- same audio as the oracle."""
+def _short_pitched_loops():
     sc = random_scene(510, nclips=8, min_len=700, max_len=1500, nblocks=1500, nframes=64, events=False)
     for ev in sc.events[0]:
         ev[1]["looping"] = 1
+    return sc
+
+
+def test_segment_table_overflow_falls_back_to_simulation(Sim):
+    """Short pitched loops over one long window, planned pass by pass (test hook): thousands of linear segments per
+    voice.  When a voice's segment table (ZL_MAXTSEG) is full the rest of its window is simulated per frame -- same
+    audio as the oracle."""
+    sc = _short_pitched_loops()
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Sim, batch=1500, no_periodic=True)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    assert syn.slow_blocks() > 100                                # the fallback was exercised
+
+
+def test_periodic_loops_are_planned_once_per_window(Sim):
+    """A sample-space loop in sustain repeats exactly: K1 plans one pass and K1c replays it (same scene as above:
+    no table overflow, a few dozen segments per voice instead of thousands, same audio)."""
+    sc = _short_pitched_loops()
     ref_bus, ref_rep, ref_syn = run_oracle(sc)
     bus, rep, syn, _ = run_backend(sc, Sim, batch=1500)
     compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
-    assert syn.slow_blocks() > 100                                # the fallback was exercised
+    playing = [v for v in range(syn.num_voices) if rep[v].playing]
+    periodic = [v for v in playing if syn.l.zlsim_periodic_segments(syn.s, v) > 0]
+    assert len(periodic) >= len(playing) // 2                     # beat-locked loops are clock-driven, not periodic
+    assert all(syn.l.zlsim_num_tsegs(syn.s, v) < 200 for v in periodic)
+    # the same in several windows / calls: the window-end state of a periodic voice is the exact recurrence value
+    bus2, rep2, syn2, _ = run_backend(sc, Sim, batch=97)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus2, rep2, sc.num_buses * sc.voices_per_bus)
 
 
 def test_no_free_voice_drops_command_like_reference(Sim):

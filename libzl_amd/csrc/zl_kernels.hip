@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
 // wave), ZL_K1C_BLOCKS consecutive blocks per wave (one binary search per lane, then a forward walk).  Blocks with
 // more than two position segments (the block after a loop restart at a small position crosses ~log2(N) binades)
 // are expanded into per-frame control by the whole wave, lanes over frames, so that K2 keeps one pipelined path.
-#define ZL_K1C_BLOCKS 16
+#define ZL_K1C_BLOCKS 8
 __global__ void __launch_bounds__(64) zl_k1c_assemble(const ZlBatch A)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;

@@ -683,6 +683,12 @@ struct ZlAssembler {
         env = A.vconst[v].env;
         idx = -1; base = 0;
         if (kbeg >= kend || rl.nts <= 0) { kend = kbeg; return; }
+        // the whole chunk inside one inline run (the steady state of unpitched playback): nothing to assemble
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < ZL_MAXRUNS; ++q)
+            if (q < rl.n && kbeg >= rl.r[q].k0 && kend <= rl.r[q].k1) { kend = kbeg; return; }
         if (!ss.locate(kbeg * A.N, idx, base)) kend = kbeg;       // cannot happen: the stream starts at t = 0
     }
 

@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 VOICE_STATE_BYTES = 104        # sizeof(ZlVoiceState)
 
 
-def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, seed, bpm=120, notes=(60, 60), source_rate=None):
+def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, seed, bpm=120, notes=(60, 60), source_rate=None, mono=False):
     """Registers one distinct stereo loop per voice (generated on the device) and starts every voice.
     `notes` = inclusive MIDI-note range drawn per voice (root note 60: 48..72 is pitch ratio 0.5..2)."""
     source_rate = source_rate or fs
@@ -51,7 +51,7 @@ def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, see
     g.manual_seed(seed)
     for v in range(V):
         src = torch.rand((2, loop_frames), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0
-        cid = syn.register_clip_device(src[0].data_ptr(), src[1].data_ptr(), loop_frames, source_rate)
+        cid = syn.register_clip_device(src[0].data_ptr(), None if mono else src[1].data_ptr(), loop_frames, source_rate)
         assert cid == v
         del src
     torch.cuda.synchronize()
@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--fs", type=float, default=48000.0)
     ap.add_argument("--loop-seconds", type=float, default=2.0)
     ap.add_argument("--notes", default="60,60", help="MIDI note range per voice (root 60); 48,72 = pitch ratio 0.5..2 (config 4)")
+    ap.add_argument("--mono", action="store_true", help="mono sources (non-default variant)")
     ap.add_argument("--hermite", action="store_true", help="4-tap Hermite interpolation (ZLHIP_MODE_HERMITE, config 4)")
     ap.add_argument("--source-rate", type=float, default=0.0, help="sample rate of the sources (default: --fs)")
     ap.add_argument("--voices-per-task", type=int, default=0)
@@ -185,7 +186,7 @@ def main():
     syn = SamplerSynth(B, vpb, max_frames=N, max_batch_blocks=KB, max_sounds=V, mode=(4 if args.hermite else 0), playback_sample_rate=args.fs,
                        sound_arena_bytes=arena, voices_per_task=args.voices_per_task, plan_window_blocks=args.plan_window, device=local_rank)
     seed = 0x5A17 + 2 + 1000 * rank
-    build_scene(syn, torch, dev, vpb, B, args.fs, loop_frames, seed, notes=notes, source_rate=source_rate)
+    build_scene(syn, torch, dev, vpb, B, args.fs, loop_frames, seed, notes=notes, source_rate=source_rate, mono=args.mono)
     syn.set_profiling(not os.environ.get('ZL_BENCH_NOPROF'))      # diagnostic switch: cost of the per-launch HIP events
 
     # the engine renders into a torch-owned device buffer so the RCCL reduce needs no copy
@@ -282,7 +283,7 @@ def main():
     # HBM traffic of K2 per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process):
     # traffic / algorithmic measured on this workload, applied to this run's algorithmic bytes; null for other workloads
     traffic = None
-    default_workload = (V, B, N, KB, args.loop_seconds, notes, args.hermite, source_rate) == (1024, 8, 256, 8192, 2.0, (60, 60), False, args.fs)
+    default_workload = (V, B, N, KB, args.loop_seconds, notes, args.hermite, source_rate, args.mono) == (1024, 8, 256, 8192, 2.0, (60, 60), False, args.fs, False)
     pmc_file = os.path.join(ROOT, "profiles", "round1_c_pmc.json")
     if default_workload and os.path.exists(pmc_file):
         traffic = json.load(open(pmc_file))["traffic_over_algorithmic"] * k2_bytes
@@ -294,7 +295,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{V} looping stereo voices per GPU on {B} buses x {vpb}, {N}-frame blocks, {KB} blocks per step ({launches} K2 launches), "
+                "workload": f"{V} looping {'mono' if args.mono else 'stereo'} voices per GPU on {B} buses x {vpb}, {N}-frame blocks, {KB} blocks per step ({launches} K2 launches), "
                             + (f"fs=sr={args.fs:.0f} (ratio 1)" if notes[0] == notes[1] and source_rate == args.fs else
                                f"fs={args.fs:.0f}, sources at {source_rate:.0f}, MIDI notes {notes[0]}..{notes[1]} around root 60") +
                             f", {'4-tap Hermite' if args.hermite else 'linear'} interp, faithful mode, distinct {args.loop_seconds:g} s sources "

@@ -301,6 +301,71 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
     if (PK) { accL = acc.x; accR = acc.y; }
 }
 
+// The same for chunks of mono sources: an 8-byte gather [x0 x1] (16 bytes [x-1 x0 x1 x2] for Hermite), r = l (:205, Q4).
+template <uint32_t MODE, bool SEG2, int U>
+static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
+                                                                int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
+{
+    constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
+    zl_f4a4 d4[HERM ? U : 1];
+    zl_f2a4b d2[HERM ? 1 : U];
+    float alpha[U];
+    int   widem = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = c0 + u;
+        double P;
+        if (SEG2) {
+            const bool seg1 = f >= s_plan[i].n1;
+            P = fma((double)(f - (seg1 ? s_plan[i].n1 : 0)), seg1 ? s_plan[i].step1 : s_plan[i].step, seg1 ? s_plan[i].P1 : s_plan[i].P0);
+        } else {
+            P = fma(fd, s_plan[i].step, s_plan[i].P0);            // exact, see zl_plan.h
+        }
+        const int pos = (int)P;                                   // :198-199 (P >= 0)
+        alpha[u] = (float)__builtin_amdgcn_fract(P);
+        const int dur = s_vc[i].sample_duration;
+        const bool inb = dur > pos;                               // :204 guard (Q5)
+        int p = inb ? pos : dur + 1;                              // out of range: the zero padding behind the source
+        const uint64_t so = s_vc[i].src_offset;
+        const float *src = A.arena + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(so >> 32)) << 32)
+                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)so));
+        if (HERM) {
+            const bool wide = inb && pos >= 1 && pos + 2 <= dur;
+            p -= wide ? 1 : 0;
+            d4[u] = *reinterpret_cast<const zl_f4a4 *>(src + (size_t)p);
+            widem |= wide ? (1 << u) : 0;
+        } else {
+            d2[u] = *reinterpret_cast<const zl_f2a4b *>(src + (size_t)p);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = c0 + u;
+        const bool wide = (widem >> u) & 1;
+        ZlTaps t;
+        t.x0r = t.x1r = t.xmr = t.x2r = 0.0f;
+        if (HERM) {
+            t.xml = d4[u].x;
+            t.x0l = wide ? d4[u].y : d4[u].x;
+            t.x1l = wide ? d4[u].z : d4[u].y;
+            t.x2l = d4[u].w;
+        } else {
+            t.x0l = d2[u].x; t.x1l = d2[u].y;
+            t.xml = t.x2l = 0.0f;
+        }
+        float l, r;
+        zl_mix_frame<MODE>(t, alpha[u], true, wide, false, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env,
+                           s_vc[i].clip_volume, s_vc[i].lpan, s_vc[i].rpan, l, r);
+        accL += l; accR += r;                                     // :218-221 (index shift applied at the store)
+        if (wantPeak) {                                           // :213-216, signed peak from 0 (Q6)
+            const float ng = l + r;
+            float pk = ng > 0.0f ? ng : 0.0f;
+            pk = zl_wave_max(pk);
+            if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[vfirst + i].peak_bits, __float_as_uint(pk));
+        }
+    }
+}
+
 template <uint32_t MODE, bool CTL, int U>
 static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
                                                     const int *s_cls, int c0, size_t pbase, int vfirst, int f, bool wantPeak,
@@ -433,21 +498,24 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
                 if (kk < A.K) pl = zl_plan_lookup(A, kk, vb + i, vc.env);   // implied by a run, explicit, or idle
             }
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
-            // 4 = "simple": whole block, sustain, stereo (and no debug trace); 8 = it has a second position segment
+            // 4 = "simple": whole block, sustain (and no debug trace); 8 = it has a second position segment; 16 = mono source
             const float gprod = vc.lgain * vc.rgain * vc.clip_volume * pl.env;     // finite iff every factor is (or one is 0 * inf = NaN)
-            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && vc.channels == 2 && !A.trace && (gprod - gprod) == 0.0f)
-                cls |= 4 | (pl.nseg == 2 ? 8 : 0);
+            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && (vc.channels == 1 || vc.channels == 2) && !A.trace && (gprod - gprod) == 0.0f)
+                cls |= 4 | (pl.nseg == 2 ? 8 : 0) | (vc.channels == 1 ? 16 : 0);
             if (b == 0) s_vc[i] = vc;
             s_plan_[b][i] = pl;                   // idle slots: a harmless record with no active frame
             s_cls_[b][i] = cls;
-            // class of each chunk of U voices: OR of bits 1, 2, 8 and AND of bit 4 (ballots over the wave's 64 voices)
-            const unsigned long long m1 = __ballot(cls & 1), m2 = __ballot(cls & 2), m4 = __ballot(cls & 4), m8 = __ballot(cls & 8);
+            // class of each chunk of U voices: OR of bits 1, 2, 8; 4 = every voice simple and of one source layout, 16 = all
+            // mono (ballots over the wave's 64 voices)
+            const unsigned long long m1 = __ballot(cls & 1), m2 = __ballot(cls & 2), m4 = __ballot(cls & 4), m8 = __ballot(cls & 8),
+                                     m16 = __ballot(cls & 16);
             const int lane = i & 63;
             if (lane < 64 / U) {
                 const unsigned long long full = (1ull << U) - 1ull;
                 const int sh = lane * U;
+                const unsigned long long mono = (m16 >> sh) & full;
                 const int cc = (((m1 >> sh) & full) ? 1 : 0) | (((m2 >> sh) & full) ? 2 : 0) | (((m8 >> sh) & full) ? 8 : 0)
-                             | ((((m4 >> sh) & full) == full) ? 4 : 0);
+                             | (((((m4 >> sh) & full) == full) && (mono == 0 || mono == full)) ? 4 : 0) | (mono == full ? 16 : 0);
                 s_chunk_[b][(i >> 6) * (64 / U) + lane] = cc;
             }
         }
@@ -462,8 +530,10 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
 #ifdef ZL_STAMPS
             zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
 #endif
-            if ((cc & 12) == 4)  zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else if (cc & 4) zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            if ((cc & 28) == 4)       zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 4)  zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 28) == 20) zl_k2_chunk_simple_mono<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 20) zl_k2_chunk_simple_mono<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
             else {
                 // general chunks (events, second segments, mono sources, per-frame control) are rare: run them as
                 // two half-chunks so their extra per-voice registers do not set the kernel's register budget

@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reuse-check", action="store_true", help="skip the auxiliary 10 s-loop measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the measured path) or gloo (rehearsal: reduce through host memory)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -268,6 +269,29 @@ def main():
         copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
 
+    # the same kernel with sources that are not re-read inside a plan window (10 s instead of 2 s loops: the Infinity
+    # Cache cannot help): an auxiliary figure next to the headline one, N = 1 only, a few steps after the timed region
+    no_reuse = None
+    if rank == 0 and not distributed and not args.no_reuse_check and args.loop_seconds < 10.0:
+        lf2 = int(10.0 * source_rate)
+        syn2 = SamplerSynth(B, vpb, max_frames=N, max_batch_blocks=KB, max_sounds=V, mode=(4 if args.hermite else 0),
+                            playback_sample_rate=args.fs, sound_arena_bytes=(lf2 + 16) * (4 if args.mono else 8) * V + (1 << 20),
+                            voices_per_task=args.voices_per_task, plan_window_blocks=args.plan_window, device=local_rank)
+        build_scene(syn2, torch, dev, vpb, B, args.fs, lf2, seed + 7, notes=notes, source_rate=source_rate, mono=args.mono)
+        syn2.set_profiling(True)
+        for i in range(2):
+            syn2.render_batch(KB, N, clock_sets[i % len(clock_sets)], bus_out_dev=bus.data_ptr(), stream=sptr)
+        syn2.profile_totals(reset=True)
+        for i in range(4):
+            syn2.render_batch(KB, N, clock_sets[(2 + i) % len(clock_sets)], bus_out_dev=bus.data_ptr(), stream=sptr)
+        t2, n2 = syn2.profile_totals()
+        b2 = (t2.source_bytes + n2 * B * 2 * N * 4 * KB) / max(1, t2.render_launches)
+        ms2 = t2.render_ms / max(1, t2.render_launches)
+        g2 = b2 / (ms2 * 1e-3) / 1e9
+        no_reuse = {"loop_seconds": 10.0, "achieved": g2, "frac": g2 / HBM_PEAK_GBS, "avg_launch_ms": ms2,
+                    "value": float(V) * KB * N * n2 / (t2.total_ms * 1e-3) if t2.total_ms > 0 else None}
+        syn2.close()
+
     total_vs = float(V) * world * KB * N * args.steps
     value = total_vs / dt
     # algorithmic bytes of the K2 launches of one step: every source frame once per block
@@ -306,6 +330,7 @@ def main():
                 "bound": "hbm", "kernel": "zl_k2_render", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/round1_c_pmc.json: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic = 1.061 on this workload" if traffic else None,
+                "no_reuse_variant": no_reuse,
                 "device_copy_GBs": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                 "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_avg_ms, "launches_per_step": launches,
                 "bytes_per_voice_sample": k2_bytes_step / (V * KB * N),

@@ -5,7 +5,7 @@ ARGS=$1; shift
 mkdir -p gpurun_out
 for round in 1 2; do
   for lib in "$@"; do
-    ZLHIP_LIBRARY=$PWD/$lib timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 $ARGS > gpurun_out/ab_tmp.json 2>gpurun_out/ab_err.log || { echo "FAILED $lib"; tail -3 gpurun_out/ab_err.log; continue; }
+    ZLHIP_LIBRARY=$PWD/$lib timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --steps 8 --warmup 2 $ARGS > gpurun_out/ab_tmp.json 2>gpurun_out/ab_err.log || { echo "FAILED $lib"; tail -3 gpurun_out/ab_err.log; continue; }
     python3 - "$lib" <<'PY'
 import json,sys
 d=json.load(open("gpurun_out/ab_tmp.json")); r=d["roofline"]

@@ -55,6 +55,7 @@ struct zlhip_engine {
     size_t windowFrames = 0;             // else a window is this many frames: 2048 blocks of 256 frames, more blocks when they are shorter
     int windowCap = 0;                   // blocks the K1 -> K2 record arrays hold
     hipStream_t planStream = nullptr;    // K0 + K1 (sequential per voice)
+    hipStream_t lastPlanStream = nullptr; hipEvent_t evPlanTail = nullptr;   // where the previous call planned (voice-state order)
     hipStream_t asmStream = nullptr;     // K1c of window w runs here, next to K1 of window w+1
     std::vector<std::pair<int, int>> wins;
     // Per-call resources, double buffered so that consecutive zlhip_render_batch calls pipeline: the host prepares
@@ -206,6 +207,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     void *host[] = { e->hBus, e->hLevelState };
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (e->evJoin) (void)hipEventDestroy(e->evJoin);
+    if (e->evPlanTail) (void)hipEventDestroy(e->evPlanTail);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -316,6 +318,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     if (rc == ZLHIP_OK) chk(hipHostGetDevicePointer((void **)&e->hBusDev, e->hBus, 0), "map hBus");
     chk(hipHostMalloc((void **)&e->hLevelState, B * sizeof(ZlLevelsState)), "hLevelState");
     chk(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming), "hipEventCreate");
+    chk(hipEventCreateWithFlags(&e->evPlanTail, hipEventDisableTiming), "hipEventCreate");
     if (rc == ZLHIP_OK) {
         chk(hipMemsetAsync(e->dSounds, 0, (size_t)cfg->max_sounds * sizeof(ZlSound), e->stream), "memset sounds");
         chk(hipMemsetAsync(e->dClips, 0, (size_t)cfg->max_sounds * sizeof(ZlClip), e->stream), "memset clips");
@@ -603,6 +606,9 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     hipStream_t ps = overlap ? e->planStream : s;
     // The call's inputs (clocks, voice operations, cleared statistics) go to the planning stream itself: it is in order
     // with the planning of the previous call, so window 0 of this call is planned while the previous call still renders.
+    // the voice state is carried from call to call by K1: when this call plans on another stream than the previous one
+    // did, order it behind that call's last planning kernel
+    if (e->lastPlanStream && e->lastPlanStream != ps) ZL_HIP(e, hipStreamWaitEvent(ps, e->evPlanTail, 0));
     ZL_HIP(e, hipMemcpyAsync(c.dClocks, c.hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, ps));
     int rc = upload_ops(e, A, ps);
     if (rc != ZLHIP_OK) return rc;
@@ -649,6 +655,8 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         q.used = true;
     }
     c.windows = nwin;
+    ZL_HIP(e, hipEventRecord(e->evPlanTail, ps));
+    e->lastPlanStream = ps;
     if (e->ps[1].hdr != nullptr) e->setPhase = (phase + (unsigned)nwin) & 1u;
     // results go straight to mapped host memory (a copy command here would make the runtime wait for the stream)
     ZL_KERNEL(e, zl_launch_reports(c.dReports, e->V, e->dGain, c.hReportsDev, c.hGainDev, c.dStats, c.hStatsDev, s));

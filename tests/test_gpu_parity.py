@@ -148,6 +148,16 @@ def test_back_to_back_calls_pipeline(Engine, seed, events):
     syn.close()
 
 
+def test_single_window_calls_pipeline(Engine):
+    """Calls of one plan window each, queued back to back: the first is planned on the caller's stream, the following
+    ones on the planning stream while their predecessor renders (the voice state is handed over between the streams)."""
+    sc = random_scene(4200, nframes=128, nblocks=2400, nclips=10, min_len=3000, max_len=40000, events=False)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=600, pipelined=True)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    syn.close()
+
+
 def test_profile_totals_sum_over_pipelined_calls(Engine):
     from libzl_amd.engine import synthetic_clocks
     sc = random_scene(4103, nframes=128, nblocks=8, events=False)

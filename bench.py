@@ -308,7 +308,7 @@ def main():
     # traffic / algorithmic measured on this workload, applied to this run's algorithmic bytes; null for other workloads
     traffic = None
     default_workload = (V, B, N, KB, args.loop_seconds, notes, args.hermite, source_rate, args.mono) == (1024, 8, 256, 8192, 2.0, (60, 60), False, args.fs, False)
-    pmc_file = os.path.join(ROOT, "profiles", "round1_c_pmc.json")
+    pmc_file = os.path.join(ROOT, "profiles", "round1_d_pmc.json")
     if default_workload and os.path.exists(pmc_file):
         traffic = json.load(open(pmc_file))["traffic_over_algorithmic"] * k2_bytes
 
@@ -329,7 +329,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "zl_k2_render", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/round1_c_pmc.json: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic = 1.061 on this workload" if traffic else None,
+                "traffic_source": "profiles/round1_d_pmc.json: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic = 1.061 on this workload" if traffic else None,
                 "no_reuse_variant": no_reuse,
                 "device_copy_GBs": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                 "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_avg_ms, "launches_per_step": launches,

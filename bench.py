@@ -347,6 +347,7 @@ def main():
         print(json.dumps(out))
     syn.close()
     if distributed:
+        dist.barrier()                       # rank 0 is still timing the CPU baseline: leave the group together
         dist.destroy_process_group()
 
 

@@ -325,6 +325,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         chk(hipMemsetAsync(e->dVoices, 0, V * sizeof(ZlVoiceState), e->stream), "memset voices");
         chk(hipMemsetAsync(e->dLevelState, 0, B * sizeof(ZlLevelsState), e->stream), "memset levels");
         for (auto &c : e->slots) chk(hipMemsetAsync(c.dReports, 0, V * sizeof(ZlReport), e->stream), "memset reports");
+        for (auto &c : e->slots) chk(hipMemsetAsync(c.dStats, 0, sizeof(ZlBatchStats), e->stream), "memset stats");
         chk(hipMemsetAsync(e->dBus, 0, B * 2 * K * N * sizeof(float), e->stream), "memset bus");
         chk(hipStreamSynchronize(e->stream), "sync");
     }
@@ -609,10 +610,11 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     // the voice state is carried from call to call by K1: when this call plans on another stream than the previous one
     // did, order it behind that call's last planning kernel
     if (e->lastPlanStream && e->lastPlanStream != ps) ZL_HIP(e, hipStreamWaitEvent(ps, e->evPlanTail, 0));
-    ZL_HIP(e, hipMemcpyAsync(c.dClocks, c.hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, ps));
+    if (nblocks == 1) { A.inline_clock = 1; A.clock0 = c.hClocks[0]; A.fuse_assemble = 1; }   // a real-time block: fewer commands
+    else ZL_HIP(e, hipMemcpyAsync(c.dClocks, c.hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, ps));
     int rc = upload_ops(e, A, ps);
     if (rc != ZLHIP_OK) return rc;
-    ZL_HIP(e, hipMemsetAsync(c.dStats, 0, sizeof(ZlBatchStats), ps));
+    // (the slot's statistics were cleared by the report kernel of the call that used it before)
     if (e->profiling) ZL_HIP(e, hipEventRecord(c.evBegin, s));
     // the record sets alternate across calls too, so that the first window of this call is not planned into the set
     // the previous call's last window still renders from
@@ -632,19 +634,19 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         if (ps != s && q.used) ZL_HIP(e, hipStreamWaitEvent(ps, q.rendered, 0));
         ZL_KERNEL(e, zl_launch_apply_ops(Aw, ps));
         ZL_KERNEL(e, zl_launch_plan(Aw, e->forceSlow, ps));
-        if (ps != s && e->asmStream) {
+        if (ps != s && e->asmStream && !Aw.fuse_assemble) {
             // K1c (lane-parallel) on its own stream: it runs next to K1 of the following window, which writes the other set
             ZL_HIP(e, hipEventRecord(q.k1done, ps));
             ZL_HIP(e, hipStreamWaitEvent(e->asmStream, q.k1done, 0));
             ZL_KERNEL(e, zl_launch_assemble(Aw, e->asmStream));
             ZL_HIP(e, hipEventRecord(q.planned, e->asmStream));
             ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
-        } else if (ps != s) {
-            ZL_KERNEL(e, zl_launch_assemble(Aw, ps));
-            ZL_HIP(e, hipEventRecord(q.planned, ps));
-            ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
         } else {
-            ZL_KERNEL(e, zl_launch_assemble(Aw, s));
+            if (!Aw.fuse_assemble) ZL_KERNEL(e, zl_launch_assemble(Aw, ps));
+            if (ps != s) {
+                ZL_HIP(e, hipEventRecord(q.planned, ps));
+                ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
+            }
         }
         if (e->profiling) ZL_HIP(e, hipEventRecord(c.evK2[2 * (size_t)w], s));
         ZL_KERNEL(e, zl_launch_render(Aw, s));

@@ -32,6 +32,29 @@ __global__ void zl_k0_apply_ops(const ZlBatch A)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1c body for one wave: block k of the wave's 64 voices (one lane each).  Blocks with more than two position
+// segments are expanded into per-frame control by the whole wave, lanes over frames.
+static __device__ __forceinline__ void zl_k1c_block(const ZlBatch &A, ZlAssembler &as, int v, int lane, int k)
+{
+    int idx0 = 0, base0 = 0, n_active = 0;
+    const int nseg = as.block(A, k, idx0, base0, n_active);
+    unsigned long long m = __ballot(nseg > 2);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const int vv = __shfl(v, l, 64), ii = __shfl(idx0, l, 64), bb = __shfl(base0, l, 64), na = __shfl(n_active, l, 64);
+        const float env = __shfl(as.env, l, 64);
+        ZlSegStream ss;
+        ss.init(A, vv, A.runs[vv]);
+        const size_t base = ((size_t)k * A.V + vv) * (size_t)A.N;
+        for (int f = lane; f < A.N; f += 64) {
+            A.ctl_P[base + f] = zl_expand_frame(ss, A.N, k, ii, bb, f < na ? f : 0);
+            A.ctl_env[base + f] = env;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1: one lane per voice; the block clocks are staged in LDS so the per-block step of the planner
 // makes no dependent global load.  Cost is O(linear runs + events) per voice, not O(blocks) (zl_plan.h).
 #define ZL_K1_CLOCKS 256
@@ -45,7 +68,9 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
     for (int kb = 0; kb < A.K; kb += ZL_K1_CLOCKS) {
         const int nk = (A.K - kb < ZL_K1_CLOCKS) ? A.K - kb : ZL_K1_CLOCKS;
         __syncthreads();
-        {
+        if (A.inline_clock) {
+            if (threadIdx.x == 0) s_clk[0] = A.clock0;             // a single real-time block: no clock upload
+        } else {
             const uint4 *g = reinterpret_cast<const uint4 *>(A.clocks + kb);
             uint4 *sh = reinterpret_cast<uint4 *>(s_clk);
             for (int i = threadIdx.x; i < nk * (int)(sizeof(ZlClock) / 16); i += blockDim.x) sh[i] = g[i];
@@ -65,6 +90,13 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
             if (pl.stats.active_frames) atomicAdd(&A.stats->active_frames, pl.stats.active_frames);
         }
     }
+    if (A.fuse_assemble) {
+        // a single block: K1c's work for the wave's voices is done here (their records were written by this wave)
+        __threadfence();
+        ZlAssembler as;
+        as.begin(A, mine ? v : 0, 0, mine ? A.K : 0);
+        for (int k = 0; k < A.K; ++k) zl_k1c_block(A, as, v, threadIdx.x, k);
+    }
 }
 
 // K1c: segment streams -> per-block plan records.  One lane per voice (coalesced 16-byte plan stores across the
@@ -81,24 +113,7 @@ __global__ void __launch_bounds__(64) zl_k1c_assemble(const ZlBatch A)
     const int kend = kbeg + ZL_K1C_BLOCKS < A.K ? kbeg + ZL_K1C_BLOCKS : A.K;
     ZlAssembler as;
     as.begin(A, mine ? v : 0, kbeg, mine ? kend : kbeg);
-    for (int k = kbeg; k < kend; ++k) {
-        int idx0 = 0, base0 = 0, n_active = 0;
-        const int nseg = as.block(A, k, idx0, base0, n_active);
-        unsigned long long m = __ballot(nseg > 2);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const int vv = __shfl(v, l, 64), ii = __shfl(idx0, l, 64), bb = __shfl(base0, l, 64), na = __shfl(n_active, l, 64);
-            const float env = __shfl(as.env, l, 64);
-            ZlSegStream ss;
-            ss.init(A, vv, A.runs[vv]);
-            const size_t base = ((size_t)k * A.V + vv) * (size_t)A.N;
-            for (int f = lane; f < A.N; f += 64) {
-                A.ctl_P[base + f] = zl_expand_frame(ss, A.N, k, ii, bb, f < na ? f : 0);
-                A.ctl_env[base + f] = env;
-            }
-        }
-    }
+    for (int k = kbeg; k < kend; ++k) zl_k1c_block(A, as, v, lane, k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,7 +701,11 @@ __global__ void zl_k_reports(const ZlReport *reports, int V, float *gain_out, Zl
                              const ZlBatchStats *stats, ZlBatchStats *host_stats)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v == 0 && host_stats) *host_stats = *stats;
+    if (v == 0 && host_stats) {
+        *host_stats = *stats;
+        ZlBatchStats z; z.source_bytes = 0; z.slow_blocks = 0; z.active_frames = 0;
+        *const_cast<ZlBatchStats *>(stats) = z;                    // cleared for the call that reuses this slot
+    }
     if (v >= V) return;
     const ZlReport r = reports[v];
     const float g = __uint_as_float(r.peak_bits) * 0.5f;

@@ -168,6 +168,9 @@ struct ZlBatch {
     uint32_t mode;
     int32_t n_op_ranges;
     int32_t trace;                // 1 = write pos trace
+    int32_t inline_clock;         // 1: the (single) block's clock travels in clock0 with the kernel arguments
+    int32_t fuse_assemble;        // 1: K1 assembles the plan records itself (single real-time block: one launch less)
+    ZlClock clock0;
     const ZlClock      *clocks;   // [K]
     const ZlSound      *sounds;
     const ZlClip       *clips;

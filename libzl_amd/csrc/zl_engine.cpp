@@ -585,6 +585,7 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     // nothing but the previous call: windows start at 256 blocks and double up to the configured size.
     int W = e->windowBlocks > 0 ? e->windowBlocks : (int)std::max<size_t>(1, e->windowFrames / (size_t)nframes);
     W = std::min(W, e->windowCap);
+    W = std::min(W, (1 << 30) / nframes);                          // window time is a 32-bit frame index in K1 / K1c
     std::vector<std::pair<int, int>> &wins = e->wins;              // (first block, blocks); member: no allocation per call
     wins.clear();
     // when the previous call is still in flight its rendering hides the planning of this call's first window: no

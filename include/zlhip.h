@@ -173,6 +173,13 @@ int zlhip_handle_command(zlhip_engine *e, const zlhip_clip_command *cmd, uint64_
 /* Same, addressed to an explicit voice slot of a bus (bypasses first-free allocation; used to
  * build large synthetic scenes deterministically). */
 int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd, uint64_t current_tick);
+/* The voice-level calls behind the JUCE SynthesiserVoice surface of SamplerSynthVoice (include/zlhip_voice_adapter.h):
+ * stopNote(velocity, allowTailOff) (SamplerSynthVoice.cpp:146-169), setCurrentCommand on a playing voice (:58-93) and
+ * the isPlaying flag (SamplerSynthVoice.h:31).  They apply before the next rendered block.  Return 1 / 0 (the voice
+ * was playing / was not), < 0 on error. */
+int zlhip_stop_voice(zlhip_engine *e, int32_t bus, int32_t slot, int allow_tail_off);
+int zlhip_update_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd);
+int zlhip_voice_is_playing(zlhip_engine *e, int32_t bus, int32_t slot);
 
 /* ---- render -------------------------------------------------------------------------------- */
 /* One real-time block: renders nframes for every bus and copies the mix to host memory.

@@ -112,6 +112,9 @@ SIGNATURES = {
     "zlhip_clip_command_clear": (None, [C.POINTER(ClipCommand)]),
     "zlhip_handle_command": (C.c_int, [_E, C.POINTER(ClipCommand), C.c_uint64]),
     "zlhip_start_voice": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(ClipCommand), C.c_uint64]),
+    "zlhip_stop_voice": (C.c_int, [_E, C.c_int32, C.c_int32, C.c_int]),
+    "zlhip_update_voice": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(ClipCommand)]),
+    "zlhip_voice_is_playing": (C.c_int, [_E, C.c_int32, C.c_int32]),
     "zlhip_render": (C.c_int, [_E, C.c_int32, C.POINTER(Clock), C.c_void_p, C.c_void_p]),
     "zlhip_render_batch": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(Clock), C.c_void_p, C.c_void_p]),
     "zlhip_synchronize": (C.c_int, [_E]),

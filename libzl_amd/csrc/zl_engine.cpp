@@ -473,6 +473,30 @@ int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_cl
     return e->hc.handle_on_bus(bus, *cmd, current_tick, slot);
 }
 
+int zlhip_stop_voice(zlhip_engine *e, int32_t bus, int32_t slot, int allow_tail_off)
+{
+    if (!e || bus < 0 || bus >= e->cfg.num_buses || slot < 0 || slot >= e->cfg.voices_per_bus) return ZLHIP_ERR_INVALID;
+    int rc = refresh_host_voices(e);
+    if (rc != ZLHIP_OK) return rc;
+    return e->hc.stop_voice(bus, slot, allow_tail_off != 0);
+}
+
+int zlhip_update_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd)
+{
+    if (!e || !cmd || bus < 0 || bus >= e->cfg.num_buses || slot < 0 || slot >= e->cfg.voices_per_bus) return ZLHIP_ERR_INVALID;
+    int rc = refresh_host_voices(e);
+    if (rc != ZLHIP_OK) return rc;
+    return e->hc.update_voice(bus, slot, *cmd);
+}
+
+int zlhip_voice_is_playing(zlhip_engine *e, int32_t bus, int32_t slot)
+{
+    if (!e || bus < 0 || bus >= e->cfg.num_buses || slot < 0 || slot >= e->cfg.voices_per_bus) return ZLHIP_ERR_INVALID;
+    int rc = refresh_host_voices(e);
+    if (rc != ZLHIP_OK) return rc;
+    return e->hc.voices[(size_t)(bus * e->cfg.voices_per_bus + slot)].isPlaying ? 1 : 0;
+}
+
 // ---- render ------------------------------------------------------------------------------------
 static int pick_group(const zlhip_engine *e, int K, int N)
 {

@@ -164,6 +164,29 @@ struct ZlHostControl {
         return consumed;
     }
 
+    // SamplerSynthVoice::stopNote on one voice (SamplerSynthVoice.cpp:146-169): with tail-off the envelope is released
+    // and the voice frees itself later; without, it stops before the next block
+    int stop_voice(int bus, int slot, bool allowTailOff)
+    {
+        const int v = bus * voices_per_bus + slot;
+        ZlHostVoice &hv = voices[(size_t)v];
+        if (!hv.isPlaying) return 0;
+        ZlVoiceOp op; std::memset(&op, 0, sizeof op);
+        op.voice = v; op.kind = allowTailOff ? ZL_OP_NOTE_OFF : ZL_OP_HARD_STOP;
+        pendingOps.push_back(op);
+        if (!allowTailOff) hv = ZlHostVoice();
+        return 1;
+    }
+
+    // setCurrentCommand on one playing voice (SamplerSynthVoice.cpp:58-93)
+    int update_voice(int bus, int slot, const zlhip_clip_command &c)
+    {
+        const int v = bus * voices_per_bus + slot;
+        if (!voices[(size_t)v].isPlaying) return 0;
+        push_merge(v, c);
+        return 1;
+    }
+
     int handle_command(const zlhip_clip_command &c, uint64_t tick)
     {
         const int bus = c.midi_channel + 2;                            // SamplerSynth.cpp:330-331

@@ -771,6 +771,8 @@ ZL_HD inline void zl_apply_op(ZlVoiceState &st, const ZlVoiceOp &op)
         st = op.start;                                            // startNote :110-144 computed by the host
     } else if (op.kind == ZL_OP_NOTE_OFF) {
         if (st.playing) zl_adsr_note_off(st);                     // stopNote(0, true) :148-151
+    } else if (op.kind == ZL_OP_HARD_STOP) {
+        if (st.playing) zl_voice_hard_stop(st);                   // stopNote(0, false) :153-168
     } else if (op.kind == ZL_OP_PATCH) {                          // setCurrentCommand merge :58-98
         if (!st.playing) return;
         if (op.patch_mask & ZL_PATCH_LOOPING)  st.looping = op.looping;

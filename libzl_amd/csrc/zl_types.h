@@ -62,7 +62,7 @@ struct ZlVoiceState {
 };
 
 // Host -> device voice operations, applied in order before the next block is planned.
-enum { ZL_OP_START = 1, ZL_OP_NOTE_OFF = 2, ZL_OP_PATCH = 3 };
+enum { ZL_OP_START = 1, ZL_OP_NOTE_OFF = 2, ZL_OP_PATCH = 3, ZL_OP_HARD_STOP = 4 };
 enum { ZL_PATCH_GAIN = 1, ZL_PATCH_LOOPING = 2, ZL_PATCH_SLICE = 4, ZL_PATCH_POSITION = 8 };
 struct ZlVoiceOp {
     int32_t  voice;

@@ -153,6 +153,17 @@ class SamplerSynth:
     def start_voice(self, bus: int, slot: int, cmd: ClipCommand, current_tick: int = 0) -> int:
         return self._ck(self._lib.zlhip_start_voice(self._e, bus, slot, C.byref(cmd), current_tick), "start_voice")
 
+    def stop_voice(self, bus: int, slot: int, allow_tail_off: bool = True) -> int:
+        """SamplerSynthVoice::stopNote on one voice slot."""
+        return self._ck(self._lib.zlhip_stop_voice(self._e, bus, slot, 1 if allow_tail_off else 0), "stop_voice")
+
+    def update_voice(self, bus: int, slot: int, cmd: ClipCommand) -> int:
+        """SamplerSynthVoice::setCurrentCommand on a playing voice."""
+        return self._ck(self._lib.zlhip_update_voice(self._e, bus, slot, C.byref(cmd)), "update_voice")
+
+    def voice_is_playing(self, bus: int, slot: int) -> bool:
+        return self._ck(self._lib.zlhip_voice_is_playing(self._e, bus, slot), "voice_is_playing") == 1
+
     # -- render -----------------------------------------------------------------------------
     def process(self, nframes: int, clock: Clock):
         """One real-time cycle of every SamplerChannel; returns (left[B,N], right[B,N])."""

@@ -26,8 +26,9 @@ def lib(built):
 
 
 def test_every_declared_symbol_is_exported(lib):
-    headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
-    assert headers
+    # the C headers of the boundary (zlhip_voice_adapter.h is a C++ template on top of them, not part of the C-ABI)
+    headers = [h for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))) if "template <" not in open(h).read()]
+    assert len(headers) == 2
     total = 0
     for h in headers:
         fns = declared_functions(h)

@@ -1,0 +1,106 @@
+"""Edge-case scenes shared by the CPU (host harness) and GPU tiers: each builds a small Scene around one unusual
+parameter combination; the oracle defines the expected behaviour, the engine must reproduce it bit for bit."""
+import ctypes as C
+
+import numpy as np
+
+from scenario import Scene, play_cmd, rand_source, stop_cmd
+
+
+def _base(seed, nframes=128, nblocks=14, nsounds=4, length=6000, sr=48000.0, mono=()):
+    rng = np.random.default_rng(seed)
+    sc = Scene(num_buses=2, voices_per_bus=4, fs=48000.0, nframes=nframes, nblocks=nblocks)
+    for i in range(nsounds):
+        L, R = rand_source(rng, length + 37 * i, stereo=(i not in mono))
+        sc.sounds.append((L, R, sr))
+    return sc
+
+
+def _play_all(sc, notes, loop=True, **extra):
+    sc.events[0] = [("cmd", play_cmd(i, midi_channel=(i % 2) - 2, loop=loop, note=notes[i % len(notes)], volume=0.5 + 0.1 * i, **extra), 0)
+                    for i in range(len(sc.sounds))]
+
+
+def extreme_ratios():
+    sc = _base(1)
+    _play_all(sc, [12, 108, 36, 96])               # pitch ratios 2^-4 .. 2^4
+    for i in range(4):
+        sc.clip_setup[i] = lambda lib, clip: lib.zlo_clip_set_length(clip, C.c_float(0.11), 120)
+    return sc
+
+
+def tiny_loops():
+    sc = _base(2, nblocks=10)
+    _play_all(sc, [60, 67, 55, 72])
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = 0.013                               # fractional: sample-space wrap
+            clip.lengthInSeconds = float(np.float32((3 + 2 * i) / 48000.0))   # loops of 3..9 frames
+        sc.clip_setup[i] = setup
+    return sc
+
+
+def stop_beyond_the_file():
+    sc = _base(3, length=1500)
+    _play_all(sc, [60, 64, 57, 70], loop=True)
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = 0.3
+            clip.lengthInSeconds = float(np.float32(0.05 + 0.01 * i))         # 2400+ frames > the 1500-frame file (Q5 zeros)
+        sc.clip_setup[i] = setup
+    return sc
+
+
+def negative_beats_q10():
+    sc = _base(4)
+    _play_all(sc, [60, 62, 58, 65])                # lengthInBeats = -1 (the default): beat-locked with a saturated tick count
+    return sc
+
+
+def start_near_the_end_and_slices():
+    sc = _base(5)
+    sc.events[0] = [("cmd", play_cmd(i, midi_channel=(i % 2) - 2, loop=True, note=60 + i, volume=0.6, changeSlice=1, slice=[15, 0, 7, 14][i]), 0)
+                    for i in range(4)]
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            lib.zlo_clip_set_start_position(clip, C.c_float(0.1))
+            lib.zlo_clip_set_length(clip, C.c_float(0.05), 120)
+        sc.clip_setup[i] = setup
+    return sc
+
+
+def envelopes_at_their_limits():
+    sc = _base(6, nblocks=18)
+    _play_all(sc, [60, 60, 65, 55], loop=False)
+    shapes = [(0.0, 0.0, 1.0, 0.0), (0.01, 0.0, 0.0, 0.02), (0.0, 0.003, 0.2, 0.0), (0.02, 0.02, 1.0, 0.03)]
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            a, d, s, r = shapes[i]
+            clip.adsr.p.attack, clip.adsr.p.decay, clip.adsr.p.sustain, clip.adsr.p.release = a, d, s, r
+            lib.zlo_clip_set_length(clip, C.c_float(0.08), 120)
+        sc.clip_setup[i] = setup
+    sc.events[6] = [("cmd", stop_cmd(i, midi_channel=(i % 2) - 2, note=[60, 60, 65, 55][i]), 0) for i in range(4)]
+    return sc
+
+
+def mono_and_stereo_neighbours():
+    sc = _base(7, nsounds=8, mono=(1, 2, 5))
+    sc.voices_per_bus = 8; sc.num_buses = 1
+    sc.events[0] = [("cmd", play_cmd(i, midi_channel=-2, loop=True, note=57 + i, volume=0.4 + 0.05 * i), 0) for i in range(8)]
+    for i in range(8):
+        sc.clip_setup[i] = lambda lib, clip: lib.zlo_clip_set_length(clip, C.c_float(0.07), 120)
+    return sc
+
+
+def resampled_sources():
+    sc = _base(8, sr=22050.0)
+    sc.sounds[1] = (sc.sounds[1][0], sc.sounds[1][1], 96000.0)
+    sc.sounds[2] = (sc.sounds[2][0], sc.sounds[2][1], 44100.0)
+    _play_all(sc, [60, 60, 61, 48])
+    for i in range(4):
+        sc.clip_setup[i] = lambda lib, clip: lib.zlo_clip_set_length(clip, C.c_float(0.09), 120)
+    return sc
+
+
+SCENES = {f.__name__: f for f in (extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
+                                  envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}

@@ -41,6 +41,26 @@ def reduce_bus(bus, dst: int = 0, group=None):
     return bus
 
 
+def reduce_bus_in_rank_order(bus, dst: int = 0, group=None):
+    """Deterministic alternative: the partial buses are gathered onto `dst` and summed there in rank
+    order, ((p0 + p1) + p2) + ..., so the result is the same bits on every run and for every world size -- it equals
+    the oracle's two-level order with one mix group per rank.  Costs world_size x the bus in memory on `dst` and the
+    root's inbound links carry every partial bus; the default `reduce_bus` lets RCCL choose the order."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bus
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [torch.empty_like(bus) for _ in range(world)] if rank == dst else None
+    dist.gather(bus, gather_list=parts, dst=dst, group=group)
+    if rank == dst:
+        acc = parts[0]
+        for p in parts[1:]:
+            acc = acc + p                                  # elementwise fp32 adds in rank order
+        bus.copy_(acc)
+    return bus
+
+
 def render_sharded(synth, nblocks: int, nframes: int, clocks, bus, dst: int = 0, stream=None, group=None):
     """One batch on this rank's voices into `bus` (device pointer of a torch tensor), then the bus reduce;
     on the root the reduced bus is scanned for AudioLevels.  `synth` is a libzl_amd.SamplerSynth."""

@@ -128,6 +128,11 @@ def cpu_baseline(args, seed):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: whatever native libraries print meanwhile (RCCL's version banner
+    # at communicator creation, for one) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -151,6 +156,9 @@ def main():
     ap.add_argument("--no-reuse-check", action="store_true", help="skip the auxiliary 10 s-loop measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the measured path) or gloo (rehearsal: reduce through host memory)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--reduce-algo", default="mesh", choices=["mesh", "reduce", "rank-order"],
+                    help="N > 1: mesh = all-to-all + rank-order sum + gather over the xGMI mesh (default), reduce = one RCCL reduce")
+    ap.add_argument("--rehearse-collectives", action="store_true", help="rehearsal only: run the N > 1 code path with one rank")
     args = ap.parse_args()
 
     import torch
@@ -167,7 +175,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.rehearse_collectives
+    if args.rehearse_collectives:
+        os.environ["ZL_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -207,7 +219,8 @@ def main():
     from libzl_amd import sharding
     overlapped = None
     if distributed and args.dist_backend == "nccl":
-        overlapped = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32), dst=0)
+        overlapped = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32), dst=0,
+                                                  algorithm=args.reduce_algo)
 
     def step(i, timed):
         # render this rank's voices, sum the partial buses onto rank 0 (one RCCL reduce), levels on the root
@@ -323,7 +336,7 @@ def main():
                             + (f"fs=sr={args.fs:.0f} (ratio 1)" if notes[0] == notes[1] and source_rate == args.fs else
                                f"fs={args.fs:.0f}, sources at {source_rate:.0f}, MIDI notes {notes[0]}..{notes[1]} around root 60") +
                             f", {'4-tap Hermite' if args.hermite else 'linear'} interp, faithful mode, distinct {args.loop_seconds:g} s sources "
-                            f"({arena / 1e6:.0f} MB), bus int peaks per block" + (", RCCL bus reduce to rank 0 per step" if distributed else ""),
+                            f"({arena / 1e6:.0f} MB), bus int peaks per block" + (f", bus reduce to rank 0 per step over RCCL ({args.reduce_algo}), overlapped with the next step" if distributed else ""),
                 "voices_per_gpu": V, "buses": B, "frames_per_block": N, "blocks_per_step": KB, "parallelism": f"voices sharded x{world}",
             },
             "roofline": {
@@ -344,7 +357,10 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, seed)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     syn.close()
     if distributed:
         dist.barrier()                       # rank 0 is still timing the CPU baseline: leave the group together

@@ -61,6 +61,36 @@ def reduce_bus_in_rank_order(bus, dst: int = 0, group=None):
     return bus
 
 
+def reduce_bus_mesh(bus, dst: int = 0, group=None, scratch=None):
+    """Sum of the partial buses on `dst` over the point-to-point mesh, in rank order.  xGMI links every pair of GPUs
+    of a node directly, so instead of a ring (every link carries the whole bus) each rank sends 1/world of its bus to
+    each peer (all-to-all: world - 1 links in parallel, 1/world of the bytes each), sums the world pieces it received
+    in rank order -- deterministic, the oracle's grouped order bit for bit -- and the reduced pieces are gathered onto
+    `dst` (again one piece per link).  Per link: 2/world of the bus instead of the whole of it.
+    `scratch`: optional receive buffer of the bus's size (kept by the caller to avoid an allocation per batch)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return bus
+    if dist.get_world_size(group) == 1 and not os.environ.get("ZL_FORCE_COLLECTIVES"):   # (set to rehearse the calls with one rank)
+        return bus
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    flat = bus.view(-1)
+    if flat.numel() % world != 0:
+        return reduce_bus_in_rank_order(bus, dst=dst, group=group)
+    chunk = flat.numel() // world
+    recv = scratch.view(-1) if scratch is not None else torch.empty_like(flat)
+    dist.all_to_all_single(recv, flat, group=group)               # recv[r] = piece `rank` of rank r's partial bus
+    parts = recv.view(world, chunk)
+    acc = parts[0].clone()
+    for r in range(1, world):
+        acc += parts[r]                                            # rank order
+    pieces = [flat[r * chunk:(r + 1) * chunk] for r in range(world)] if rank == dst else None
+    dist.gather(acc, gather_list=pieces, dst=dst, group=group)    # piece r of the final bus comes from rank r
+    return bus
+
+
 def render_sharded(synth, nblocks: int, nframes: int, clocks, bus, dst: int = 0, stream=None, group=None):
     """One batch on this rank's voices into `bus` (device pointer of a torch tensor), then the bus reduce;
     on the root the reduced bus is scanned for AudioLevels.  `synth` is a libzl_amd.SamplerSynth."""
@@ -73,32 +103,59 @@ def render_sharded(synth, nblocks: int, nframes: int, clocks, bus, dst: int = 0,
 
 
 class OverlappedBusReduce:
-    """Double-buffered partial buses: the RCCL reduce of batch i runs on the collective stream while batch i+1
-    renders into the other buffer (xGMI is point-to-point, ~153 GB/s per link, so a 100+ MB bus takes about as
-    long to reduce as to render; hiding it keeps the weak-scaling curve flat)."""
+    """Double-buffered partial buses: the reduce of batch i runs while batch i+1 renders into the other buffer (a
+    100+ MB bus takes about as long to cross xGMI as to render; hiding it keeps the weak-scaling curve flat).
+    algorithm: "mesh" (reduce_bus_mesh: all-to-all + rank-order sum + gather, on a communication stream of its own),
+    "reduce" (one RCCL reduce, async) or "rank-order" (reduce_bus_in_rank_order, on the communication stream)."""
 
-    def __init__(self, synth, make_bus, dst: int = 0, group=None):
-        self.synth, self.dst, self.group = synth, dst, group
+    def __init__(self, synth, make_bus, dst: int = 0, group=None, algorithm: str = "mesh"):
+        self.synth, self.dst, self.group, self.algorithm = synth, dst, group, algorithm
         self.bus = [make_bus(), make_bus()]
+        self.cuda = self.bus[0].is_cuda
         self.work = [None, None]
         self.shape = [None, None]
         self.i = 0
+        if algorithm != "reduce":
+            import torch
+            self.scratch = [torch.empty_like(self.bus[0]), torch.empty_like(self.bus[0])] if algorithm == "mesh" else [None, None]
+            if self.cuda:
+                self.comm = torch.cuda.Stream(device=self.bus[0].device)
+                self.done = [torch.cuda.Event(), torch.cuda.Event()]
 
     def _finish(self, j, stream):
+        import torch
         import torch.distributed as dist
         if self.work[j] is not None:
-            self.work[j].wait()                       # the current stream waits for the collective
+            if self.work[j] is True:
+                if self.cuda:
+                    torch.cuda.current_stream(self.bus[j].device).wait_event(self.done[j])
+            else:
+                self.work[j].wait()                   # the current stream waits for the collective
             self.work[j] = None
             if dist.get_rank(self.group) == self.dst and self.shape[j] is not None:
                 nb, nf = self.shape[j]
                 self.synth.levels_scan_device(self.bus[j].data_ptr(), nb, nf, stream=stream)   # levels see the final mix
 
     def step(self, nblocks: int, nframes: int, clocks, stream=None):
+        import torch
         import torch.distributed as dist
         j = self.i & 1
         self._finish(j, stream)                       # buffer j was reduced two steps ago
         self.synth.render_batch(nblocks, nframes, clocks, bus_out_dev=self.bus[j].data_ptr(), stream=stream)
-        self.work[j] = dist.reduce(self.bus[j], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.algorithm == "reduce":
+            self.work[j] = dist.reduce(self.bus[j], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            fn = (lambda: reduce_bus_mesh(self.bus[j], dst=self.dst, group=self.group, scratch=self.scratch[j])) \
+                if self.algorithm == "mesh" else (lambda: reduce_bus_in_rank_order(self.bus[j], dst=self.dst, group=self.group))
+            if self.cuda:
+                # the exchange, the ordered sum and the gather run on the communication stream, behind the render
+                self.comm.wait_stream(torch.cuda.current_stream(self.bus[j].device))
+                with torch.cuda.stream(self.comm):
+                    fn()
+                    self.done[j].record(self.comm)
+            else:
+                fn()
+            self.work[j] = True
         self.shape[j] = (nblocks, nframes)
         self.i += 1
         return self.bus[j]

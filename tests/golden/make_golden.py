@@ -144,6 +144,36 @@ def main():
                       8: [stop(0)],
                       12: [play(0, note=65, vol=0.7)]})
 
+    # G6: pitch ratios of 1/16 and 16 (binade crossings every frame / every few blocks) and loops of a few frames
+    # (several restarts per block), linear and Hermite
+    e0, e1, e2, e3 = src(4000), src(900), src(700, stereo=False), src(5000)
+    clips6 = [dict(set_length=(0.11, 120), volume_abs=0.9, pan=0.1), dict(length_beats=0.013, length_sec=7.0 / 48000.0, volume_abs=0.7, pan=-0.5),
+              dict(length_beats=0.011, length_sec=3.0 / 48000.0, volume_abs=0.8, pan=0.4), dict(set_length=(0.17, 120), volume_abs=0.6, pan=-0.2)]
+    ev6 = {0: [play(0, note=12, vol=0.8), play(1, note=64, vol=0.6), play(2, note=55, vol=0.9), play(3, note=108, vol=0.5)]}
+    for mode, nm in ((0, "g6_extreme_ratios_tiny_loops"), (4, "g6_extreme_ratios_tiny_loops_hermite")):
+        run_scene(nm, B=1, VPB=4, fs=48000.0, mode=mode, nframes=128, nblocks=10,
+                  sounds=[(e0[0], e0[1], 48000.0), (e1[0], e1[1], 48000.0), (e2[0], None, 48000.0), (e3[0], e3[1], 48000.0)],
+                  clips=clips6, events=ev6)
+
+    # G7: a loop longer than its file (quirk Q5: silence past the last frame), lengthInBeats = -1 (quirk Q10: the
+    # float -> quint64 tick count saturates), mono source through Hermite, one-shot running off the end
+    f0, f1, f2 = src(1500), src(1300, stereo=False), src(1000)
+    clips7 = [dict(length_beats=0.3, length_sec=0.05, volume_abs=0.8, pan=0.25), dict(length_sec=0.02, volume_abs=0.9, pan=-0.3),
+              dict(length_beats=0.25, length_sec=0.03, adsr=(0.0, 0.1, 1.0, 0.0))]
+    ev7 = {0: [play(0, note=60, vol=0.7), play(1, note=62, vol=0.8), play(2, loop=False, note=57, vol=0.9)]}
+    for mode, nm in ((0, "g7_past_the_end_q10"), (4, "g7_past_the_end_q10_hermite")):
+        run_scene(nm, B=1, VPB=4, fs=48000.0, mode=mode, nframes=128, nblocks=12,
+                  sounds=[(f0[0], f0[1], 48000.0), (f1[0], None, 48000.0), (f2[0], f2[1], 48000.0)], clips=clips7, events=ev7)
+
+    # G8: 256-frame blocks, sources at 22.05 / 96 / 44.1 kHz played at 48 kHz, start offset + slice playback
+    g0, g1, g2 = src(3000), src(9000), src(2500, stereo=False)
+    clips8 = [dict(set_length=(0.12, 120), volume_abs=0.85, pan=0.3), dict(start_sec=0.01, set_length=(0.06, 120), volume_abs=0.5, pan=-0.6),
+              dict(set_length=(0.09, 120), volume_abs=0.75, pan=0.0)]
+    ev8 = {0: [play(0, note=60, vol=0.8), play(1, note=65, vol=0.6, change_slice=True, slice=5), play(2, note=53, vol=0.9)],
+           4: [dict(clip=1, midi_channel=-2, midi_note=65, change_slice=True, slice=5, change_volume=True, volume=0.3)]}
+    run_scene("g8_resampled_256", B=1, VPB=4, fs=48000.0, mode=0, nframes=256, nblocks=8,
+              sounds=[(g0[0], g0[1], 22050.0), (g1[0], g1[1], 96000.0), (g2[0], None, 44100.0)], clips=clips8, events=ev8)
+
 
 if __name__ == "__main__":
     main()

@@ -352,7 +352,7 @@ def main():
                 "state_and_levels_bytes_per_step": state_bytes, "slow_blocks": int(slow),
                 "note": "sources are 2 s loops re-read every 375 blocks: inside a plan window part of the re-reads is served by the "
                         "256 MiB Infinity Cache (bus-major launch order keeps one bus's 98 MB of sources hot); "
-                        "run with --loop-seconds 10 for a no-reuse variant (DESIGN.md section 4)",
+                        "no_reuse_variant is the same kernel on 10 s sources (DESIGN.md section 4)",
             },
         }
         if not args.no_cpu_baseline:

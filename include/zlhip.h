@@ -170,6 +170,11 @@ void zlhip_clip_command_clear(zlhip_clip_command *c);           /* ClipCommand.h
  * b - 2, SamplerSynth.cpp:270).  Returns 1 if a voice took / merged the command, 0 if it was
  * dropped (no free voice, as in the reference), < 0 on error. */
 int zlhip_handle_command(zlhip_engine *e, const zlhip_clip_command *cmd, uint64_t current_tick);
+/* A block's worth of commands in one call (SyncTimer dispatches every command that is due in a cycle,
+ * SyncTimer.cpp:553-558): handled in array order like the channel's command ring; they reach the device as ONE
+ * voice-table update (K0) before the next rendered block.  taken[i] (optional) receives what zlhip_handle_command
+ * would have returned for command i; the return value is their sum, < 0 on error. */
+int zlhip_handle_commands(zlhip_engine *e, const zlhip_clip_command *cmds, int32_t count, uint64_t current_tick, int32_t *taken);
 /* Same, addressed to an explicit voice slot of a bus (bypasses first-free allocation; used to
  * build large synthetic scenes deterministically). */
 int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd, uint64_t current_tick);

@@ -465,6 +465,20 @@ int zlhip_handle_command(zlhip_engine *e, const zlhip_clip_command *cmd, uint64_
     return e->hc.handle_command(*cmd, current_tick);
 }
 
+int zlhip_handle_commands(zlhip_engine *e, const zlhip_clip_command *cmds, int32_t count, uint64_t current_tick, int32_t *taken)
+{
+    if (!e || (!cmds && count > 0) || count < 0) return ZLHIP_ERR_INVALID;
+    int rc = refresh_host_voices(e);                               // once for the whole batch
+    if (rc != ZLHIP_OK) return rc;
+    int n = 0;
+    for (int32_t i = 0; i < count; ++i) {
+        const int t = e->hc.handle_command(cmds[i], current_tick); // arrival order, as the channel's command ring
+        if (taken) taken[i] = t;
+        n += t;
+    }
+    return n;
+}
+
 int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd, uint64_t current_tick)
 {
     if (!e || !cmd || bus < 0 || bus >= e->cfg.num_buses || slot < 0 || slot >= e->cfg.voices_per_bus) return ZLHIP_ERR_INVALID;

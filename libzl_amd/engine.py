@@ -150,6 +150,14 @@ class SamplerSynth:
     def handle_clip_command(self, cmd: ClipCommand, current_tick: int = 0) -> int:
         return self._ck(self._lib.zlhip_handle_command(self._e, C.byref(cmd), current_tick), "handle_command")
 
+    def handle_clip_commands(self, cmds: Sequence[ClipCommand], current_tick: int = 0):
+        """A block's worth of commands in one call; returns the per-command results (1 taken / 0 dropped)."""
+        n = len(cmds)
+        arr = (ClipCommand * n)(*cmds)
+        taken = (C.c_int32 * n)()
+        self._ck(self._lib.zlhip_handle_commands(self._e, arr, n, current_tick, taken), "handle_commands")
+        return list(taken)
+
     def start_voice(self, bus: int, slot: int, cmd: ClipCommand, current_tick: int = 0) -> int:
         return self._ck(self._lib.zlhip_start_voice(self._e, bus, slot, C.byref(cmd), current_tick), "start_voice")
 

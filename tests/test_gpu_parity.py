@@ -312,6 +312,41 @@ def test_size_independent_properties_at_full_size(Engine):
     s1.close(); s2.close()
 
 
+def test_command_batches_equal_single_commands(Engine):
+    """zlhip_handle_commands (a block's worth of commands in one call, one K0 update) == the same commands one by one."""
+    from scenario import engine_cmd
+    sc = random_scene(6100, num_buses=4, voices_per_bus=8, nclips=12, nframes=128, nblocks=12, events=True)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+
+    class Batched(Engine):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self._pending, self._tick = [], 0
+
+        def handle_clip_command(self, cmd, current_tick=0):
+            if self._pending and current_tick != self._tick:
+                self._flush()
+            self._pending.append(cmd); self._tick = current_tick
+            return 1
+
+        def _flush(self):
+            if self._pending:
+                self.handle_clip_commands(self._pending, self._tick)
+                self._pending = []
+
+        def set_clip_params(self, clip, params):
+            self._flush()
+            return super().set_clip_params(clip, params)
+
+        def render_batch(self, *a, **k):
+            self._flush()
+            return super().render_batch(*a, **k)
+
+    bus, rep, syn, _ = run_backend(sc, Batched, batch=4)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    syn.close()
+
+
 def test_voice_stealing_and_slot_reuse(Engine):
     """One-shots end on the device; their slots must become allocatable again exactly as in the oracle."""
     sc = random_scene(800, num_buses=1, voices_per_bus=3, nclips=4, nblocks=30, nframes=128, events=False, min_len=900, max_len=1400)

@@ -597,6 +597,11 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.N = nframes; A.Ktot = nblocks;
     A.G = pick_group(e, nblocks, nframes);
     A.groups = (A.VPB + A.G - 1) / A.G;
+    // narrow buses in batches: several whole buses per K2 workgroup (voices of consecutive buses are contiguous); needs the
+    // bus width to be a multiple of K2's chunk of 8 voices, no mix groups, one frame tile per block
+    A.NB = 1;
+    if (nblocks > 1 && A.groups == 1 && A.VPB <= 64 && (A.VPB % 8) == 0 && nframes <= 256)
+        A.NB = std::max(1, std::min(128 / A.VPB, A.B));
     A.mode = e->cfg.mode;
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
     A.voices = e->dVoices; A.reports = c.dReports;
@@ -860,7 +865,7 @@ int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblo
     ZL_HIP(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     ZlBatch A; std::memset(&A, 0, sizeof A);
-    A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.Ktot = nblocks; A.k0 = 0; A.N = nframes; A.G = A.VPB; A.groups = 1;
+    A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.K = nblocks; A.Ktot = nblocks; A.k0 = 0; A.N = nframes; A.G = A.VPB; A.groups = 1; A.NB = 1;
     A.levels = e->dLevels; A.bus = nullptr;
     ZL_KERNEL(e, zl_launch_finalize(A, bus_dev, s));
     if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->evJoin, s)); e->joins[1] = e->evJoin; }

@@ -473,6 +473,8 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     __shared__ ZlVoiceConst s_vc[ZL_K2_CHUNK];
     __shared__ int s_cls_[BPW][ZL_K2_CHUNK];          // per voice: 1 = plays this block, 2 = per-frame control
     __shared__ int s_chunk_[BPW][ZL_K2_CHUNK / U];    // class of each chunk of U voices
+    __shared__ int   s_pk[2][4];                      // fused level scan: per-wave partial results
+    __shared__ float s_sq[2][4];
 
     const int N = A.N, V = A.V;
     const int blk = (BPW > 1) ? (int)threadIdx.x / N : 0;          // which of the workgroup's blocks this lane renders
@@ -482,11 +484,15 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     const ZlBlockPlan *s_plan = s_plan_[blk];
     const int *s_cls = s_cls_[blk];
     const int *s_chunk = s_chunk_[blk];
-    const int bus = blockIdx.z / A.groups;
-    const int g   = blockIdx.z - bus * A.groups;
-    const int v0 = bus * A.VPB + g * A.G;
-    const int vend = (bus + 1) * A.VPB;
-    const int v1 = (v0 + A.G < vend) ? v0 + A.G : vend;
+    // Narrow buses (the reference's 8 voices per channel): one workgroup renders A.NB whole buses, one after the other,
+    // from ONE staging pass over their NB * VPB <= 128 voices -- the gathers of consecutive buses keep flowing and the
+    // fixed costs per workgroup are shared.  NB == 1: one (bus, mix group) per workgroup.
+    const int NB = A.NB;
+    const int bus0 = (NB > 1) ? (int)blockIdx.z * NB : (int)blockIdx.z / A.groups;
+    const int g    = (NB > 1) ? 0 : (int)blockIdx.z - bus0 * A.groups;
+    const int v0 = bus0 * A.VPB + g * A.G;
+    const int vlim = (NB > 1) ? ((bus0 + NB) * A.VPB < V ? (bus0 + NB) * A.VPB : V) : (bus0 + 1) * A.VPB;
+    const int v1 = (NB > 1) ? vlim : ((v0 + A.G < vlim) ? v0 + A.G : vlim);
     const bool wantPeak = live && (A.k0 + k == A.Ktot - 1);        // the report covers the last block of the call
     const double fd = (double)f;
 #ifdef ZL_STAMPS
@@ -494,6 +500,62 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
 #endif
 
     float accL = 0.0f, accR = 0.0f;
+    int curBus = bus0, busEnd = (bus0 + 1) * A.VPB;               // NB > 1: the bus being summed and its end in voice numbers
+
+    // the finished mix of one bus (or mix group): bus row / partials row, and the fused AudioLevels block scan
+    auto store_bus = [&](int bus) {
+        float *outL, *outR;
+        if (A.groups == 1) {
+            const size_t KN = (size_t)A.Ktot * N;
+            outL = A.bus + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N;
+            outR = outL + KN;
+        } else {
+            outL = A.partials + ((((size_t)k * A.B + bus) * A.groups + g) * 2) * (size_t)N;
+            outR = outL + N;
+        }
+        bool written = false;
+        if (live) {
+            if (MODE & ZL_MODE_FIX_DELAY) {
+                outL[f] = accL; outR[f] = accR;
+                written = true;
+            } else {
+                // quirk Q2: the reference pre-increments its output pointers, so frame f lands in out[f+1],
+                // out[0] stays 0 and the sample of the last frame falls outside the buffer (dropped)
+                written = f + 1 < N;
+                if (written) { outL[f + 1] = accL; outR[f + 1] = accR; }
+                if (f == 0)  { outL[0] = 0.0f;    outR[0] = 0.0f; }
+            }
+        }
+        // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of its
+        //      whole block(s) (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
+        if (A.groups == 1 && gridDim.x == 1 && A.levels) {
+            int pkL = written ? zl_sample_to_peak_int(accL) : 0, pkR = written ? zl_sample_to_peak_int(accR) : 0;
+            float sqL = written ? accL * accL : 0.0f, sqR = written ? accR * accR : 0.0f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int a = __shfl_xor(pkL, o, 64), b = __shfl_xor(pkR, o, 64);
+                pkL = a > pkL ? a : pkL; pkR = b > pkR ? b : pkR;
+                sqL += __shfl_xor(sqL, o, 64); sqR += __shfl_xor(sqR, o, 64);
+            }
+            const int w = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { s_pk[0][w] = pkL; s_pk[1][w] = pkR; s_sq[0][w] = sqL; s_sq[1][w] = sqR; }
+            __syncthreads();
+            if (f == 0 && live) {
+                // the waves of this lane's block: all of the workgroup's (BPW == 1) or N / 64 of them
+                const int w0 = (BPW > 1) ? blk * (N >> 6) : 0;
+                const int nw = (BPW > 1) ? (N >> 6) : (int)((blockDim.x + 63) >> 6);
+                ZlBlockLevels lv; lv.peak_l = 0; lv.peak_r = 0; lv.sumsq_l = 0.0f; lv.sumsq_r = 0.0f;
+                for (int i = w0; i < w0 + nw; ++i) {
+                    lv.peak_l = s_pk[0][i] > lv.peak_l ? s_pk[0][i] : lv.peak_l;
+                    lv.peak_r = s_pk[1][i] > lv.peak_r ? s_pk[1][i] : lv.peak_r;
+                    lv.sumsq_l += s_sq[0][i]; lv.sumsq_r += s_sq[1][i];
+                }
+                A.levels[(size_t)k * A.B + bus] = lv;
+            }
+            if (NB > 1) __syncthreads();                           // the partial results are reused for the next bus
+        }
+    };
+
     for (int vb = v0; vb < v1; vb += ZL_K2_CHUNK) {
         const int nv = (v1 - vb < ZL_K2_CHUNK) ? v1 - vb : ZL_K2_CHUNK;
         // ---- stage the per-voice records of this pass in LDS: one lane per (block, voice) issues every load it may
@@ -541,22 +603,28 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
         const size_t pbase = (size_t)k * V + vb;
         for (int c0 = 0; c0 < nv; c0 += U) {
             const int cc = __builtin_amdgcn_readfirstlane(s_chunk[c0 / U]);
-            if (cc == 0) continue;                                // nobody in this chunk plays (SamplerSynth.cpp:137)
 #ifdef ZL_STAMPS
-            zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
+            if (cc) zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
 #endif
-            if ((cc & 28) == 4)       zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 20) == 4)  zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 28) == 20) zl_k2_chunk_simple_mono<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 20) == 20) zl_k2_chunk_simple_mono<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            if (cc == 0) {                                        // nobody in this chunk plays (SamplerSynth.cpp:137)
+            } else if ((cc & 28) == 4)  zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 4)    zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 28) == 20)   zl_k2_chunk_simple_mono<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 20)   zl_k2_chunk_simple_mono<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
             else {
-                // general chunks (events, second segments, mono sources, per-frame control) are rare: run them as
+                // general chunks (events, second segments, mixed layouts, per-frame control) are rare: run them as
                 // two half-chunks so their extra per-voice registers do not set the kernel's register budget
                 constexpr int H = U / 2;
                 for (int h = 0; h < U; h += H) {
                     if (cc & 2) zl_k2_chunk<MODE, true, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, f, wantPeak, accL, accR);
                     else        zl_k2_chunk<MODE, false, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, f, wantPeak, accL, accR);
                 }
+            }
+            if (NB > 1 && vb + c0 + U == busEnd) {
+                // that was the last chunk of a bus (VPB is a multiple of the chunk size here): write it, start the next one
+                store_bus(curBus);
+                accL = 0.0f; accR = 0.0f;
+                ++curBus; busEnd += A.VPB;
             }
         }
     }
@@ -568,57 +636,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
         st[3] = zl_paths;
     }
 #endif
-    float *outL, *outR;
-    if (A.groups == 1) {
-        const size_t KN = (size_t)A.Ktot * N;
-        outL = A.bus + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N;
-        outR = outL + KN;
-    } else {
-        outL = A.partials + ((((size_t)k * A.B + bus) * A.groups + g) * 2) * (size_t)N;
-        outR = outL + N;
-    }
-    bool written = false;
-    if (live) {
-        if (MODE & ZL_MODE_FIX_DELAY) {
-            outL[f] = accL; outR[f] = accR;
-            written = true;
-        } else {
-            // quirk Q2: the reference pre-increments its output pointers, so frame f lands in out[f+1],
-            // out[0] stays 0 and the sample of the last frame falls outside the buffer (dropped)
-            written = f + 1 < N;
-            if (written) { outL[f + 1] = accL; outR[f + 1] = accR; }
-            if (f == 0)  { outL[0] = 0.0f;    outR[0] = 0.0f; }
-        }
-    }
-    // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of its
-    //      whole block(s) (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
-    if (A.groups == 1 && gridDim.x == 1 && A.levels) {
-        __shared__ int   s_pk[2][4];
-        __shared__ float s_sq[2][4];
-        int pkL = written ? zl_sample_to_peak_int(accL) : 0, pkR = written ? zl_sample_to_peak_int(accR) : 0;
-        float sqL = written ? accL * accL : 0.0f, sqR = written ? accR * accR : 0.0f;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int a = __shfl_xor(pkL, o, 64), b = __shfl_xor(pkR, o, 64);
-            pkL = a > pkL ? a : pkL; pkR = b > pkR ? b : pkR;
-            sqL += __shfl_xor(sqL, o, 64); sqR += __shfl_xor(sqR, o, 64);
-        }
-        const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { s_pk[0][w] = pkL; s_pk[1][w] = pkR; s_sq[0][w] = sqL; s_sq[1][w] = sqR; }
-        __syncthreads();
-        if (f == 0 && live) {
-            // the waves of this lane's block: all of the workgroup's (BPW == 1) or N / 64 of them
-            const int w0 = (BPW > 1) ? blk * (N >> 6) : 0;
-            const int nw = (BPW > 1) ? (N >> 6) : (int)((blockDim.x + 63) >> 6);
-            ZlBlockLevels lv; lv.peak_l = 0; lv.peak_r = 0; lv.sumsq_l = 0.0f; lv.sumsq_r = 0.0f;
-            for (int i = w0; i < w0 + nw; ++i) {
-                lv.peak_l = s_pk[0][i] > lv.peak_l ? s_pk[0][i] : lv.peak_l;
-                lv.peak_r = s_pk[1][i] > lv.peak_r ? s_pk[1][i] : lv.peak_r;
-                lv.sumsq_l += s_sq[0][i]; lv.sumsq_r += s_sq[1][i];
-            }
-            A.levels[(size_t)k * A.B + bus] = lv;
-        }
-    }
+    if (NB == 1) store_bus(bus0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,7 +799,7 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s)
     // blocks shorter than 256 frames: 256 / N blocks per workgroup (batches only; a single block keeps its small workgroup)
     const int bpw = (A.N < 256 && 256 % A.N == 0 && A.K > 1) ? 256 / A.N : 1;
     const int tpb = bpw > 1 ? 256 : (A.N < 256 ? A.N : 256);
-    const dim3 grid(bpw > 1 ? 1 : A.N / tpb, (A.K + bpw - 1) / bpw, A.B * A.groups), block(tpb);
+    const dim3 grid(bpw > 1 ? 1 : A.N / tpb, (A.K + bpw - 1) / bpw, A.NB > 1 ? (A.B + A.NB - 1) / A.NB : A.B * A.groups), block(tpb);
     switch (A.mode & 7u) {
 #define ZL_CASE(M) case M: \
         if (bpw == 4)      hipLaunchKernelGGL((zl_k2_render<M, 4>), grid, block, 0, s, A); \

@@ -165,6 +165,7 @@ struct ZlBatch {
     int32_t k0, Ktot;             // first block of the window inside the call, blocks of the whole call (bus stride)
     int32_t G;                    // voices per render task (mix group); groups per bus = ceil(VPB / G)
     int32_t groups;
+    int32_t NB;                   // buses rendered by one K2 workgroup (narrow buses in batches), else 1
     uint32_t mode;
     int32_t n_op_ranges;
     int32_t trace;                // 1 = write pos trace

@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 VOICE_STATE_BYTES = 104        # sizeof(ZlVoiceState)
 
 
-def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, seed, bpm=120, notes=(60, 60), source_rate=None, mono=False):
+def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, seed, bpm=120, notes=(60, 60), source_rate=None, mono=False, beat_locked=False):
     """Registers one distinct stereo loop per voice (generated on the device) and starts every voice.
     `notes` = inclusive MIDI-note range drawn per voice (root note 60: 48..72 is pitch ratio 0.5..2)."""
     source_rate = source_rate or fs
@@ -59,7 +59,8 @@ def build_scene(syn, torch, dev, voices_per_bus, num_buses, fs, loop_frames, see
     for v in range(V):
         p = syn.default_clip_params(loop_frames / source_rate)
         # fractional beat length -> deterministic sample-space loop wrap (SamplerSynthVoice.cpp:243-246)
-        p.length_in_beats = 3.5
+        # an integer number of beats makes the restart clock-driven (beat-locked, :227-241) instead
+        p.length_in_beats = 4.0 if beat_locked else 3.5
         p.length_seconds = float(np.float32((loop_frames - 64 - (v % 17)) / source_rate))
         p.volume_absolute = float(np.float32(rng.uniform(0.25, 1.0)))
         p.pan = float(np.float32(rng.uniform(-1.0, 1.0)))
@@ -145,6 +146,7 @@ def main():
     ap.add_argument("--loop-seconds", type=float, default=2.0)
     ap.add_argument("--notes", default="60,60", help="MIDI note range per voice (root 60); 48,72 = pitch ratio 0.5..2 (config 4)")
     ap.add_argument("--mono", action="store_true", help="mono sources (non-default variant)")
+    ap.add_argument("--beat-locked", action="store_true", help="integer lengthInBeats: loops restart against the JACK clock (non-default variant)")
     ap.add_argument("--hermite", action="store_true", help="4-tap Hermite interpolation (ZLHIP_MODE_HERMITE, config 4)")
     ap.add_argument("--source-rate", type=float, default=0.0, help="sample rate of the sources (default: --fs)")
     ap.add_argument("--voices-per-task", type=int, default=0)
@@ -199,7 +201,7 @@ def main():
     syn = SamplerSynth(B, vpb, max_frames=N, max_batch_blocks=KB, max_sounds=V, mode=(4 if args.hermite else 0), playback_sample_rate=args.fs,
                        sound_arena_bytes=arena, voices_per_task=args.voices_per_task, plan_window_blocks=args.plan_window, device=local_rank)
     seed = 0x5A17 + 2 + 1000 * rank
-    build_scene(syn, torch, dev, vpb, B, args.fs, loop_frames, seed, notes=notes, source_rate=source_rate, mono=args.mono)
+    build_scene(syn, torch, dev, vpb, B, args.fs, loop_frames, seed, notes=notes, source_rate=source_rate, mono=args.mono, beat_locked=args.beat_locked)
     syn.set_profiling(not os.environ.get('ZL_BENCH_NOPROF'))      # diagnostic switch: cost of the per-launch HIP events
 
     # the engine renders into a torch-owned device buffer so the RCCL reduce needs no copy
@@ -320,7 +322,7 @@ def main():
     # HBM traffic of K2 per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process):
     # traffic / algorithmic measured on this workload, applied to this run's algorithmic bytes; null for other workloads
     traffic = None
-    default_workload = (V, B, N, KB, args.loop_seconds, notes, args.hermite, source_rate, args.mono) == (1024, 8, 256, 8192, 2.0, (60, 60), False, args.fs, False)
+    default_workload = (V, B, N, KB, args.loop_seconds, notes, args.hermite, source_rate, args.mono, args.beat_locked) == (1024, 8, 256, 8192, 2.0, (60, 60), False, args.fs, False, False)
     pmc_file = os.path.join(ROOT, "profiles", "round1_d_pmc.json")
     if default_workload and os.path.exists(pmc_file):
         traffic = json.load(open(pmc_file))["traffic_over_algorithmic"] * k2_bytes

@@ -591,7 +591,12 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
         int hrc = harvest_slot(e, c);
         if (hrc != ZLHIP_OK) return hrc;
     }
-    for (int k = 0; k < nblocks; ++k) ZlHostControl::fill_clock(c.hClocks[k], clocks[k], nframes);
+    bool regular = true;                                           // monotone time, one period: lets K1 bisect for loop restarts
+    for (int k = 0; k < nblocks; ++k) {
+        ZlHostControl::fill_clock(c.hClocks[k], clocks[k], nframes);
+        if (c.hClocks[k].usecs_per_frame >= (1ull << 21) || c.hClocks[k].usecs_per_frame != c.hClocks[0].usecs_per_frame
+            || (k > 0 && c.hClocks[k].current_usecs < c.hClocks[k - 1].current_usecs)) regular = false;
+    }
 
     ZlBatch A; std::memset(&A, 0, sizeof A);
     A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.N = nframes; A.Ktot = nblocks;
@@ -602,6 +607,7 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     A.NB = 1;
     if (nblocks > 1 && A.groups == 1 && A.VPB <= 64 && (A.VPB % 8) == 0 && nframes <= 256)
         A.NB = std::max(1, std::min(128 / A.VPB, A.B));
+    A.clocks_regular = regular ? 1 : 0;
     A.mode = e->cfg.mode;
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
     A.voices = e->dVoices; A.reports = c.dReports;

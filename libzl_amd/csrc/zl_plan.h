@@ -493,16 +493,35 @@ struct ZlPlanner {
                 }
             }
         } else if (clockMode) {
-            // the frame after whose rendering the beat-locked test (:232) fires, block by block
+            // the frame after whose rendering the beat-locked test (:232) fires
             const int tlimit = t + maxsteps;
-            int kk = kcur, nn = n;
-            for (int bs = tb; bs < tlimit; bs += N, ++kk, nn = 0) {
-                const ZlClock &cj = clk0[kk - kb];
-                if (nn == 0 && cj.usecs_per_frame >= (1ull << 21)) { steps = bs - t; break; }   // simulated block (bs > t)
-                const int fa = zl_clock_event_frame(cj, st.next_loop_usecs, nn, N);
-                if (fa < N) {
-                    if (bs + fa < tlimit) { steps = bs + fa - t + 1; event = true; ke = kk; }
-                    break;
+            if (A.clocks_regular) {
+                // regular clocks: "the test can fire in block j" (current_usecs_j + (N-1) * usecs_per_frame >= next loop
+                // time) is monotone in j, so the first such block is found by bisection instead of a walk
+                const ZlClock &c0 = clk0[kcur - kb];
+                int fa = zl_clock_event_frame(c0, st.next_loop_usecs, n, N);      // the rest of the current block
+                int kf = kcur;
+                if (fa >= N) {
+                    int lo = kcur + 1, hi = zl_block_of(tlimit - 1, N, invN) + 1; // candidate blocks [lo, hi)
+                    const int hi0 = hi;
+                    const uint64_t span = (uint64_t)(N - 1) * c0.usecs_per_frame;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (clk0[mid - kb].current_usecs + span >= st.next_loop_usecs) hi = mid; else lo = mid + 1;
+                    }
+                    if (lo < hi0) { kf = lo; fa = zl_clock_event_frame(clk0[lo - kb], st.next_loop_usecs, 0, N); }
+                }
+                if (fa < N && kf * N + fa < tlimit) { steps = kf * N + fa - t + 1; event = true; ke = kf; }
+            } else {
+                int kk = kcur, nn = n;
+                for (int bs = tb; bs < tlimit; bs += N, ++kk, nn = 0) {                // block by block
+                    const ZlClock &cj = clk0[kk - kb];
+                    if (nn == 0 && cj.usecs_per_frame >= (1ull << 21)) { steps = bs - t; break; }   // simulated block (bs > t)
+                    const int fa = zl_clock_event_frame(cj, st.next_loop_usecs, nn, N);
+                    if (fa < N) {
+                        if (bs + fa < tlimit) { steps = bs + fa - t + 1; event = true; ke = kk; }
+                        break;
+                    }
                 }
             }
         }

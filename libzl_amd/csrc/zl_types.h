@@ -169,6 +169,8 @@ struct ZlBatch {
     uint32_t mode;
     int32_t n_op_ranges;
     int32_t trace;                // 1 = write pos trace
+    int32_t clocks_regular;       // 1: current_usecs never decreases and usecs_per_frame is constant (< 2^21) over the call:
+                                  //    the block in which a beat-locked loop restarts can be found by bisection
     int32_t inline_clock;         // 1: the (single) block's clock travels in clock0 with the kernel arguments
     int32_t fuse_assemble;        // 1: K1 assembles the plan records itself (single real-time block: one launch less)
     ZlClock clock0;

@@ -149,7 +149,12 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
 {
     const size_t V = (size_t)S->V;
     std::vector<ZlClock> ck((size_t)K);
-    for (int k = 0; k < K; ++k) ZlHostControl::fill_clock(ck[(size_t)k], clocks[k], N);
+    bool regular = true;
+    for (int k = 0; k < K; ++k) {
+        ZlHostControl::fill_clock(ck[(size_t)k], clocks[k], N);
+        if (ck[(size_t)k].usecs_per_frame >= (1ull << 21) || ck[(size_t)k].usecs_per_frame != ck[0].usecs_per_frame
+            || (k > 0 && ck[(size_t)k].current_usecs < ck[(size_t)k - 1].current_usecs)) regular = false;
+    }
     S->planHdr.assign((size_t)K * V, ZlPlanHdr{}); S->planSeg0.assign((size_t)K * V, ZlPlanSeg0{}); S->planSeg1.assign((size_t)K * V, ZlPlanSeg1{});
     S->ctlP.assign((size_t)K * V * N, 0.0); S->ctlEnv.assign((size_t)K * V * N, 0.0f);
     S->trace.assign((size_t)K * V * N, -1);
@@ -159,7 +164,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     S->hc.drain_ops(ops, ranges);
 
     ZlBatch A; std::memset(&A, 0, sizeof A);
-    A.V = S->V; A.B = S->B; A.VPB = S->VPB; A.K = K; A.N = N; A.k0 = 0; A.Ktot = K; A.G = S->G; A.groups = (S->VPB + S->G - 1) / S->G; A.mode = S->mode;
+    A.V = S->V; A.B = S->B; A.VPB = S->VPB; A.K = K; A.N = N; A.k0 = 0; A.Ktot = K; A.G = S->G; A.groups = (S->VPB + S->G - 1) / S->G; A.mode = S->mode; A.clocks_regular = regular ? 1 : 0;
     A.clocks = ck.data(); A.sounds = S->sounds.data(); A.clips = S->clips.data(); A.arena = S->arena.data();
     A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.tsegs = S->tsegs.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data();
     A.ctl_P = S->ctlP.data(); A.ctl_env = S->ctlEnv.data(); A.reports = S->reports.data();

@@ -102,5 +102,48 @@ def resampled_sources():
     return sc
 
 
-SCENES = {f.__name__: f for f in (extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
+def beat_locked_with_irregular_clocks():
+    """Beat-locked loops (integer lengthInBeats: restart against the JACK clock, Q9a) under a clock that jitters, changes
+    its period and once steps backwards: the planner's walk over the blocks (no bisection) must find the same frames."""
+    from libzl_amd._abi import Clock
+    sc = _base(9, nblocks=40, length=9000)
+    _play_all(sc, [60, 63, 57, 66])
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = float(1 + (i % 2))                   # integer beats -> clock-driven restart
+            clip.lengthInSeconds = float(np.float32(0.05 + 0.02 * i))
+        sc.clip_setup[i] = setup
+    sc.bpm = 174
+
+    def clocks(start, n):
+        arr = (Clock * n)()
+        sub = ((60000000000) // (sc.bpm * 96)) // 1000
+        for j in range(n):
+            k = start + j
+            period = 2667 + (37 if k % 3 == 0 else -21 if k % 5 == 0 else 0)          # changing period
+            cur = k * 2667 + ((k * 7919) % 13) - (900 if k == 17 else 0)              # jitter, one backward step
+            arr[j].current_usecs = cur
+            arr[j].next_usecs = cur + period
+            arr[j].jack_playhead = 0
+            arr[j].jack_playhead_usecs = 0
+            arr[j].jack_subbeat_length_usecs = sub
+        return arr
+    sc.clocks = clocks
+    return sc
+
+
+def beat_locked_long_regular():
+    """Beat-locked loops over a long batch with a regular clock: restarts found by bisection over the window's blocks."""
+    sc = _base(10, nblocks=700, length=30000)
+    _play_all(sc, [60, 64, 55, 67])
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = float(1 + i)
+            clip.lengthInSeconds = float(np.float32(0.3 + 0.05 * i))
+        sc.clip_setup[i] = setup
+    sc.bpm = 140
+    return sc
+
+
+SCENES = {f.__name__: f for f in (beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
                                   envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}

@@ -43,12 +43,12 @@ static __device__ __forceinline__ void zl_k1c_block(const ZlBatch &A, ZlAssemble
         const int l = __builtin_ctzll(m);
         m &= m - 1;
         const int vv = __shfl(v, l, 64), ii = __shfl(idx0, l, 64), bb = __shfl(base0, l, 64), na = __shfl(n_active, l, 64);
-        const float env = __shfl(as.env, l, 64);
         ZlSegStream ss;
         ss.init(A, vv, A.runs[vv]);
         const size_t base = ((size_t)k * A.V + vv) * (size_t)A.N;
         for (int f = lane; f < A.N; f += 64) {
-            A.ctl_P[base + f] = zl_expand_frame(ss, A.N, k, ii, bb, f < na ? f : 0);
+            float env;
+            A.ctl_P[base + f] = zl_expand_frame(ss, A.N, k, ii, bb, f < na ? f : 0, env);
             A.ctl_env[base + f] = env;
         }
     }
@@ -153,7 +153,7 @@ typedef float zl_f2a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef float zl_f4a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float zl_f2a4b __attribute__((ext_vector_type(2), aligned(4)));
 
-struct ZlK2Tap { ZlTaps t; float alpha; int flags; };   // flags: 1 act, 2 inb, 4 stereo, 16 wide
+struct ZlK2Tap { ZlTaps t; float alpha, env; int flags; };   // flags: 1 act, 2 inb, 4 stereo, 16 wide
 
 // One chunk of U consecutive voices for one lane (= one output frame).  Branch-free per voice so the
 // U gathers (and, for CTL chunks, the U per-frame control loads before them) are issued back to back
@@ -412,6 +412,8 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
         const double P0 = seg1 ? s_plan[i].P1 : s_plan[i].P0;
         const double st = seg1 ? s_plan[i].step1 : s_plan[i].step;
         double P = fma((double)(fe - (seg1 ? s_plan[i].n1 : 0)), st, P0);            // exact, see zl_plan.h
+        tap[u].env = (float)fma((double)(fe - (seg1 ? s_plan[i].n1 : 0)), (double)(seg1 ? s_plan[i].estep1 : s_plan[i].estep0),
+                                (double)(seg1 ? s_plan[i].E1 : s_plan[i].env));    // exact fp32 envelope ramp (0 slope in sustain)
         if (CTL) { if (cls & 2) P = Pc[u]; }
         int pos;
         zl_split_position(P, pos, tap[u].alpha);                  // :198-199
@@ -447,7 +449,7 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
         const int i = c0 + u;
         const int tf = tap[u].flags;
         const bool act = tf & 1;
-        float env = s_plan[i].env;
+        float env = tap[u].env;
         if (CTL) { if (s_cls[i] & 2) env = Ec[u]; }
         float l, r;
         zl_mix_frame<MODE>(tap[u].t, tap[u].alpha, tf & 2, tf & 16, tf & 4, s_vc[i].lgain, s_vc[i].rgain, env,
@@ -577,7 +579,8 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
             // 4 = "simple": whole block, sustain (and no debug trace); 8 = it has a second position segment; 16 = mono source
             const float gprod = vc.lgain * vc.rgain * vc.clip_volume * pl.env;     // finite iff every factor is (or one is 0 * inf = NaN)
-            if (cls == 1 && pl.nseg <= 2 && pl.n_active == N && (vc.channels == 1 || vc.channels == 2) && !A.trace && (gprod - gprod) == 0.0f)
+            if (cls == 1 && pl.nseg <= 2 && !(pl.flags & ZL_PLAN_ENV) && pl.n_active == N && (vc.channels == 1 || vc.channels == 2) && !A.trace
+                && (gprod - gprod) == 0.0f)
                 cls |= 4 | (pl.nseg == 2 ? 8 : 0) | (vc.channels == 1 ? 16 : 0);
             if (b == 0) s_vc[i] = vc;
             s_plan_[b][i] = pl;                   // idle slots: a harmless record with no active frame

@@ -183,6 +183,62 @@ ZL_HD inline void zl_linear_run(double P, double r, double inv_r, double &s, int
     L = cnt > (double)ZL_RUN_CAP ? ZL_RUN_CAP : (int)cnt;
 }
 
+// Envelope ramps (juce::ADSR attack / decay / release) are fp32 recurrences e <- fl32(e + d) with a constant d.  Inside
+// one binade of e, and while the exact sum stays in it, every step adds the same multiple of ulp(e), so the values are
+// an exact arithmetic progression e + i * es.  Returns es and the number Lc >= 0 of steps i = 1..Lc that are (a)
+// exactly that progression and (b) do not reach `limit` (d > 0: e_i < limit, d < 0: e_i > limit), i.e. cause no ADSR
+// state change.  Lc == 0: take one real step (zl_adsr_next).
+ZL_HD inline void zl_env_linear_run(float e, float d, float limit, float &es, int &Lc)
+{
+    es = 0.0f; Lc = 0;
+    const uint32_t eb = __builtin_bit_cast(uint32_t, e);
+    const int ex = (int)((eb >> 23) & 0xffu);
+    if ((eb >> 31) || ex == 0 || ex >= 0xfe || !(d == d) || d == 0.0f) return;   // e <= 0, subnormal, huge; no ramp
+    const double u = zl_from_bits((uint64_t)(ex - 150 + 1023) << 52);            // ulp(e)
+    const double inv_u = zl_from_bits((uint64_t)(150 - ex + 1023) << 52);
+    const double m = (double)e * inv_u;                          // mantissa as an integer in [2^23, 2^24)
+    const bool up = d > 0.0f;
+    const double rq = fabs((double)d) * inv_u;                   // |d| in ulps, exact
+    const double q = floor(rq);
+    if (!(q < 16777216.0)) return;                               // leaves the binade at once
+    const double fr = rq - q;
+    double c;
+    if (fr > 0.5) c = q + 1.0;
+    else if (fr < 0.5) c = q;
+    else {                                                       // tie: round-half-even on the mantissa
+        if (eb & 1u) return;                                     // odd mantissa: one real step makes it even
+        c = (((long long)q) & 1ll) ? q + 1.0 : q;                // even mantissa stays even from here on
+    }
+    if (c <= 0.0) {                                              // |d| <= ulp/2: the envelope does not move (es = 0) ...
+        if (up || m - rq >= 8388608.0) Lc = ZL_RUN_CAP;           // ... unless it sits on the binade's bottom, going down
+        return;
+    }
+    // steps that stay inside the binade: up, the result m_i + c may reach 2^24 (the top itself); down, the EXACT
+    // difference m_i - rq must not fall below 2^23 (below it the spacing halves and the rounding changes)
+    const double num = up ? 16777216.0 - m : m - 8388608.0 - rq + c;   // nb = floor(num / c), both cases
+    double nb = 0.0;
+    if (num >= c) {
+        nb = floor(num / c);
+        while (nb > 0.0 && fma(nb, c, -num) > 0.0) nb -= 1.0;
+        while (fma(nb + 1.0, c, -num) <= 0.0) nb += 1.0;
+    }
+    // steps before the ADSR event: the values e + i * es are exact in double
+    const double esd = up ? c * u : -(c * u);
+    const double gap = up ? (double)limit - (double)e : (double)e - (double)limit;      // > 0 while the state lasts
+    double nev = 0.0;
+    if (gap > 0.0) {
+        const double step = c * u;
+        nev = ceil(gap / step) - 1.0;                            // largest i with i * step < gap, then corrected exactly
+        if (nev < 0.0) nev = 0.0;
+        while (nev > 0.0 && !(fma(nev, step, -gap) < 0.0)) nev -= 1.0;
+        while (fma(nev + 1.0, step, -gap) < 0.0) nev += 1.0;
+    }
+    double n = nb < nev ? nb : nev;
+    if (n > (double)ZL_RUN_CAP) n = (double)ZL_RUN_CAP;
+    es = (float)esd;                                             // exact: c < 2^24 ulps
+    Lc = (int)n;
+}
+
 // Smallest i in [1, L] with P + i*s >= X (values are exact), or ZL_INF_STEPS.
 ZL_HD inline int zl_steps_to_reach(double P, double s, double inv_r, int L, double X)
 {
@@ -269,7 +325,7 @@ struct ZlPlanStats { unsigned long long source_bytes, slow_blocks, active_frames
 ZL_HD inline void zl_plan_clear(ZlBlockPlan &pl)
 {
     pl.flags = 0; pl.n_active = 0; pl.nseg = 0; pl.env = 0.0f; pl.P0 = 0.0; pl.step = 0.0;
-    pl.n1 = INT_MAX; pl.pad = 0; pl.P1 = 0.0; pl.step1 = 0.0; pl.pad2 = 0.0;
+    pl.n1 = INT_MAX; pl.estep0 = 0.0f; pl.P1 = 0.0; pl.step1 = 0.0; pl.E1 = 0.0f; pl.estep1 = 0.0f;
 }
 
 ZL_HD inline void zl_plan_store(const ZlBatch &A, size_t pidx, const ZlBlockPlan &pl)
@@ -278,8 +334,8 @@ ZL_HD inline void zl_plan_store(const ZlBatch &A, size_t pidx, const ZlBlockPlan
     A.plan_hdr[pidx] = h;
     ZlPlanSeg0 s0; s0.P0 = pl.P0; s0.step = pl.step;
     A.plan_seg0[pidx] = s0;
-    if (pl.nseg >= 2) {
-        ZlPlanSeg1 s1; s1.P1 = pl.P1; s1.step1 = pl.step1; s1.n1 = pl.n1; s1.pad = 0; s1.pad2 = 0.0;
+    if (pl.nseg >= 2 || (pl.flags & ZL_PLAN_ENV)) {
+        ZlPlanSeg1 s1; s1.P1 = pl.P1; s1.step1 = pl.step1; s1.n1 = pl.n1; s1.estep0 = pl.estep0; s1.E1 = pl.E1; s1.estep1 = pl.estep1;
         A.plan_seg1[pidx] = s1;
     }
 }
@@ -293,9 +349,9 @@ ZL_HD inline ZlBlockPlan zl_plan_load(const ZlBatch &A, size_t pidx)
     const ZlPlanSeg0 s0 = A.plan_seg0[pidx];
     pl.flags = h.flags; pl.n_active = h.n_active; pl.nseg = h.nseg; pl.env = h.env;
     pl.P0 = s0.P0; pl.step = s0.step;
-    if (h.nseg >= 2 && !(h.flags & ZL_PLAN_SLOW)) {
+    if ((h.nseg >= 2 || (h.flags & ZL_PLAN_ENV)) && !(h.flags & ZL_PLAN_SLOW)) {
         const ZlPlanSeg1 s1 = A.plan_seg1[pidx];
-        pl.P1 = s1.P1; pl.step1 = s1.step1; pl.n1 = s1.n1;
+        pl.P1 = s1.P1; pl.step1 = s1.step1; pl.n1 = s1.n1; pl.estep0 = s1.estep0; pl.E1 = s1.E1; pl.estep1 = s1.estep1;
     }
     return pl;
 }
@@ -323,6 +379,10 @@ struct ZlPlanner {
     double inv_r, invN;          // 1 / pitch_ratio, 1 / N
     double s;                    // current linear run: step, linear steps left, steps to the position event
     int L, ie;
+    // current envelope run: frame t has envelope eNext, the following eLeft - 1 frames add es each (exactly, fp32)
+    float eNext, es;
+    int eLeft;
+    bool haveERun, endAfter;     // endAfter: the envelope reached idle at frame t, the voice stops after rendering it
     int v;
     bool valid, posMode, clockMode, haveRun, slowNext, lastMarker;
     int t;                       // next frame to plan (window time); its position is st.P
@@ -330,7 +390,7 @@ struct ZlPlanner {
     int t_end;                   // frame at which the voice stopped (INT_MAX while it plays)
     int dead_from;
     // state at the start of the block that contains frame t (restored when that block has to be simulated after all)
-    double Pbs; uint64_t tick_bs, usecs_bs; int jbs;
+    double Pbs; uint64_t tick_bs, usecs_bs; int jbs; float env_bs; int adsr_bs;
     // inline runs: the open one lives in registers and is stored when the next one opens
     ZlRun cur;
     int  nruns;
@@ -348,6 +408,7 @@ struct ZlPlanner {
         stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
         nruns = 0; haveCur = false; cur.P = 0.0; cur.step = 0.0; cur.k0 = 0; cur.k1 = 0;
         s = 0.0; L = 0; ie = ZL_INF_STEPS; haveRun = false; slowNext = false; lastMarker = false;
+        eNext = 0.0f; es = 0.0f; eLeft = 0; haveERun = false; endAfter = false; env_bs = 0.0f; adsr_bs = 0;
         t = 0; nts = 0; t_end = INT_MAX; dead_from = 0;
         Pbs = 0.0; tick_bs = 0; usecs_bs = 0; jbs = 0;
         invN = 1.0 / (double)A.N;
@@ -403,12 +464,14 @@ struct ZlPlanner {
         if (t > tb) {
             stats.active_frames -= (unsigned long long)(t - tb);
             stats.source_bytes -= blockBytes;
-            st.P = Pbs; st.next_loop_tick = tick_bs; st.next_loop_usecs = usecs_bs;
             nts = jbs;
             t = tb;
         }
+        // the state at the start of the block (the envelope may have taken its step for frame t already)
+        st.P = Pbs; st.next_loop_tick = tick_bs; st.next_loop_usecs = usecs_bs;
+        st.env = env_bs; st.adsr_state = adsr_bs;
         if (perState == 1) perState = 2;
-        haveRun = false;
+        haveRun = false; haveERun = false; endAfter = false;
         slowNext = true;
     }
 
@@ -428,8 +491,10 @@ struct ZlPlanner {
             const ZlClock &ck = clk0[kcur - kb];
             if (st.next_loop_usecs == 0)                            // :179-182
                 st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
-            const bool slow = (force_slow & 1) || slowNext || st.adsr_state != ZL_ADSR_SUSTAIN
-                              || (clockMode && ck.usecs_per_frame >= (1ull << 21)) || nts >= ZL_MAXTSEG - 1;
+            // (attack / decay / release ramps are planned as exact fp32 runs; only the every-frame noteOff of a
+            // one-shot's tail, quirk Q7, needs the per-frame path -- it arrives here through slowNext)
+            const bool slow = (force_slow & 1) || slowNext || (clockMode && ck.usecs_per_frame >= (1ull << 21)) || nts >= ZL_MAXTSEG - 1
+                              || (!st.looping && st.release > 0.0f && st.P >= c.tail_T);
             if (slow) {
                 // envelope transient, release tail (Q7) or a pathological clock: per-frame simulation of this block
                 const size_t pidx = (size_t)kcur * A.V + v;
@@ -444,7 +509,7 @@ struct ZlPlanner {
                 zl_plan_clear(pl);
                 pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW; pl.env = st.sustain; pl.P0 = st.P;
                 pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
-                haveRun = false;
+                haveRun = false; haveERun = false; endAfter = false;
                 zl_plan_store(A, pidx, pl);
                 stats.slow_blocks += 1;
                 stats.source_bytes += blockBytes;
@@ -454,27 +519,48 @@ struct ZlPlanner {
                 return;
             }
             Pbs = st.P; tick_bs = st.next_loop_tick; usecs_bs = st.next_loop_usecs; jbs = nts;
+            env_bs = st.env; adsr_bs = st.adsr_state;
         }
 
-        // ---- a new linear run (and its segment) when the previous one is used up ----
-        if (!haveRun) {
+        // ---- a new linear position run and / or a new envelope run when the previous one is used up: one segment ----
+        if (!haveRun || !haveERun) {
             if (nts >= ZL_MAXTSEG - 1) { rollback_block(tb); return; }   // table full (one slot is kept for a marker): simulate this block
-            zl_linear_run(st.P, st.pitch_ratio, inv_r, s, L);
-            haveRun = true;
-            // the event inside the run's L linear steps, else at the real addition that closes it (step L + 1)
-            ie = ZL_INF_STEPS;
-            if (posMode) {
-                ie = zl_steps_to_reach(st.P, s, inv_r, L, X);
-                if (ie == ZL_INF_STEPS && (fma((double)L, s, st.P) + st.pitch_ratio) >= X) ie = L + 1;
+            if (!haveRun) {
+                zl_linear_run(st.P, st.pitch_ratio, inv_r, s, L);
+                haveRun = true;
+                // the event inside the run's L linear steps, else at the real addition that closes it (step L + 1)
+                ie = ZL_INF_STEPS;
+                if (posMode) {
+                    ie = zl_steps_to_reach(st.P, s, inv_r, L, X);
+                    if (ie == ZL_INF_STEPS && (fma((double)L, s, st.P) + st.pitch_ratio) >= X) ie = L + 1;
+                }
             }
-            ZlTSeg sg; sg.P = st.P; sg.step = s; sg.t = t; sg.flags = 0;
+            if (!haveERun) {
+                // the envelope of frame t by one real juce::ADSR step (:201), then its exact linear continuation: no state
+                // change and no change of the fp32 spacing inside it (sustain: constant for ever)
+                eNext = zl_adsr_next(st);
+                es = 0.0f; eLeft = 1; endAfter = false;
+                if (st.adsr_state == ZL_ADSR_IDLE) endAfter = true;                    // :258-261, the voice stops after this frame
+                else if (st.adsr_state == ZL_ADSR_SUSTAIN) eLeft = (eNext == st.sustain) ? ZL_RUN_CAP : 1;   // (the frame that enters sustain still has the ramp's last value)
+                else {
+                    int Lc = 0;
+                    if (st.adsr_state == ZL_ADSR_ATTACK)       zl_env_linear_run(eNext, st.attack_rate, 1.0f, es, Lc);
+                    else if (st.adsr_state == ZL_ADSR_DECAY)   zl_env_linear_run(eNext, -st.decay_rate, st.sustain, es, Lc);
+                    else                                       zl_env_linear_run(eNext, -st.release_rate, 0.0f, es, Lc);
+                    eLeft = Lc + 1;
+                }
+                haveERun = true;
+                if (st.adsr_state != ZL_ADSR_SUSTAIN && perState == 1) perState = 2;   // a ramping pass is not a template
+            }
+            ZlTSeg sg; sg.P = st.P; sg.step = s; sg.t = t; sg.flags = 0; sg.E = eNext; sg.estep = es;
             ts[nts++] = sg;
             lastMarker = false;
         }
 
         // ---- how far this iteration goes: the run (L linear steps + 1 real addition), an event, the end of the chunk ----
         const int S = L + 1;
-        const int room = Tend - t;
+        int room = Tend - t;
+        if (eLeft < room) room = eLeft;                              // ... or the end of the envelope run
         const int maxsteps = S < room ? S : room;
         int steps = maxsteps;
         bool event = false;
@@ -534,7 +620,7 @@ struct ZlPlanner {
             stats.active_frames += (unsigned long long)steps;
             const int started = zl_block_of(t1 - 1, N, invN) - kcur + (n == 0 ? 1 : 0);
             stats.source_bytes += blockBytes * (unsigned long long)started;
-            if (k1 > k0) {
+            if (k1 > k0 && es == 0.0f && st.adsr_state == ZL_ADSR_SUSTAIN) {
                 const double Pk0 = fma((double)(k0 * N - t), s, st.P);     // exact: on the line
                 if (haveCur && cur.k1 == k0 && cur.step == s && fma((double)((k0 - cur.k0) * N), s, cur.P) == Pk0) {
                     cur.k1 = k1;                                    // the same run continued (chunk boundary)
@@ -555,7 +641,7 @@ struct ZlPlanner {
                 zl_loop_restart(st, c, clk0[ke - kb], clockMode);
                 if (posMode && !force_slow) {                       // (force_slow bit 1: test hook, plan every pass)
                     // sample-space loop: the pass that begins now repeats exactly (same integer start, same ratio)
-                    if (perState == 0) { perState = 1; tcap = t1; jcap = nts; }
+                    if (perState == 0 && st.adsr_state == ZL_ADSR_SUSTAIN) { perState = 1; tcap = t1; jcap = nts; }
                     else if (perState == 1) {
                         perState = 2;
                         if (nts - jcap >= 3 && nts - jcap <= 64) {  // passes of one or two segments are cheaper as inline runs
@@ -577,12 +663,32 @@ struct ZlPlanner {
             L -= steps;
             if (ie != ZL_INF_STEPS) ie -= steps;
         }
-        if (st.playing) st.env = st.sustain;                        // the sustain branch assigns envelopeVal every frame
+        // ---- the envelope over the same frames: st.env is the value of the last rendered frame ----
+        const float eFirst = eNext;
+        if (st.playing) {
+            st.env = (float)fma((double)(steps - 1), (double)es, (double)eFirst);      // exact: inside the envelope run
+            eLeft -= steps;
+            if (eLeft > 0) eNext = (float)((double)st.env + (double)es); else haveERun = false;
+            if (endAfter) {
+                // the envelope ran out at this frame (:258-261): the voice stops after rendering it
+                zl_voice_hard_stop(st);
+                t_end = t1;
+                dead_from = zl_block_of(t1 - 1, N, invN) + 1;
+                haveRun = false; haveERun = false; endAfter = false;
+                jump = false;
+            }
+        } else {
+            haveERun = false; endAfter = false;
+        }
         // ---- state at the start of the block that now contains t1 ----
         if (k1 * N > t) {
             const int b = k1 * N;
-            if (b == t1) { Pbs = st.P; tick_bs = st.next_loop_tick; usecs_bs = st.next_loop_usecs; }
-            else         { Pbs = fma((double)(b - t), s, Pold); tick_bs = tickOld; usecs_bs = usecsOld; }   // the event (if any) comes after b
+            if (b == t1) { Pbs = st.P; tick_bs = st.next_loop_tick; usecs_bs = st.next_loop_usecs; env_bs = st.env; }
+            else {                                                  // the event (if any) comes after b
+                Pbs = fma((double)(b - t), s, Pold); tick_bs = tickOld; usecs_bs = usecsOld;
+                env_bs = (float)fma((double)(b - t - 1), (double)es, (double)eFirst);
+            }
+            adsr_bs = st.adsr_state;
             jbs = nts;
         }
         t = t1;
@@ -594,7 +700,8 @@ struct ZlPlanner {
             int j = per_j0 + per_n - 1;                             // the pass segment that covers offset rem
             while (j > per_j0 && ts[j].t - per_t0 > rem) --j;
             st.P = fma((double)(rem - (ts[j].t - per_t0)), ts[j].step, ts[j].P);   // exact: on the segment's line
-            haveRun = false;
+            st.env = st.sustain;
+            haveRun = false; haveERun = false;
             stats.active_frames += (unsigned long long)Rm;
             stats.source_bytes += blockBytes * (unsigned long long)(A.K - (k1 + (t1 > k1 * N ? 1 : 0)));
             t = TW;
@@ -734,7 +841,7 @@ struct ZlAssembler {
         n_active = (rl.t_end - T < N) ? rl.t_end - T : N;
         // the entries that start inside the block (up to two are looked at)
         int nseg = 1, i1 = idx, b1 = base;
-        ZlTSeg b; b.P = 0.0; b.step = 0.0; b.t = 0; b.flags = 0;
+        ZlTSeg b; b.P = 0.0; b.step = 0.0; b.t = 0; b.flags = 0; b.E = 0.0f; b.estep = 0.0f;
         int bt = 0;
         {
             int i2 = idx, b2 = base;
@@ -745,12 +852,16 @@ struct ZlAssembler {
             if (nseg >= 2) { b = ss.ts[i1]; bt = b.t + b1; }
         }
         const size_t pidx = (size_t)k * A.V + v;
-        ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE | (nseg > 2 ? ZL_PLAN_SLOW : 0); h.n_active = n_active; h.nseg = nseg; h.env = env;
+        const float E0 = (float)fma((double)(T - (a.t + base)), (double)a.estep, (double)a.E);    // exact: inside the envelope run
+        const bool ramps = a.estep != 0.0f || (nseg == 2 && (b.estep != 0.0f || b.E != E0));
+        ZlPlanHdr h; h.flags = ZL_PLAN_ACTIVE | (nseg > 2 ? ZL_PLAN_SLOW : 0) | (ramps && nseg <= 2 ? ZL_PLAN_ENV : 0);
+        h.n_active = n_active; h.nseg = nseg; h.env = E0;
         ZlPlanSeg0 s0; s0.P0 = fma((double)(T - (a.t + base)), a.step, a.P); s0.step = a.step;   // exact: on the segment's line
         A.plan_hdr[pidx] = h;
         A.plan_seg0[pidx] = s0;
-        if (nseg == 2) {
-            ZlPlanSeg1 s1; s1.P1 = b.P; s1.step1 = b.step; s1.n1 = bt - T; s1.pad = 0; s1.pad2 = 0.0;
+        if (nseg == 2 || (ramps && nseg == 1)) {
+            ZlPlanSeg1 s1; s1.P1 = b.P; s1.step1 = b.step; s1.n1 = nseg == 2 ? bt - T : INT_MAX;
+            s1.estep0 = a.estep; s1.E1 = b.E; s1.estep1 = b.estep;
             A.plan_seg1[pidx] = s1;
         }
         idx0 = idx; base0 = base;
@@ -758,9 +869,9 @@ struct ZlAssembler {
     }
 };
 
-// Per-frame control of a block with more than two segments: the position of frame f (< n_active) of block k;
+// Per-frame control of a block with more than two segments: position and envelope of frame f (< n_active) of block k;
 // (idx0, base0) = the stream position that covers the block's first frame.
-ZL_HD inline double zl_expand_frame(const ZlSegStream &ss, int N, int k, int idx0, int base0, int f)
+ZL_HD inline double zl_expand_frame(const ZlSegStream &ss, int N, int k, int idx0, int base0, int f, float &env)
 {
     const int T = k * N + f;
     int idx = idx0, base = base0;
@@ -770,6 +881,7 @@ ZL_HD inline double zl_expand_frame(const ZlSegStream &ss, int N, int k, int idx
         idx = i2; base = b2;
     }
     const ZlTSeg a = ss.ts[idx];
+    env = (float)fma((double)(T - (a.t + base)), (double)a.estep, (double)a.E);                    // exact
     return fma((double)(T - (a.t + base)), a.step, a.P);          // exact
 }
 

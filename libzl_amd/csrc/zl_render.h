@@ -18,9 +18,10 @@ ZL_HD inline void zl_eval_control(const ZlBlockPlan &pl, const double *ctlP, con
         env = ctlEnv[f];
         return;
     }
-    env = pl.env;
     const bool seg1 = f >= pl.n1;
-    P = fma((double)(f - (seg1 ? pl.n1 : 0)), seg1 ? pl.step1 : pl.step, seg1 ? pl.P1 : pl.P0);   // exact (see zl_plan.h)
+    const int n0 = seg1 ? pl.n1 : 0;
+    P = fma((double)(f - n0), seg1 ? pl.step1 : pl.step, seg1 ? pl.P1 : pl.P0);                     // exact (see zl_plan.h)
+    env = (float)fma((double)(f - n0), (double)(seg1 ? pl.estep1 : pl.estep0), (double)(seg1 ? pl.E1 : pl.env));   // exact fp32 ramp
 }
 
 ZL_HD inline float zl_hermite4(float y0, float y1, float y2, float y3, float a)

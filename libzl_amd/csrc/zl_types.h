@@ -87,14 +87,15 @@ struct ZlVoiceConst {             // per voice, constant over a batch; 48 bytes 
     int32_t  pad[2];
 };
 
-enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2 };
-// K1's output per voice and plan window is a stream of linear position segments in window time: frames
-// [t, next segment's t) are rendered at P + (frame - t) * step, exactly (zl_plan.h).  A segment ends at a binade
-// crossing, a loop restart or the end of the voice.  K1c turns the stream into per-block plans, lane-parallel.
+enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2, ZL_PLAN_ENV = 4 };   // ENV: the envelope ramps inside the block (ZlPlanSeg1 holds the slopes)
+// K1's output per voice and plan window is a stream of linear segments in window time: frames [t, next segment's t)
+// are rendered at position P + (frame - t) * step with envelope E + (frame - t) * estep, both exactly (zl_plan.h).  A
+// segment ends at a binade crossing of the position or of the envelope, an ADSR state change, a loop restart or the
+// end of the voice.  K1c turns the stream into per-block plans, lane-parallel.
 // ZL_TSEG_SLOW marks the start of blocks that K1 simulated per frame itself (envelope transients, release tails).
 #define ZL_MAXTSEG   1024
 #define ZL_TSEG_SLOW 1
-struct ZlTSeg { double P, step; int32_t t, flags; };
+struct ZlTSeg { double P, step; int32_t t, flags; float E, estep; };   // E: envelope of frame t, + estep per frame (exact fp32 ramp)
 
 // Whole blocks inside one segment differ only in P0 and need no plan record at all: blocks [k0, k1) of a run
 // are rendered whole, in sustain, with P0(k) = P + (k - k0) * N * step (exact).  The first ZL_MAXRUNS such
@@ -119,19 +120,19 @@ struct ZlRunList {
 // second segment, ZlPlanSeg1[K][V].  K2 reassembles this 64-byte record in LDS.
 struct ZlPlanHdr  { int32_t flags, n_active, nseg; float env; };
 struct ZlPlanSeg0 { double P0, step; };
-struct ZlPlanSeg1 { double P1, step1; int32_t n1, pad; double pad2; };
+struct ZlPlanSeg1 { double P1, step1; int32_t n1; float estep0, E1, estep1; };   // second segment + the envelope slopes of both
 struct ZlBlockPlan {              // per (block, voice); 64 bytes, the first two linear segments inline
     int32_t flags;
     int32_t n_active;             // frames rendered in this block (N unless the voice stopped inside it)
     int32_t nseg;                 // 1 or 2 for fast blocks (blocks with more are expanded to per-frame control by K1c)
-    float   env;                  // envelope value of every frame of a fast block (sustain)
+    float   env;                  // envelope of frame 0 of a fast block (of every frame in sustain)
     double  P0;                   // position of frame 0
     double  step;                 // exact per-frame increment inside the first segment
     int32_t n1;                   // first frame of the second segment (INT_MAX when there is none)
-    int32_t pad;
+    float   estep0;               // envelope slope of the first segment (0 in sustain); env is the envelope of frame 0
     double  P1;                   // position of frame n1
     double  step1;
-    double  pad2;
+    float   E1, estep1;           // envelope of frame n1 and the slope of the second segment
 };
 struct ZlReport {                 // device side of zlhip_voice_report
     int32_t playing, valid;

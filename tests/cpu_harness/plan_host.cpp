@@ -190,8 +190,9 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
             ++S->expanded;
             const size_t pidx = (size_t)k * V + (size_t)v;
             for (int f = 0; f < N; ++f) {
-                S->ctlP[pidx * (size_t)N + f] = zl_expand_frame(as.ss, N, k, idx0, base0, f < n_active ? f : 0);
-                S->ctlEnv[pidx * (size_t)N + f] = as.env;
+                float env;
+                S->ctlP[pidx * (size_t)N + f] = zl_expand_frame(as.ss, N, k, idx0, base0, f < n_active ? f : 0, env);
+                S->ctlEnv[pidx * (size_t)N + f] = env;
             }
         }
     }
@@ -228,6 +229,12 @@ unsigned long long zlsim_source_bytes(ZlSim *S) { return S->stats.source_bytes; 
 int zlsim_nseg(ZlSim *S, int k, int v) { return S->planHdr[(size_t)k * S->V + v].nseg; }
 int zlsim_num_runs(ZlSim *S, int v) { return S->runs[(size_t)v].n; }
 int zlsim_num_tsegs(ZlSim *S, int v) { return S->runs[(size_t)v].nts; }
+// segment j of voice v of the last window: out = {P, step, t, flags, E, estep}
+void zlsim_get_tseg(ZlSim *S, int v, int j, double *out)
+{
+    const ZlTSeg &g = S->tsegs[(size_t)v * ZL_MAXTSEG + (size_t)j];
+    out[0] = g.P; out[1] = g.step; out[2] = g.t; out[3] = g.flags; out[4] = g.E; out[5] = g.estep;
+}
 int zlsim_periodic_segments(ZlSim *S, int v) { return S->runs[(size_t)v].per_n; }
 int zlsim_plan_flags(ZlSim *S, int k, int v) { return S->planHdr[(size_t)k * S->V + v].flags; }
 
@@ -259,6 +266,38 @@ long long zlsim_check_linear_runs(double P0, double r, long long steps, long lon
         done += take;
     }
     if (runs_out) *runs_out = runs;
+    return -1;
+}
+
+// fp32 envelope ramps: walks e <- e + d both ways (naive float recurrence vs zl_env_linear_run + one real step between
+// runs) until the ADSR event (d > 0: e >= limit, d < 0: e <= limit) or `steps`; returns the first mismatching step or -1.
+long long zlsim_check_env_runs(float e0, float d, float limit, long long steps, long long *runs_out, long long *linear_out)
+{
+    float en = e0, e = e0;
+    long long done = 0, runs = 0, lin = 0;
+    auto event = [&](float x) { return d > 0.0f ? x >= limit : x <= limit; };
+    while (done < steps) {
+        float es; int Lc;
+        zl_env_linear_run(e, d, limit, es, Lc);
+        ++runs;
+        long long take = Lc;
+        if (take > steps - done) take = steps - done;
+        for (long long i = 1; i <= take; ++i) {
+            en = en + d;                                          // the recurrence, one fp32 addition per step
+            const float ei = (float)fma((double)i, (double)es, (double)e);
+            if (ei != en) return done + i;
+            if (event(en)) return -(done + i) - 2;                // the run must stop before the event
+        }
+        lin += take;
+        e = (float)fma((double)take, (double)es, (double)e);
+        done += take;
+        if (done >= steps) break;
+        e = e + d; en = en + d; ++done;                           // the real step between two runs
+        if (e != en) return done;
+        if (event(en)) break;
+    }
+    if (runs_out) *runs_out = runs;
+    if (linear_out) *linear_out = lin;
     return -1;
 }
 

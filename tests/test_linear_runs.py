@@ -72,3 +72,34 @@ def test_steps_to_reach_is_exact(sim):
             assert got == i, (P, r, X, got, i)
         else:
             assert i > 1               # the run ended before the threshold
+
+
+def test_envelope_ramps_are_exact_linear_runs(sim):
+    """fp32 ADSR ramps (attack up to 1, decay down to the sustain level, release down to 0): zl_env_linear_run's
+    arithmetic progressions reproduce the per-frame float recurrence bit for bit and stop before the state change."""
+    lib = sim
+    lib.zlsim_check_env_runs.restype = C.c_longlong
+    lib.zlsim_check_env_runs.argtypes = [C.c_float, C.c_float, C.c_float, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    rng = np.random.default_rng(77)
+    total_runs = total_lin = total_steps = 0
+    cases = []
+    for _ in range(300):
+        sr = float(rng.choice([22050.0, 44100.0, 48000.0, 96000.0]))
+        t = float(np.float32(rng.uniform(0.0005, 3.0)))
+        S = float(np.float32(rng.uniform(0.05, 1.0)))
+        cases.append((np.float32(0.0) + np.float32(1.0 / (t * sr)), np.float32(1.0 / (t * sr)), np.float32(1.0)))          # attack from its first value
+        cases.append((np.float32(1.0), -np.float32((1.0 - S) / (t * sr)), np.float32(S)))                                   # decay
+        e0 = np.float32(rng.uniform(0.01, 1.0))
+        cases.append((e0, -np.float32(float(e0) / (t * sr)), np.float32(0.0)))                                              # release
+    cases += [(np.float32(0.75), np.float32(2.0 ** -25), np.float32(1.0)),      # tie: half an ulp per step
+              (np.float32(0.5), -np.float32(2.0 ** -25), np.float32(0.0)),      # at the bottom of a binade, going down
+              (np.float32(0.3), np.float32(1e-12), np.float32(1.0))]            # below half an ulp: never moves
+    for e0, d, lim in cases:
+        if float(d) == 0.0:
+            continue
+        runs, lin = C.c_longlong(0), C.c_longlong(0)
+        steps = 400000
+        bad = lib.zlsim_check_env_runs(float(e0), float(d), float(lim), steps, C.byref(runs), C.byref(lin))
+        assert bad == -1, (float(e0), float(d), float(lim), bad)
+        total_runs += runs.value; total_lin += lin.value
+    assert total_lin > 20 * total_runs                           # the runs are long: tens of frames per real step at least

@@ -145,5 +145,28 @@ def beat_locked_long_regular():
     return sc
 
 
+def random_envelopes(seed):
+    """A mixed random scene whose clips get random ADSR times (zero, tiny, short, longer than the scene) and sustain
+    levels (0, 1, in between), with the scene's own commands (note-offs, restarts, volume changes) on top."""
+    from scenario import random_scene
+    rng = np.random.default_rng(seed)
+    sc = random_scene(seed, nframes=int(rng.choice([64, 128, 256])), nblocks=int(rng.integers(24, 90)), nclips=int(rng.integers(5, 12)),
+                      min_len=2000, max_len=30000, events=True)
+    for i in list(sc.clip_setup):
+        base = sc.clip_setup[i]
+        a = float(rng.choice([0.0, 1e-4, rng.uniform(0.001, 0.2), rng.uniform(0.2, 1.5)]))
+        d = float(rng.choice([0.0, 1e-4, rng.uniform(0.001, 0.2), rng.uniform(0.2, 1.5)]))
+        sus = float(rng.choice([0.0, 1.0, rng.uniform(0.01, 0.99), 1e-3]))
+        r = float(rng.choice([0.0, 1e-4, rng.uniform(0.001, 0.1), rng.uniform(0.1, 0.8)]))
+
+        def setup(lib, clip, base=base, a=a, d=d, sus=sus, r=r):
+            base(lib, clip)
+            clip.adsr.p.attack, clip.adsr.p.decay, clip.adsr.p.sustain, clip.adsr.p.release = a, d, sus, r
+        sc.clip_setup[i] = setup
+    return sc
+
+
 SCENES = {f.__name__: f for f in (beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
                                   envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}
+for _seed in range(8):
+    SCENES[f"random_envelopes_{_seed}"] = (lambda _seed=_seed: random_envelopes(9100 + _seed))

@@ -174,6 +174,16 @@ def main():
     run_scene("g8_resampled_256", B=1, VPB=4, fs=48000.0, mode=0, nframes=256, nblocks=8,
               sounds=[(g0[0], g0[1], 22050.0), (g1[0], g1[1], 96000.0), (g2[0], None, 44100.0)], clips=clips8, events=ev8)
 
+    # G9: envelopes that span many blocks: slow attack into a slow decay, sustain levels 0.35 / 0 / 1, note-off with a long
+    # linear release that runs the voice out, a second note-off inside the attack
+    h0, h1, h2 = src(6000), src(5000, stereo=False), src(7000)
+    clips9 = [dict(set_length=(0.2, 120), adsr=(0.03, 0.05, 0.35, 0.04), pan=0.2), dict(set_length=(0.15, 120), adsr=(0.012, 0.02, 0.0, 0.02), pan=-0.4),
+              dict(set_length=(0.25, 120), adsr=(0.08, 0.0, 1.0, 0.06), volume_abs=0.7)]
+    ev9 = {0: [play(0, note=60, vol=0.9), play(1, note=64, vol=0.7), play(2, note=55, vol=0.8)],
+           9: [stop(2, note=55)], 16: [stop(0, note=60)], 22: [play(1, note=67, vol=0.6)]}
+    run_scene("g9_long_envelopes", B=1, VPB=4, fs=48000.0, mode=0, nframes=128, nblocks=40,
+              sounds=[(h0[0], h0[1], 48000.0), (h1[0], None, 48000.0), (h2[0], h2[1], 44100.0)], clips=clips9, events=ev9)
+
 
 if __name__ == "__main__":
     main()

@@ -481,7 +481,12 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     const int N = A.N, V = A.V;
     const int blk = (BPW > 1) ? (int)threadIdx.x / N : 0;          // which of the workgroup's blocks this lane renders
     const int f = (BPW > 1) ? (int)threadIdx.x - blk * N : (int)(blockIdx.x * blockDim.x + threadIdx.x);   // frame inside the block
-    const int k = blockIdx.y * BPW + blk;
+    // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin in launch order, so launch slot y runs on XCD
+    // y % 8; giving XCD x the contiguous blocks [x * KY / 8, (x + 1) * KY / 8) lets neighbouring blocks (which share the
+    // cache line at their common edge of every source) meet in the same L2
+    const int ky = (int)gridDim.y;
+    const int yb = ((ky & 7) == 0) ? (int)(blockIdx.y & 7u) * (ky >> 3) + (int)(blockIdx.y >> 3) : (int)blockIdx.y;
+    const int k = yb * BPW + blk;
     const bool live = k < A.K;                                     // the last workgroup may hold fewer than BPW blocks
     const ZlBlockPlan *s_plan = s_plan_[blk];
     const int *s_cls = s_cls_[blk];
@@ -566,7 +571,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
         __syncthreads();
         for (int idx = threadIdx.x; idx < BPW * ZL_K2_CHUNK; idx += blockDim.x) {   // whole waves: blockDim.x is a multiple of 64
             const int b = idx / ZL_K2_CHUNK, i = idx - b * ZL_K2_CHUNK;
-            const int kk = blockIdx.y * BPW + b;
+            const int kk = yb * BPW + b;
             ZlVoiceConst vc;
             ZlBlockPlan pl;
             zl_plan_clear(pl);

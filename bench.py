@@ -344,7 +344,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "zl_k2_render", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/round1_d_pmc.json: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic = 1.061 on this workload" if traffic else None,
+                "traffic_source": "profiles/round1_d_pmc.json: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic on this workload" if traffic else None,
                 "no_reuse_variant": no_reuse,
                 "device_copy_GBs": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                 "algorithmic_bytes_per_launch": k2_bytes, "avg_launch_ms": k2_avg_ms, "launches_per_step": launches,

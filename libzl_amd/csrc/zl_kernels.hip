@@ -484,8 +484,8 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin in launch order, so launch slot y runs on XCD
     // y % 8; giving XCD x the contiguous blocks [x * KY / 8, (x + 1) * KY / 8) lets neighbouring blocks (which share the
     // cache line at their common edge of every source) meet in the same L2
-    const int ky = (int)gridDim.y;
-    const int yb = ((ky & 7) == 0) ? (int)(blockIdx.y & 7u) * (ky >> 3) + (int)(blockIdx.y >> 3) : (int)blockIdx.y;
+    const int ky = (int)gridDim.y, xq = ky >> 3, xr = ky & 7, xx = (int)(blockIdx.y & 7u);
+    const int yb = xx * xq + (xx < xr ? xx : xr) + (int)(blockIdx.y >> 3);      // a bijection of [0, ky) for every ky
     const int k = yb * BPW + blk;
     const bool live = k < A.K;                                     // the last workgroup may hold fewer than BPW blocks
     const ZlBlockPlan *s_plan = s_plan_[blk];

@@ -159,7 +159,7 @@ struct ZlK2Tap { ZlTaps t; float alpha, env; int flags; };   // flags: 1 act, 2 
 // U gathers (and, for CTL chunks, the U per-frame control loads before them) are issued back to back
 // and stay in flight together; the voices are then mixed and accumulated in voice order.
 // CTL = the chunk contains a block with per-frame control (envelope not in steady sustain, or a
-// block expanded by K1b); regular voices of such a chunk read a dummy control word.
+// block expanded by K1c); regular voices of such a chunk read a dummy control word.
 // SIMPLE chunks (the steady state): every voice of the chunk plays the whole block from one position segment, in
 // sustain, from a stereo source.  No per-voice predicates are needed, which halves the VALU work.
 // Packed (l, r) arithmetic of zl_mix_frame for the simple chunks: both channels go through the same expression, so

@@ -728,7 +728,7 @@ struct ZlPlanner {
     }
 };
 
-// The plan of block k of voice v: implied by a run, explicit, or idle.  Used by K2's staging and by K1b.
+// The plan of block k of voice v: implied by a run, explicit, or idle.  Used by K2's staging.
 ZL_HD inline ZlBlockPlan zl_plan_lookup(const ZlBatch &A, int k, int v, float run_env)
 {
     ZlBlockPlan pl;

@@ -9,7 +9,7 @@
 #include "zl_types.h"
 #include <math.h>
 
-// Position and envelope of frame f of a planned block (after K1b: at most two inline segments, or
+// Position and envelope of frame f of a planned block (after K1c: at most two inline segments, or
 // per-frame control).
 ZL_HD inline void zl_eval_control(const ZlBlockPlan &pl, const double *ctlP, const float *ctlEnv, int f, double &P, float &env)
 {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: planning time (K0+K1+K1b before the first K2 launch) for different scene shapes."""
+"""Diagnostic: planning time (K0+K1+K1c before the first K2 launch) for different scene shapes."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

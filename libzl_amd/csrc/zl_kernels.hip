@@ -167,6 +167,9 @@ struct ZlK2Tap { ZlTaps t; float alpha, env; int flags; };   // flags: 1 act, 2 
 // kernel's VALU budget is ~49 lane-operations per voice-sample at the HBM roofline; un-fused, -ffp-contract=off).
 typedef float zl_f2 __attribute__((ext_vector_type(2)));
 
+// unit-step blocks (playback at the source rate inside an exact run): integer part of P0 and the constant fraction
+struct ZlUnit { int ipos; float alpha; };
+
 static __device__ __forceinline__ zl_f2 zl_hermite4_pk(zl_f2 y0, zl_f2 y1, zl_f2 y2, zl_f2 y3, float a)
 {
     const zl_f2 c1 = 0.5f * (y2 - y0);
@@ -205,8 +208,8 @@ static __device__ __forceinline__ zl_f2 zl_mix_frame_pk(zl_f2 xm, zl_f2 x0, zl_f
 #define ZL_K2_PK_HERMITE 1
 #endif
 
-template <uint32_t MODE, bool SEG2, int U>
-static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
+template <uint32_t MODE, bool SEG2, bool UNIT, int U>
+static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
                                                            int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
 {
     constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
@@ -221,12 +224,19 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
         if (SEG2) {                                               // a binade crossing or loop restart inside the block
             const bool seg1 = f >= s_plan[i].n1;
             P = fma((double)(f - (seg1 ? s_plan[i].n1 : 0)), seg1 ? s_plan[i].step1 : s_plan[i].step, seg1 ? s_plan[i].P1 : s_plan[i].P0);
-        } else {
+        } else if (!UNIT) {
             P = fma(fd, s_plan[i].step, s_plan[i].P0);            // exact, see zl_plan.h
         }
         // :198-199 -- P >= 0 here, so pos = floor(P) and alpha = (float)(P - pos) = (float)fract(P), both exact
-        const int pos = (int)P;
-        alpha[u] = (float)__builtin_amdgcn_fract(P);
+        int pos;
+        if (UNIT) {
+            // step == 1 inside an exact run: every frame has the fractional part of P0 and the integer part moves by f
+            pos = s_unit[i].ipos + f;
+            alpha[u] = s_unit[i].alpha;
+        } else {
+            pos = (int)P;
+            alpha[u] = (float)__builtin_amdgcn_fract(P);
+        }
         const int dur = s_vc[i].sample_duration;
         const bool inb = dur > pos;                               // :204 guard (Q5)
         // out of range: gather the zero padding behind the source (8 frames, written by zl_k_interleave), so that
@@ -317,8 +327,8 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
 }
 
 // The same for chunks of mono sources: an 8-byte gather [x0 x1] (16 bytes [x-1 x0 x1 x2] for Hermite), r = l (:205, Q4).
-template <uint32_t MODE, bool SEG2, int U>
-static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
+template <uint32_t MODE, bool SEG2, bool UNIT, int U>
+static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
                                                                 int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
 {
     constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
@@ -333,11 +343,12 @@ static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A,
         if (SEG2) {
             const bool seg1 = f >= s_plan[i].n1;
             P = fma((double)(f - (seg1 ? s_plan[i].n1 : 0)), seg1 ? s_plan[i].step1 : s_plan[i].step, seg1 ? s_plan[i].P1 : s_plan[i].P0);
-        } else {
+        } else if (!UNIT) {
             P = fma(fd, s_plan[i].step, s_plan[i].P0);            // exact, see zl_plan.h
         }
-        const int pos = (int)P;                                   // :198-199 (P >= 0)
-        alpha[u] = (float)__builtin_amdgcn_fract(P);
+        int pos;                                                  // :198-199 (P >= 0)
+        if (UNIT) { pos = s_unit[i].ipos + f; alpha[u] = s_unit[i].alpha; }
+        else      { pos = (int)P; alpha[u] = (float)__builtin_amdgcn_fract(P); }
         const int dur = s_vc[i].sample_duration;
         const bool inb = dur > pos;                               // :204 guard (Q5)
         int p = inb ? pos : dur + 1;                              // out of range: the zero padding behind the source
@@ -475,6 +486,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     __shared__ ZlVoiceConst s_vc[ZL_K2_CHUNK];
     __shared__ int s_cls_[BPW][ZL_K2_CHUNK];          // per voice: 1 = plays this block, 2 = per-frame control
     __shared__ int s_chunk_[BPW][ZL_K2_CHUNK / U];    // class of each chunk of U voices
+    __shared__ ZlUnit s_unit_[BPW][ZL_K2_CHUNK];
     __shared__ int   s_pk[2][4];                      // fused level scan: per-wave partial results
     __shared__ float s_sq[2][4];
 
@@ -491,6 +503,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
     const ZlBlockPlan *s_plan = s_plan_[blk];
     const int *s_cls = s_cls_[blk];
     const int *s_chunk = s_chunk_[blk];
+    const ZlUnit *s_unit = s_unit_[blk];
     // Narrow buses (the reference's 8 voices per channel): one workgroup renders A.NB whole buses, one after the other,
     // from ONE staging pass over their NB * VPB <= 128 voices -- the gathers of consecutive buses keep flowing and the
     // fixed costs per workgroup are shared.  NB == 1: one (bus, mix group) per workgroup.
@@ -586,21 +599,23 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
             const float gprod = vc.lgain * vc.rgain * vc.clip_volume * pl.env;     // finite iff every factor is (or one is 0 * inf = NaN)
             if (cls == 1 && pl.nseg <= 2 && !(pl.flags & ZL_PLAN_ENV) && pl.n_active == N && (vc.channels == 1 || vc.channels == 2) && !A.trace
                 && (gprod - gprod) == 0.0f)
-                cls |= 4 | (pl.nseg == 2 ? 8 : 0) | (vc.channels == 1 ? 16 : 0);
+                cls |= 4 | (pl.nseg == 2 ? 8 : 0) | (vc.channels == 1 ? 16 : 0) | ((pl.nseg == 1 && pl.step == 1.0 && pl.P0 < 1073741824.0) ? 32 : 0);
+            { ZlUnit un; un.ipos = (int)pl.P0; un.alpha = (float)(pl.P0 - (double)un.ipos); s_unit_[b][i] = un; }
             if (b == 0) s_vc[i] = vc;
             s_plan_[b][i] = pl;                   // idle slots: a harmless record with no active frame
             s_cls_[b][i] = cls;
             // class of each chunk of U voices: OR of bits 1, 2, 8; 4 = every voice simple and of one source layout, 16 = all
             // mono (ballots over the wave's 64 voices)
             const unsigned long long m1 = __ballot(cls & 1), m2 = __ballot(cls & 2), m4 = __ballot(cls & 4), m8 = __ballot(cls & 8),
-                                     m16 = __ballot(cls & 16);
+                                     m16 = __ballot(cls & 16), m32 = __ballot(cls & 32);
             const int lane = i & 63;
             if (lane < 64 / U) {
                 const unsigned long long full = (1ull << U) - 1ull;
                 const int sh = lane * U;
                 const unsigned long long mono = (m16 >> sh) & full;
                 const int cc = (((m1 >> sh) & full) ? 1 : 0) | (((m2 >> sh) & full) ? 2 : 0) | (((m8 >> sh) & full) ? 8 : 0)
-                             | (((((m4 >> sh) & full) == full) && (mono == 0 || mono == full)) ? 4 : 0) | (mono == full ? 16 : 0);
+                             | (((((m4 >> sh) & full) == full) && (mono == 0 || mono == full)) ? 4 : 0) | (mono == full ? 16 : 0)
+                             | ((((m32 >> sh) & full) == full) ? 32 : 0);
                 s_chunk_[b][(i >> 6) * (64 / U) + lane] = cc;
             }
         }
@@ -615,10 +630,12 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
             if (cc) zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
 #endif
             if (cc == 0) {                                        // nobody in this chunk plays (SamplerSynth.cpp:137)
-            } else if ((cc & 28) == 4)  zl_k2_chunk_simple<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 20) == 4)    zl_k2_chunk_simple<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 28) == 20)   zl_k2_chunk_simple_mono<MODE, false, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 20) == 20)   zl_k2_chunk_simple_mono<MODE, true, U>(A, s_plan, s_vc, c0, vb, f, fd, wantPeak, accL, accR);
+            } else if ((cc & 60) == 36) zl_k2_chunk_simple<MODE, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 28) == 4)    zl_k2_chunk_simple<MODE, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 4)    zl_k2_chunk_simple<MODE, true, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 60) == 52)   zl_k2_chunk_simple_mono<MODE, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 28) == 20)   zl_k2_chunk_simple_mono<MODE, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 20)   zl_k2_chunk_simple_mono<MODE, true, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
             else {
                 // general chunks (events, second segments, mixed layouts, per-frame control) are rare: run them as
                 // two half-chunks so their extra per-voice registers do not set the kernel's register budget

@@ -250,11 +250,13 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
             // taps pos-1 .. pos+2 as two 16-byte loads; at the source edges (not wide) the pair pos, pos+1 comes first
             const bool wide = inb && pos >= 1 && pos + 2 <= dur;
             p -= wide ? 1 : 0;
-            d[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p);
-            e[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p + 4);      // inside the arena padding at the end
+            // (uniform 64-bit base + 32-bit byte offset: the scalar-base form of global_load, no 64-bit VALU address)
+            const uint32_t ob = (uint32_t)p << 3;
+            d[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ob);
+            e[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ob + 16u);   // inside the arena padding at the end
             widem |= wide ? (1 << u) : 0;
         } else {
-            d[u] = *reinterpret_cast<const zl_f4a4 *>(src + 2 * (size_t)p);
+            d[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ((uint32_t)p << 3));
         }
     }
     zl_f2 acc = {accL, accR};
@@ -358,10 +360,10 @@ static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A,
         if (HERM) {
             const bool wide = inb && pos >= 1 && pos + 2 <= dur;
             p -= wide ? 1 : 0;
-            d4[u] = *reinterpret_cast<const zl_f4a4 *>(src + (size_t)p);
+            d4[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ((uint32_t)p << 2));
             widem |= wide ? (1 << u) : 0;
         } else {
-            d2[u] = *reinterpret_cast<const zl_f2a4b *>(src + (size_t)p);
+            d2[u] = *reinterpret_cast<const zl_f2a4b *>(reinterpret_cast<const char *>(src) + ((uint32_t)p << 2));
         }
     }
 #pragma unroll

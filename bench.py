@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--hermite", action="store_true", help="4-tap Hermite interpolation (ZLHIP_MODE_HERMITE, config 4)")
     ap.add_argument("--source-rate", type=float, default=0.0, help="sample rate of the sources (default: --fs)")
     ap.add_argument("--voices-per-task", type=int, default=0)
+    ap.add_argument("--fanout", default="none", choices=["none", "fused", "separate"],
+                    help="also produce the JackPassthrough fan-out [B][6][frames] of every bus (SURVEY 8f n1): fused into the bus "
+                         "write (zlhip_render_batch_fanout) or as a separate pass over the bus (non-default variant, N = 1)")
     ap.add_argument("--plan-window", type=int, default=0)
     ap.add_argument("--cpu-blocks", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -224,6 +227,12 @@ def main():
         overlapped = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32), dst=0,
                                                   algorithm=args.reduce_algo)
 
+    fan = fan_params = None
+    if args.fanout != "none":
+        from libzl_amd import PassthroughParams
+        fan = torch.zeros((B, 6, KB * N), device=dev, dtype=torch.float32)
+        fan_params = [PassthroughParams(0.9, 0.5, 0.25, 0.1 * (b % 3 - 1), 0) for b in range(B)]     # every pair multiplied
+
     def step(i, timed):
         # render this rank's voices, sum the partial buses onto rank 0 (one RCCL reduce), levels on the root
         if distributed and args.dist_backend != "nccl":
@@ -237,8 +246,12 @@ def main():
                 syn.levels_scan_device(bus.data_ptr(), KB, N, stream=sptr)
         elif distributed:
             overlapped.step(KB, N, clock_sets[i], stream=sptr)       # reduce of step i overlaps rendering of step i+1
+        elif args.fanout == "fused":
+            syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr, fan_params=fan_params, fan_out_dev=fan.data_ptr())
         else:
             syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr)
+            if args.fanout == "separate":
+                syn.passthrough(fan_params, bus.data_ptr(), fan.data_ptr(), KB * N, stream=sptr)
 
     torch.cuda.synchronize()
     torch.cuda.set_stream(stream)
@@ -311,7 +324,7 @@ def main():
     value = total_vs / dt
     # algorithmic bytes of the K2 launches of one step: every source frame once per block
     # (summed by K1 per voice-block: (ceil(N*ratio)+taps-1)*channels*4) + the bus write; a step is `launches` K2 launches
-    bus_bytes = B * 2 * N * 4 * KB
+    bus_bytes = B * 2 * N * 4 * KB * (4 if args.fanout == "fused" else 1)      # fused fan-out: three more stereo pairs per bus frame
     k2_bytes_step = src_bytes + bus_bytes
     state_bytes = V * 2 * VOICE_STATE_BYTES + B * 16 * KB
     k2_step_ms = float(np.mean(render_ms)) if render_ms else float("nan")      # sum of the step's K2 launches (HIP events)
@@ -322,7 +335,7 @@ def main():
     # HBM traffic of K2 per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process):
     # traffic / algorithmic measured on this workload, applied to this run's algorithmic bytes; null for other workloads
     traffic = None
-    default_workload = (V, B, N, KB, args.loop_seconds, notes, args.hermite, source_rate, args.mono, args.beat_locked) == (1024, 8, 256, 8192, 2.0, (60, 60), False, args.fs, False, False)
+    default_workload = (V, B, N, KB, args.loop_seconds, notes, args.hermite, source_rate, args.mono, args.beat_locked) == (1024, 8, 256, 8192, 2.0, (60, 60), False, args.fs, False, False) and args.fanout == "none"
     pmc_file = os.path.join(ROOT, "profiles", "round1_d_pmc.json")
     if default_workload and os.path.exists(pmc_file):
         traffic = json.load(open(pmc_file))["traffic_over_algorithmic"] * k2_bytes
@@ -338,7 +351,7 @@ def main():
                             + (f"fs=sr={args.fs:.0f} (ratio 1)" if notes[0] == notes[1] and source_rate == args.fs else
                                f"fs={args.fs:.0f}, sources at {source_rate:.0f}, MIDI notes {notes[0]}..{notes[1]} around root 60") +
                             f", {'4-tap Hermite' if args.hermite else 'linear'} interp, faithful mode, distinct {args.loop_seconds:g} s sources "
-                            f"({arena / 1e6:.0f} MB), bus int peaks per block" + (f", bus reduce to rank 0 per step over RCCL ({args.reduce_algo}), overlapped with the next step" if distributed else ""),
+                            f"({arena / 1e6:.0f} MB), bus int peaks per block" + ({"none": "", "fused": ", JackPassthrough fan-out fused into the bus write", "separate": ", JackPassthrough fan-out as a separate pass"}[args.fanout]) + (f", bus reduce to rank 0 per step over RCCL ({args.reduce_algo}), overlapped with the next step" if distributed else ""),
                 "voices_per_gpu": V, "buses": B, "frames_per_block": N, "blocks_per_step": KB, "parallelism": f"voices sharded x{world}",
             },
             "roofline": {

@@ -118,6 +118,7 @@ SIGNATURES = {
     "zlhip_voice_is_playing": (C.c_int, [_E, C.c_int32, C.c_int32]),
     "zlhip_render": (C.c_int, [_E, C.c_int32, C.POINTER(Clock), C.c_void_p, C.c_void_p]),
     "zlhip_render_batch": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(Clock), C.c_void_p, C.c_void_p]),
+    "zlhip_render_batch_fanout": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(Clock), C.c_void_p, C.POINTER(PassthroughParams), C.c_void_p, C.c_void_p]),
     "zlhip_synchronize": (C.c_int, [_E]),
     "zlhip_read_bus": (C.c_int, [_E, C.c_void_p, C.c_size_t]),
     "zlhip_voice_reports": (C.c_int, [_E, C.POINTER(VoiceReport), C.c_int32]),

@@ -24,8 +24,6 @@
 
 namespace {
 
-struct PassParamsDev { float dry, fx1, fx2, pan; int muted; };
-
 template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
 }  // namespace
@@ -62,6 +60,7 @@ struct zlhip_engine {
     // (and the planning stream plans) call i+1 while call i still renders; a slot is reused by call i+2.
     struct CallSlot {
         ZlClock *hClocks = nullptr, *dClocks = nullptr;
+        ZlPassParams *hPass = nullptr, *dPass = nullptr;   // fused fan-out parameters of the call
         ZlReport *hReports = nullptr, *dReports = nullptr;
         float *hGain = nullptr;
         ZlBatchStats *hStats = nullptr, *dStats = nullptr;
@@ -78,7 +77,7 @@ struct zlhip_engine {
     float *dBus = nullptr;
     ZlBlockLevels *dLevels = nullptr; ZlLevelsState *dLevelState = nullptr;
     ZlVoiceOp *dOps = nullptr; ZlOpRange *dOpRanges = nullptr;
-    int32_t *dTrace = nullptr; PassParamsDev *dPass = nullptr;
+    int32_t *dTrace = nullptr; ZlPassParams *dPass = nullptr;
     size_t opsCap = 0, rangesCap = 0, traceInts = 0;
     int maxGroups = 1;
 
@@ -194,9 +193,9 @@ void zlhip_engine_destroy(zlhip_engine *e)
         if (q.k1done) (void)hipEventDestroy(q.k1done);
     }
     for (auto &c : e->slots) {
-        void *cd[] = { c.dClocks, c.dReports, c.dStats };
+        void *cd[] = { c.dClocks, c.dReports, c.dStats, c.dPass };
         for (void *p : cd) if (p) (void)hipFree(p);
-        void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats };
+        void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats, c.hPass };
         for (void *p : ch) if (p) (void)hipHostFree(p);
         for (auto &x : c.evK2) if (x) (void)hipEventDestroy(x);
         hipEvent_t evs[] = { c.evBegin, c.evEnd, c.done };
@@ -299,6 +298,8 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             chk(dalloc(&c.dReports, V), "reports");
             chk(dalloc(&c.dStats, 1), "stats");
             chk(hipHostMalloc((void **)&c.hClocks, K * sizeof(ZlClock)), "hClocks");
+            chk(dalloc(&c.dPass, B), "fan-out params");
+            chk(hipHostMalloc((void **)&c.hPass, std::max<size_t>(B, 1) * sizeof(ZlPassParams)), "hPass");
             chk(hipHostMalloc((void **)&c.hReports, V * sizeof(ZlReport)), "hReports");
             chk(hipHostMalloc((void **)&c.hGain, V * sizeof(float)), "hGain");
             chk(hipHostMalloc((void **)&c.hStats, sizeof(ZlBatchStats)), "hStats");
@@ -574,9 +575,20 @@ static int harvest_slot(zlhip_engine *e, zlhip_engine::CallSlot &c)
     return ZLHIP_OK;
 }
 
+static ZlPassParams pass_params(const zlhip_passthrough_params &p)
+{
+    return ZlPassParams{ p.dry_amount, p.wet_fx1_amount, p.wet_fx2_amount, p.pan_amount, p.muted };
+}
+
 int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks, float *bus_out_dev, void *stream)
 {
-    if (!e || !clocks) return ZLHIP_ERR_INVALID;
+    return zlhip_render_batch_fanout(e, nblocks, nframes, clocks, bus_out_dev, nullptr, nullptr, stream);
+}
+
+int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks, float *bus_out_dev,
+                              const zlhip_passthrough_params *fan_params, float *fan_out_dev, void *stream)
+{
+    if (!e || !clocks || ((fan_params == nullptr) != (fan_out_dev == nullptr))) return ZLHIP_ERR_INVALID;
     if (nblocks < 1 || nblocks > e->cfg.max_batch_blocks) return fail(e, ZLHIP_ERR_CAPACITY, "nblocks exceeds max_batch_blocks");
     if (nframes < 64 || nframes > e->cfg.max_frames || (nframes % 64) != 0 || (nframes > 256 && (nframes % 256) != 0))
         return fail(e, ZLHIP_ERR_INVALID, "nframes must be a multiple of 64 (of 256 above 256) and <= max_frames");
@@ -662,6 +674,11 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     if (e->lastPlanStream && e->lastPlanStream != ps) ZL_HIP(e, hipStreamWaitEvent(ps, e->evPlanTail, 0));
     if (nblocks == 1) { A.inline_clock = 1; A.clock0 = c.hClocks[0]; A.fuse_assemble = 1; }   // a real-time block: fewer commands
     else ZL_HIP(e, hipMemcpyAsync(c.dClocks, c.hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, ps));
+    if (fan_out_dev) {                                             // the rendering stream is ordered behind ps by the window events
+        for (int b = 0; b < A.B; ++b) c.hPass[b] = pass_params(fan_params[b]);
+        ZL_HIP(e, hipMemcpyAsync(c.dPass, c.hPass, (size_t)A.B * sizeof(ZlPassParams), hipMemcpyHostToDevice, ps));
+        A.pass = c.dPass; A.fan = fan_out_dev;
+    }
     int rc = upload_ops(e, A, ps);
     if (rc != ZLHIP_OK) return rc;
     // (the slot's statistics were cleared by the report kernel of the call that used it before)
@@ -891,10 +908,9 @@ int zlhip_passthrough_process(zlhip_engine *e, const zlhip_passthrough_params *p
     if (!e || !params || !in_dev || !out_dev || frames < 1) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    std::vector<PassParamsDev> pp((size_t)e->cfg.num_buses);
-    for (int b = 0; b < e->cfg.num_buses; ++b)
-        pp[(size_t)b] = PassParamsDev{ params[b].dry_amount, params[b].wet_fx1_amount, params[b].wet_fx2_amount, params[b].pan_amount, params[b].muted };
-    ZL_HIP(e, hipMemcpyAsync(e->dPass, pp.data(), pp.size() * sizeof(PassParamsDev), hipMemcpyHostToDevice, s));
+    std::vector<ZlPassParams> pp((size_t)e->cfg.num_buses);
+    for (int b = 0; b < e->cfg.num_buses; ++b) pp[(size_t)b] = pass_params(params[b]);
+    ZL_HIP(e, hipMemcpyAsync(e->dPass, pp.data(), pp.size() * sizeof(ZlPassParams), hipMemcpyHostToDevice, s));
     ZL_KERNEL(e, zl_launch_passthrough(e->dPass, in_dev, out_dev, e->cfg.num_buses, (long long)frames, s));
     e->outstanding = true;
     return ZLHIP_OK;

@@ -547,6 +547,26 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
                 if (written) { outL[f + 1] = accL; outR[f + 1] = accR; }
                 if (f == 0)  { outL[0] = 0.0f;    outR[0] = 0.0f; }
             }
+            if (A.fan && A.groups == 1) {
+                // fused JackPassthrough fan-out of the finished bus (JackPassthrough.cpp:45-115): three more stereo pairs
+                // written from the registers that hold the mix -- no second pass over the bus
+                const size_t KN = (size_t)A.Ktot * N;
+                const ZlPassParams pp = A.pass[bus];
+                float *o = A.fan + ((size_t)bus * 6) * KN + (size_t)(A.k0 + k) * N;
+                float lm, rm; zl_pass_pan(pp, lm, rm);
+                const float amounts[3] = { pp.dry, pp.fx1, pp.fx2 };
+                const int fo = (MODE & ZL_MODE_FIX_DELAY) ? f : f + 1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float ol, orr;
+                    zl_pass_pair(pp, amounts[c], lm, rm, accL, accR, ol, orr);
+                    if (fo < N) { o[(size_t)(2 * c) * KN + fo] = ol; o[(size_t)(2 * c + 1) * KN + fo] = orr; }
+                    if (!(MODE & ZL_MODE_FIX_DELAY) && f == 0) {   // the bus holds 0 in frame 0 (Q2)
+                        zl_pass_pair(pp, amounts[c], lm, rm, 0.0f, 0.0f, ol, orr);
+                        o[(size_t)(2 * c) * KN] = ol; o[(size_t)(2 * c + 1) * KN] = orr;
+                    }
+                }
+            }
         }
         // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of its
         //      whole block(s) (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
@@ -686,6 +706,18 @@ __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const flo
             const float *p = A.partials + (((size_t)k * A.B + bus) * A.groups) * 2 * (size_t)N;
             for (int g = 0; g < A.groups; ++g) { l += p[f]; r += p[N + f]; p += 2 * (size_t)N; }
             outL[f] = l; outR[f] = r;
+            if (A.fan) {                                           // fused JackPassthrough fan-out, as in K2
+                const ZlPassParams pp = A.pass[bus];
+                float *o = A.fan + ((size_t)bus * 6) * KN + (size_t)(A.k0 + k) * N;
+                float lm, rm; zl_pass_pan(pp, lm, rm);
+                const float amounts[3] = { pp.dry, pp.fx1, pp.fx2 };
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float ol, orr;
+                    zl_pass_pair(pp, amounts[c], lm, rm, l, r, ol, orr);
+                    o[(size_t)(2 * c) * KN + f] = ol; o[(size_t)(2 * c + 1) * KN + f] = orr;
+                }
+            }
         } else {
             l = inL[f]; r = inR[f];
         }
@@ -759,9 +791,9 @@ __global__ void zl_k_reports(const ZlReport *reports, int V, float *gain_out, Zl
 }
 
 // ------------------------------------------------------------------------------------------------
-// JackPassthrough: in [B][2][frames] -> out [B][6][frames]
-struct ZlPassParams { float dry, fx1, fx2, pan; int muted; };
-
+// JackPassthrough: in [B][2][frames] -> out [B][6][frames].  Pure streaming (8 B read, 24 B written per bus frame):
+// VEC = 4 frames per lane with 16-byte accesses when frames % 4 == 0 and the buffers are 16-byte aligned.
+template <int VEC>
 __global__ void __launch_bounds__(256) zl_k_passthrough(const ZlPassParams *params, const float *in, float *out, long long frames)
 {
     const int bus = blockIdx.y;
@@ -769,18 +801,25 @@ __global__ void __launch_bounds__(256) zl_k_passthrough(const ZlPassParams *para
     const float *inL = in + (size_t)bus * 2 * frames, *inR = inL + frames;
     float *o = out + (size_t)bus * 6 * frames;
     const float amounts[3] = { p.dry, p.fx1, p.fx2 };
-    const float lm = fminf(1 - p.pan, 1.0f), rm = fminf(1 + p.pan, 1.0f);   // JackPassthrough.cpp:100-101
-    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < frames; f += (long long)gridDim.x * blockDim.x) {
-        const float sl = inL[f], sr = inR[f];
+    float lm, rm; zl_pass_pan(p, lm, rm);
+    const long long nvec = frames / VEC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float sl[VEC], sr[VEC];
+        if (VEC == 4) {
+            const float4 a = reinterpret_cast<const float4 *>(inL)[i], b = reinterpret_cast<const float4 *>(inR)[i];
+            sl[0] = a.x; sl[1 % VEC] = a.y; sl[2 % VEC] = a.z; sl[3 % VEC] = a.w;
+            sr[0] = b.x; sr[1 % VEC] = b.y; sr[2 % VEC] = b.z; sr[3 % VEC] = b.w;
+        } else { sl[0] = inL[i]; sr[0] = inR[i]; }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float ol, orr;
-            if (p.muted)                               { ol = 0.0f; orr = 0.0f; }             // :55-61
-            else if (p.pan == 0 && amounts[c] == 0)    { ol = 0.0f; orr = 0.0f; }             // memset fast path
-            else if (p.pan == 0 && amounts[c] == 1)    { ol = sl;   orr = sr; }               // memcpy fast path
-            else { ol = amounts[c] * sl * lm; orr = amounts[c] * sr * rm; }                   // :100-109
-            o[(size_t)(2 * c) * frames + f] = ol;
-            o[(size_t)(2 * c + 1) * frames + f] = orr;
+            float ol[VEC], orr[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) zl_pass_pair(p, amounts[c], lm, rm, sl[j], sr[j], ol[j], orr[j]);
+            float *oL = o + (size_t)(2 * c) * frames, *oR = oL + frames;
+            if (VEC == 4) {
+                reinterpret_cast<float4 *>(oL)[i] = make_float4(ol[0], ol[1 % VEC], ol[2 % VEC], ol[3 % VEC]);
+                reinterpret_cast<float4 *>(oR)[i] = make_float4(orr[0], orr[1 % VEC], orr[2 % VEC], orr[3 % VEC]);
+            } else { oL[i] = ol[0]; oR[i] = orr[0]; }
         }
     }
 }
@@ -864,10 +903,12 @@ int zl_launch_levels_tick(ZlLevelsState *state, const ZlBlockLevels *levels, int
 
 int zl_launch_passthrough(const void *params_dev, const float *in, float *out, int B, long long frames, hipStream_t s)
 {
-    long long nb = (frames + 255) / 256;
+    const bool vec = (frames % 4) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0;
+    long long nb = (frames / (vec ? 4 : 1) + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(zl_k_passthrough, dim3((unsigned)nb, B), dim3(256), 0, s, (const ZlPassParams *)params_dev, in, out, frames);
+    if (vec) hipLaunchKernelGGL(zl_k_passthrough<4>, dim3((unsigned)nb, B), dim3(256), 0, s, (const ZlPassParams *)params_dev, in, out, frames);
+    else     hipLaunchKernelGGL(zl_k_passthrough<1>, dim3((unsigned)nb, B), dim3(256), 0, s, (const ZlPassParams *)params_dev, in, out, frames);
     ZL_LAUNCH_CHECK();
     return 0;
 }

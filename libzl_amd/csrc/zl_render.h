@@ -76,6 +76,24 @@ ZL_HD inline void zl_mix_frame(const ZlTaps &t, float alpha, bool inb, bool wide
     rout = rpan * mSignal - sSignal;                             // :211
 }
 
+// JackPassthrough fan-out of one bus frame (JackPassthrough.cpp:55-109): output pair c (0 dry, 1 wetFx1, 2 wetFx2) of
+// input (sl, sr).  lm, rm = zl_pass_pan().  The memset / memcpy fast paths of the reference are value-identical to
+// these selects (they differ from the multiply only in the sign of zero and for non-finite input, which is why they
+// are kept).
+ZL_HD inline void zl_pass_pan(const ZlPassParams &p, float &lm, float &rm)
+{
+    const float a = 1 - p.pan, b = 1 + p.pan;
+    lm = (1.0f < a) ? 1.0f : a;                                  // std::min(1 - panAmount, 1.0f), :100
+    rm = (1.0f < b) ? 1.0f : b;                                  // :101
+}
+ZL_HD inline void zl_pass_pair(const ZlPassParams &p, float amount, float lm, float rm, float sl, float sr, float &ol, float &orr)
+{
+    if (p.muted)                            { ol = 0.0f; orr = 0.0f; }                      // :55-61
+    else if (p.pan == 0 && amount == 0)     { ol = 0.0f; orr = 0.0f; }                      // :66-69 memset
+    else if (p.pan == 0 && amount == 1)     { ol = sl;   orr = sr; }                        // :70-73 memcpy
+    else                                    { ol = amount * sl * lm; orr = amount * sr * rm; }   // :100-109
+}
+
 // Host-side convenience used by tests/cpu_harness: gather + mix for one (voice, frame).
 // src points at the voice's source in the arena (interleaved stereo or mono).
 template <uint32_t MODE>

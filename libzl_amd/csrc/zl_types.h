@@ -154,6 +154,9 @@ struct ZlLevelsState {            // AudioLevelsChannel meter state per bus
     int32_t frames, pad;
 };
 
+// JackPassthrough parameters of one bus (JackPassthrough.cpp:27-31)
+struct ZlPassParams { float dry, fx1, fx2, pan; int muted; };
+
 struct ZlBatchStats {
     unsigned long long source_bytes;
     unsigned long long slow_blocks;
@@ -193,6 +196,8 @@ struct ZlBatch {
     ZlReport           *reports;  // [V]
     float              *partials; // [K][B][groups][2][N]  (only when groups > 1)
     float              *bus;      // [B][2][Ktot*N]
+    const ZlPassParams *pass;     // [B] JackPassthrough parameters of the fused fan-out (with fan)
+    float              *fan;      // [B][6][Ktot*N] dry L,R / wetFx1 L,R / wetFx2 L,R of every bus, or nullptr
     ZlBlockLevels      *levels;   // [K][B]
     int32_t            *pos_trace;// [K][V][N] or null
     ZlBatchStats       *stats;

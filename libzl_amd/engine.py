@@ -181,8 +181,14 @@ class SamplerSynth:
         self._last = (1, nframes)
         return L, R
 
-    def render_batch(self, nblocks: int, nframes: int, clocks, bus_out_dev: Optional[int] = None, stream: Optional[int] = None):
-        self._ck(self._lib.zlhip_render_batch(self._e, nblocks, nframes, clocks, bus_out_dev, stream), "render_batch")
+    def render_batch(self, nblocks: int, nframes: int, clocks, bus_out_dev: Optional[int] = None, stream: Optional[int] = None,
+                     fan_params: Optional[Sequence[PassthroughParams]] = None, fan_out_dev: Optional[int] = None):
+        """fan_params + fan_out_dev: also write the JackPassthrough fan-out [num_buses][6][nblocks*nframes] (fused)."""
+        if fan_out_dev is not None:
+            arr = (PassthroughParams * self.num_buses)(*fan_params)
+            self._ck(self._lib.zlhip_render_batch_fanout(self._e, nblocks, nframes, clocks, bus_out_dev, arr, fan_out_dev, stream), "render_batch_fanout")
+        else:
+            self._ck(self._lib.zlhip_render_batch(self._e, nblocks, nframes, clocks, bus_out_dev, stream), "render_batch")
         self._last = (nblocks, nframes)
 
     def synchronize(self):

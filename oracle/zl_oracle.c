@@ -678,8 +678,9 @@ void zlo_passthrough_process(const zlo_passthrough *p, const float *inL, const f
         }
     }
     if (p->panAmount != 0 || output[0] || output[1] || output[2]) {   /* :93-112 */
-        const float lm = (1 - p->panAmount) < 1.0f ? (1 - p->panAmount) : 1.0f;   /* std::min(1 - panAmount, 1.0f) */
-        const float rm = (1 + p->panAmount) < 1.0f ? (1 + p->panAmount) : 1.0f;
+        const float la = 1 - p->panAmount, ra = 1 + p->panAmount;
+        const float lm = (1.0f < la) ? 1.0f : la;               /* std::min(1 - panAmount, 1.0f) = (b < a) ? b : a */
+        const float rm = (1.0f < ra) ? 1.0f : ra;
         for (uint32_t f = 0; f < nframes; ++f) {
             const float sl = inL[f], sr = inR[f];
             for (int k = 0; k < 3; ++k) {

@@ -131,10 +131,12 @@ def run_oracle(scene: Scene, batch: int = 1 << 30, threads: int = 1, fast: bool 
 
 
 def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bool = False, force_slow: bool = False,
-                pipelined: bool = False, no_periodic: bool = False, **factory_kw):
+                pipelined: bool = False, no_periodic: bool = False, fanout=None, **factory_kw):
     """factory(**kwargs) -> object with the libzl_amd.SamplerSynth surface (engine or CPU harness).
     pipelined (GPU engine only): every call renders into its own device buffer on one HIP stream and nothing is read
-    back or synchronised until the end, so consecutive zlhip_render_batch calls overlap."""
+    back or synchronised until the end, so consecutive zlhip_render_batch calls overlap.
+    fanout (GPU engine only): a PassthroughParams per bus; every call also writes the fused JackPassthrough fan-out, which
+    is left in syn.fan_result as [num_buses][6][frames]."""
     # the oracle's setters are the single source of clip parameters for both sides
     ref = zo.OracleSynth(1, 1, scene.fs, scene.mode, max_sounds=max(8, len(scene.sounds)))
     syn = factory(num_buses=scene.num_buses, voices_per_bus=scene.voices_per_bus, mode=scene.mode,
@@ -150,9 +152,10 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
         syn.set_clip_params(i, snapshot_clip(ref.clips[i]))
     if trace or force_slow or no_periodic:
         syn.enable_trace(trace or force_slow, force_slow=force_slow, no_periodic=no_periodic)
-    buses, traces = [], []
-    if pipelined:
+    buses, traces, fans = [], [], []
+    if pipelined or fanout is not None:
         import torch
+    if pipelined:
         stream = torch.cuda.Stream()
     for (k0, n) in _segments(scene, batch):
         for ev in scene.events.get(k0, []):
@@ -163,12 +166,16 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
             elif ev[0] == "clip":
                 ev[2](ref.lib, ref.clips[ev[1]])
                 syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))
+        fan_kw = {}
+        if fanout is not None:
+            fans.append(torch.full((scene.num_buses, 6, n * scene.nframes), 7.0, device="cuda", dtype=torch.float32))
+            fan_kw = dict(fan_params=fanout, fan_out_dev=fans[-1].data_ptr())
         if pipelined:
             out = torch.zeros((scene.num_buses, 2, n * scene.nframes), device="cuda", dtype=torch.float32)
-            syn.render_batch(n, scene.nframes, scene.make_clocks(k0, n), bus_out_dev=out.data_ptr(), stream=stream.cuda_stream)
+            syn.render_batch(n, scene.nframes, scene.make_clocks(k0, n), bus_out_dev=out.data_ptr(), stream=stream.cuda_stream, **fan_kw)
             buses.append(out)
             continue
-        syn.render_batch(n, scene.nframes, scene.make_clocks(k0, n))
+        syn.render_batch(n, scene.nframes, scene.make_clocks(k0, n), **fan_kw)
         buses.append(np.array(syn.read_bus(), copy=True))
         if trace:
             traces.append(syn.read_trace())
@@ -176,6 +183,10 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
         syn.synchronize()
         torch.cuda.synchronize()
         buses = [b.cpu().numpy() for b in buses]
+    if fanout is not None:
+        syn.synchronize()
+        torch.cuda.synchronize()
+        syn.fan_result = np.concatenate([f.cpu().numpy() for f in fans], axis=2)
     reports = syn.voice_reports()
     return np.concatenate(buses, axis=2), reports, syn, (np.concatenate(traces, axis=0) if traces else None)
 

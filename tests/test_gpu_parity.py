@@ -384,12 +384,13 @@ def test_levels_tick_matches_oracle(Engine):
     syn.close()
 
 
-def test_passthrough_matches_oracle(Engine):
+@pytest.mark.parametrize("n", [1000, 1001, 64])      # 16-byte accesses (frames % 4 == 0) and the scalar form
+def test_passthrough_matches_oracle(Engine, n):
     import torch
     from oracle import zl_oracle as zo
     from libzl_amd import PassthroughParams
     lib = zo.load()
-    B, n = 3, 1000
+    B = 3
     x = torch.rand((B, 2, n), device="cuda") * 2 - 1
     out = torch.full((B, 6, n), 7.0, device="cuda")
     syn = Engine(B, 2, max_frames=64, max_batch_blocks=1, max_sounds=4)
@@ -405,6 +406,54 @@ def test_passthrough_matches_oracle(Engine):
         lib.zlo_passthrough_process(C.byref(p), L.ctypes.data, R.ctypes.data, arr, n)
         for c in range(6):
             assert np.array_equal(oh[b, c].view(np.int32), outs[c].view(np.int32)), (b, c)
+    syn.close()
+
+
+def _oracle_fanout(bus, params):
+    """JackPassthrough (oracle) applied to every bus of [B][2][frames]."""
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    B, _, n = bus.shape
+    out = np.zeros((B, 6, n), dtype=np.float32)
+    for b in range(B):
+        rows = [np.zeros(n, dtype=np.float32) for _ in range(6)]
+        arr = (C.c_void_p * 6)(*[o.ctypes.data for o in rows])
+        p = zo.Passthrough(params[b].dry_amount, params[b].wet_fx1_amount, params[b].wet_fx2_amount, params[b].pan_amount, params[b].muted)
+        L = np.ascontiguousarray(bus[b, 0]); R = np.ascontiguousarray(bus[b, 1])
+        lib.zlo_passthrough_process(C.byref(p), L.ctypes.data, R.ctypes.data, arr, n)
+        out[b] = np.stack(rows)
+    return out
+
+
+FANOUT_CASES = {
+    # name: (scene kwargs, batch, pipelined)
+    "several_buses_per_workgroup": (dict(num_buses=5, voices_per_bus=8, nframes=128, nblocks=12), 1 << 30, False),
+    "four_blocks_per_workgroup":   (dict(num_buses=3, voices_per_bus=16, nframes=64, nblocks=22), 1 << 30, False),
+    "odd_bus_width":               (dict(num_buses=4, voices_per_bus=12, nframes=256, nblocks=9), 4, True),
+    "two_frame_tiles":             (dict(num_buses=3, voices_per_bus=8, nframes=512, nblocks=6), 1 << 30, False),
+    "mix_groups":                  (dict(num_buses=3, voices_per_bus=8, nframes=128, nblocks=10, mix_group=4), 1 << 30, False),
+    "delay_fixed":                 (dict(num_buses=3, voices_per_bus=8, nframes=128, nblocks=10, mode=2), 1 << 30, False),
+    "single_blocks":               (dict(num_buses=4, voices_per_bus=8, nframes=128, nblocks=5), 1, False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(FANOUT_CASES))
+def test_fused_fanout_is_the_passthrough_of_the_bus(Engine, case):
+    """zlhip_render_batch_fanout: bus identical to the plain call (the oracle's), fan-out identical to the oracle's
+    JackPassthrough applied to that bus -- every fast path, negative amounts, pan beyond +-1, in every K2 / K3 shape."""
+    from libzl_amd import PassthroughParams
+    kw, batch, pipelined = FANOUT_CASES[case]
+    sc = random_scene(4242, **kw)
+    zoo = [PassthroughParams(1.0, 0.0, 0.5, 0.0, 0), PassthroughParams(0.8, 1.0, -1.25, -0.3, 0), PassthroughParams(1.0, 1.0, 1.0, 0.0, 1),
+           PassthroughParams(-0.5, 2.0, 0.0, 1.5, 0), PassthroughParams(1.0, 1.0, 1.0, 0.0, 0)]
+    params = [zoo[b % len(zoo)] for b in range(sc.num_buses)]
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=batch, pipelined=pipelined, fanout=params)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    want = _oracle_fanout(ref_bus, params)
+    got = syn.fan_result
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.int32), want.view(np.int32)), np.argwhere(got.view(np.int32) != want.view(np.int32))[:4].tolist()
     syn.close()
 
 

@@ -26,6 +26,19 @@ namespace {
 
 template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)); }
 
+// host memory mapped into the device, grown by doubling (the buffer must be idle)
+template <typename T> hipError_t grow_mapped(T **host, T **dev, size_t *cap, size_t need)
+{
+    if (need <= *cap) return hipSuccess;
+    if (*host) { hipError_t r = hipHostFree(*host); *host = nullptr; *dev = nullptr; *cap = 0; if (r != hipSuccess) return r; }
+    const size_t n = need * 2;
+    hipError_t r = hipHostMalloc((void **)host, n * sizeof(T));
+    if (r != hipSuccess) return r;
+    r = hipHostGetDevicePointer((void **)dev, *host, 0);
+    if (r == hipSuccess) *cap = n;
+    return r;
+}
+
 }  // namespace
 
 struct zlhip_engine {
@@ -61,6 +74,9 @@ struct zlhip_engine {
     struct CallSlot {
         ZlClock *hClocks = nullptr, *dClocks = nullptr;
         ZlPassParams *hPass = nullptr, *dPass = nullptr;   // fused fan-out parameters of the call
+        // the call's voice operations, in host memory mapped into the device: K0 reads them in place (no copy command)
+        ZlVoiceOp *hOps = nullptr, *hOpsDev = nullptr; ZlOpRange *hRanges = nullptr, *hRangesDev = nullptr;
+        size_t opsCap = 0, rangesCap = 0;
         ZlReport *hReports = nullptr, *dReports = nullptr;
         float *hGain = nullptr;
         ZlBatchStats *hStats = nullptr, *dStats = nullptr;
@@ -76,9 +92,8 @@ struct zlhip_engine {
     float *dGain = nullptr;
     float *dBus = nullptr;
     ZlBlockLevels *dLevels = nullptr; ZlLevelsState *dLevelState = nullptr;
-    ZlVoiceOp *dOps = nullptr; ZlOpRange *dOpRanges = nullptr;
     int32_t *dTrace = nullptr; ZlPassParams *dPass = nullptr;
-    size_t opsCap = 0, rangesCap = 0, traceInts = 0;
+    size_t traceInts = 0;
     int maxGroups = 1;
 
     // pinned host staging
@@ -87,7 +102,7 @@ struct zlhip_engine {
 
     // host mirrors
     ZlHostControl hc;                    // voices / sounds / clip parameters / pending ops (zl_host.h)
-    std::vector<ZlVoiceOp> sortedOps; std::vector<ZlOpRange> ranges;
+    std::vector<ZlOpRange> ranges;
 
     // last batch
     int lastK = 0, lastN = 0, lastWindows = 0; float *lastBus = nullptr; bool outstanding = false; bool reportsFresh = false;
@@ -182,8 +197,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->planStream) (void)hipStreamSynchronize(e->planStream);
     if (e->asmStream) (void)hipStreamSynchronize(e->asmStream);
-    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dOps,
-                    e->dOpRanges, e->dTrace, e->dPass };
+    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dTrace, e->dPass };
     for (void *p : dev) if (p) (void)hipFree(p);
     for (auto &q : e->ps) {
         void *pd[] = { q.vconst, q.runs, q.tsegs, q.hdr, q.seg0, q.seg1, q.ctlP, q.ctlEnv, q.partials };
@@ -195,7 +209,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     for (auto &c : e->slots) {
         void *cd[] = { c.dClocks, c.dReports, c.dStats, c.dPass };
         for (void *p : cd) if (p) (void)hipFree(p);
-        void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats, c.hPass };
+        void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats, c.hPass, c.hOps, c.hRanges };
         for (void *p : ch) if (p) (void)hipHostFree(p);
         for (auto &x : c.evK2) if (x) (void)hipEventDestroy(x);
         hipEvent_t evs[] = { c.evBegin, c.evEnd, c.done };
@@ -524,25 +538,19 @@ static int pick_group(const zlhip_engine *e, int K, int N)
     return VPB;
 }
 
-static int upload_ops(zlhip_engine *e, ZlBatch &A, hipStream_t s)
+// The pending voice operations of this call -> the slot's mapped host buffers (the slot is idle: its previous call was
+// waited for), sorted by voice.  K0 reads them over the bus in place: a real-time block with a thousand commands costs
+// no copy command and no staging.
+static int upload_ops(zlhip_engine *e, zlhip_engine::CallSlot &c, ZlBatch &A)
 {
     A.n_op_ranges = 0; A.ops = nullptr; A.op_ranges = nullptr;
-    if (e->hc.pendingOps.empty()) return ZLHIP_OK;
-    e->hc.drain_ops(e->sortedOps, e->ranges);
-    if (e->sortedOps.size() > e->opsCap) {
-        if (e->dOps) ZL_HIP(e, hipFree(e->dOps));
-        e->opsCap = e->sortedOps.size() * 2;
-        ZL_HIP(e, dalloc(&e->dOps, e->opsCap));
-    }
-    if (e->ranges.size() > e->rangesCap) {
-        if (e->dOpRanges) ZL_HIP(e, hipFree(e->dOpRanges));
-        e->rangesCap = e->ranges.size() * 2;
-        ZL_HIP(e, dalloc(&e->dOpRanges, e->rangesCap));
-    }
-    // pageable -> device copies are staged synchronously by the runtime, so the vectors may be reused
-    ZL_HIP(e, hipMemcpyAsync(e->dOps, e->sortedOps.data(), e->sortedOps.size() * sizeof(ZlVoiceOp), hipMemcpyHostToDevice, s));
-    ZL_HIP(e, hipMemcpyAsync(e->dOpRanges, e->ranges.data(), e->ranges.size() * sizeof(ZlOpRange), hipMemcpyHostToDevice, s));
-    A.n_op_ranges = (int)e->ranges.size(); A.ops = e->dOps; A.op_ranges = e->dOpRanges;
+    const size_t n = e->hc.pendingOps.size();
+    if (n == 0) return ZLHIP_OK;
+    ZL_HIP(e, grow_mapped(&c.hOps, &c.hOpsDev, &c.opsCap, n));
+    e->hc.drain_ops_to(c.hOps, e->ranges);
+    ZL_HIP(e, grow_mapped(&c.hRanges, &c.hRangesDev, &c.rangesCap, e->ranges.size()));
+    std::memcpy(c.hRanges, e->ranges.data(), e->ranges.size() * sizeof(ZlOpRange));
+    A.n_op_ranges = (int)e->ranges.size(); A.ops = c.hOpsDev; A.op_ranges = c.hRangesDev;
     return ZLHIP_OK;
 }
 
@@ -679,7 +687,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         ZL_HIP(e, hipMemcpyAsync(c.dPass, c.hPass, (size_t)A.B * sizeof(ZlPassParams), hipMemcpyHostToDevice, ps));
         A.pass = c.dPass; A.fan = fan_out_dev;
     }
-    int rc = upload_ops(e, A, ps);
+    int rc = upload_ops(e, c, A);
     if (rc != ZLHIP_OK) return rc;
     // (the slot's statistics were cleared by the report kernel of the call that used it before)
     if (e->profiling) ZL_HIP(e, hipEventRecord(c.evBegin, s));

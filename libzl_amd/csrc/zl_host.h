@@ -40,6 +40,7 @@ struct ZlHostControl {
     std::vector<char> soundUsed;
     std::vector<ZlHostVoice> voices;
     std::vector<ZlVoiceOp> pendingOps;
+    std::vector<uint32_t> opOrder;
 
     void init(int B, int VPB, int max_sounds, double fs)
     {
@@ -194,19 +195,26 @@ struct ZlHostControl {
         return handle_on_bus(bus, c, tick, -1);
     }
 
-    // pending ops -> stable-sorted by voice + per-voice ranges (applied in arrival order per voice)
-    void drain_ops(std::vector<ZlVoiceOp> &sorted, std::vector<ZlOpRange> &ranges)
+    // pending ops -> voice order (stable: arrival order per voice) written to out[0 .. pendingOps.size()) + per-voice
+    // ranges.  Sorts indices, so every op is moved once -- straight into the caller's (pinned) buffer.
+    void drain_ops_to(ZlVoiceOp *out, std::vector<ZlOpRange> &ranges)
     {
-        sorted = pendingOps;
-        std::stable_sort(sorted.begin(), sorted.end(), [](const ZlVoiceOp &a, const ZlVoiceOp &b) { return a.voice < b.voice; });
+        const size_t n = pendingOps.size();
+        opOrder.resize(n);
+        for (size_t i = 0; i < n; ++i) opOrder[i] = (uint32_t)i;
+        std::stable_sort(opOrder.begin(), opOrder.end(), [this](uint32_t a, uint32_t b) { return pendingOps[a].voice < pendingOps[b].voice; });
         ranges.clear();
-        for (size_t i = 0; i < sorted.size();) {
-            size_t j = i;
-            while (j < sorted.size() && sorted[j].voice == sorted[i].voice) ++j;
-            ranges.push_back(ZlOpRange{ sorted[i].voice, (int32_t)i, (int32_t)(j - i), 0 });
-            i = j;
+        for (size_t i = 0; i < n; ++i) {
+            out[i] = pendingOps[opOrder[i]];
+            if (!ranges.empty() && ranges.back().voice == out[i].voice) ranges.back().count += 1;
+            else ranges.push_back(ZlOpRange{ out[i].voice, (int32_t)i, 1, 0 });
         }
         pendingOps.clear();
+    }
+    void drain_ops(std::vector<ZlVoiceOp> &sorted, std::vector<ZlOpRange> &ranges)
+    {
+        sorted.resize(pendingOps.size());
+        drain_ops_to(sorted.data(), ranges);
     }
 
     static void fill_clock(ZlClock &c, const zlhip_clock &k, int nframes)

@@ -145,6 +145,9 @@ typedef float zl_f2a4 __attribute__((ext_vector_type(2), aligned(4)));
 #ifndef ZL_K2_U
 #define ZL_K2_U     8        // gathers in flight per wavefront
 #endif
+#ifndef ZL_K2_U_HERMITE
+#define ZL_K2_U_HERMITE 4    // voices per chunk with 4-tap interpolation (two 16-byte gathers per voice)
+#endif
 #ifndef ZL_K2_MINWAVES
 #define ZL_K2_MINWAVES 1      // __launch_bounds__ minimum waves per SIMD (caps the VGPR budget)
 #endif
@@ -483,7 +486,7 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
 template <uint32_t MODE, int BPW>
 __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
 {
-    constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U / 2 : ZL_K2_U;
+    constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U_HERMITE : ZL_K2_U;
     __shared__ ZlBlockPlan  s_plan_[BPW][ZL_K2_CHUNK];
     __shared__ ZlVoiceConst s_vc[ZL_K2_CHUNK];
     __shared__ int s_cls_[BPW][ZL_K2_CHUNK];          // per voice: 1 = plays this block, 2 = per-frame control

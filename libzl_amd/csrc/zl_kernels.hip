@@ -211,7 +211,9 @@ static __device__ __forceinline__ zl_f2 zl_mix_frame_pk(zl_f2 xm, zl_f2 x0, zl_f
 #define ZL_K2_PK_HERMITE 1
 #endif
 
-template <uint32_t MODE, bool SEG2, bool UNIT, int U>
+// INT ("interior"): every frame of the block lies inside the source for every voice of the chunk (checked per voice at
+// staging from the block's first and last position) -- no bounds guard, no tap selects, no read of the duration.
+template <uint32_t MODE, bool SEG2, bool UNIT, bool INT, int U>
 static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
                                                            int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
 {
@@ -240,8 +242,8 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
             pos = (int)P;
             alpha[u] = (float)__builtin_amdgcn_fract(P);
         }
-        const int dur = s_vc[i].sample_duration;
-        const bool inb = dur > pos;                               // :204 guard (Q5)
+        const int dur = INT ? 0 : s_vc[i].sample_duration;
+        const bool inb = INT || dur > pos;                        // :204 guard (Q5)
         // out of range: gather the zero padding behind the source (8 frames, written by zl_k_interleave), so that
         // l = r = 0 falls out of the arithmetic (0 * finite = +-0, +0 + -0 = +0) without a select per channel;
         // voices with a non-finite gain are not "simple"
@@ -251,7 +253,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
                                       | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)so));
         if (HERM) {
             // taps pos-1 .. pos+2 as two 16-byte loads; at the source edges (not wide) the pair pos, pos+1 comes first
-            const bool wide = inb && pos >= 1 && pos + 2 <= dur;
+            const bool wide = INT || (inb && pos >= 1 && pos + 2 <= dur);
             p -= wide ? 1 : 0;
             // (uniform 64-bit base + 32-bit byte offset: the scalar-base form of global_load, no 64-bit VALU address)
             const uint32_t ob = (uint32_t)p << 3;
@@ -265,7 +267,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
     zl_f2 acc = {accL, accR};
     // every lane of the wave has all four Hermite taps inside its source (true except in the blocks at a loop's ends):
     // the wave-uniform fast form needs no tap selects and no linear alternative
-    const bool allWide = HERM && PK && __all(widem == (1 << U) - 1);
+    const bool allWide = HERM && PK && (INT || __all(widem == (1 << U) - 1));
     if (allWide) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -288,7 +290,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
-        const bool wide = (widem >> u) & 1;
+        const bool wide = INT || ((widem >> u) & 1);
         float l, r;
         if (PK) {
             zl_f2 xm, x0, x1, x2;
@@ -332,7 +334,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
 }
 
 // The same for chunks of mono sources: an 8-byte gather [x0 x1] (16 bytes [x-1 x0 x1 x2] for Hermite), r = l (:205, Q4).
-template <uint32_t MODE, bool SEG2, bool UNIT, int U>
+template <uint32_t MODE, bool SEG2, bool UNIT, bool INT, int U>
 static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
                                                                 int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
 {
@@ -354,14 +356,14 @@ static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A,
         int pos;                                                  // :198-199 (P >= 0)
         if (UNIT) { pos = s_unit[i].ipos + f; alpha[u] = s_unit[i].alpha; }
         else      { pos = (int)P; alpha[u] = (float)__builtin_amdgcn_fract(P); }
-        const int dur = s_vc[i].sample_duration;
-        const bool inb = dur > pos;                               // :204 guard (Q5)
+        const int dur = INT ? 0 : s_vc[i].sample_duration;
+        const bool inb = INT || dur > pos;                        // :204 guard (Q5)
         int p = inb ? pos : dur + 1;                              // out of range: the zero padding behind the source
         const uint64_t so = s_vc[i].src_offset;
         const float *src = A.arena + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(so >> 32)) << 32)
                                       | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)so));
         if (HERM) {
-            const bool wide = inb && pos >= 1 && pos + 2 <= dur;
+            const bool wide = INT || (inb && pos >= 1 && pos + 2 <= dur);
             p -= wide ? 1 : 0;
             d4[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ((uint32_t)p << 2));
             widem |= wide ? (1 << u) : 0;
@@ -372,7 +374,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
-        const bool wide = (widem >> u) & 1;
+        const bool wide = INT || ((widem >> u) & 1);
         ZlTaps t;
         t.x0r = t.x1r = t.xmr = t.x2r = 0.0f;
         if (HERM) {
@@ -484,7 +486,9 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
 // threads are BPW groups of N frames), so the per-workgroup fixed costs -- launch, staging of the voice records -- are
 // paid once per 256 frames whatever the block size is.  A wavefront never straddles two blocks (N is a multiple of 64).
 template <uint32_t MODE, int BPW>
-__global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
+// (faithful linear mode, one block per workgroup -- the headline shape: ask for the 6 waves per SIMD its 78 registers
+// allow; left to itself the allocator takes 82 and drops to 5)
+__global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 && BPW == 1) ? 6 : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
 {
     constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U_HERMITE : ZL_K2_U;
     __shared__ ZlBlockPlan  s_plan_[BPW][ZL_K2_CHUNK];
@@ -622,9 +626,18 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
             // 4 = "simple": whole block, sustain (and no debug trace); 8 = it has a second position segment; 16 = mono source
             const float gprod = vc.lgain * vc.rgain * vc.clip_volume * pl.env;     // finite iff every factor is (or one is 0 * inf = NaN)
+            // (sources of 4 GiB and more take the general path: the simple paths address a source with 32-bit byte offsets)
             if (cls == 1 && pl.nseg <= 2 && !(pl.flags & ZL_PLAN_ENV) && pl.n_active == N && (vc.channels == 1 || vc.channels == 2) && !A.trace
-                && (gprod - gprod) == 0.0f)
-                cls |= 4 | (pl.nseg == 2 ? 8 : 0) | (vc.channels == 1 ? 16 : 0) | ((pl.nseg == 1 && pl.step == 1.0 && pl.P0 < 1073741824.0) ? 32 : 0);
+                && (gprod - gprod) == 0.0f && (uint32_t)vc.sample_duration < 0x1ffffff0u)
+            {
+                // 64 = "interior": first and last position of the block (P0 and P0 + (N-1) step, step > 0) leave room for
+                // every tap: pos + 1 <= duration (pos >= 1 and pos + 2 <= duration with 4 taps)
+                constexpr bool HM = (MODE & ZL_MODE_HERMITE) != 0;
+                const double Pmax = fma((double)(N - 1), pl.step, pl.P0);
+                const bool interior = pl.nseg == 1 && pl.P0 >= (HM ? 1.0 : 0.0) && Pmax < (double)(vc.sample_duration - (HM ? 1 : 0));
+                cls |= 4 | (pl.nseg == 2 ? 8 : 0) | (vc.channels == 1 ? 16 : 0) | ((pl.nseg == 1 && pl.step == 1.0 && pl.P0 < 1073741824.0) ? 32 : 0)
+                     | (interior ? 64 : 0);
+            }
             { ZlUnit un; un.ipos = (int)pl.P0; un.alpha = (float)(pl.P0 - (double)un.ipos); s_unit_[b][i] = un; }
             if (b == 0) s_vc[i] = vc;
             s_plan_[b][i] = pl;                   // idle slots: a harmless record with no active frame
@@ -632,7 +645,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
             // class of each chunk of U voices: OR of bits 1, 2, 8; 4 = every voice simple and of one source layout, 16 = all
             // mono (ballots over the wave's 64 voices)
             const unsigned long long m1 = __ballot(cls & 1), m2 = __ballot(cls & 2), m4 = __ballot(cls & 4), m8 = __ballot(cls & 8),
-                                     m16 = __ballot(cls & 16), m32 = __ballot(cls & 32);
+                                     m16 = __ballot(cls & 16), m32 = __ballot(cls & 32), m64 = __ballot(cls & 64);
             const int lane = i & 63;
             if (lane < 64 / U) {
                 const unsigned long long full = (1ull << U) - 1ull;
@@ -640,7 +653,7 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
                 const unsigned long long mono = (m16 >> sh) & full;
                 const int cc = (((m1 >> sh) & full) ? 1 : 0) | (((m2 >> sh) & full) ? 2 : 0) | (((m8 >> sh) & full) ? 8 : 0)
                              | (((((m4 >> sh) & full) == full) && (mono == 0 || mono == full)) ? 4 : 0) | (mono == full ? 16 : 0)
-                             | ((((m32 >> sh) & full) == full) ? 32 : 0);
+                             | ((((m32 >> sh) & full) == full) ? 32 : 0) | ((((m64 >> sh) & full) == full) ? 64 : 0);
                 s_chunk_[b][(i >> 6) * (64 / U) + lane] = cc;
             }
         }
@@ -655,12 +668,14 @@ __global__ void __launch_bounds__(256, ZL_K2_MINWAVES) zl_k2_render(const ZlBatc
             if (cc) zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
 #endif
             if (cc == 0) {                                        // nobody in this chunk plays (SamplerSynth.cpp:137)
-            } else if ((cc & 60) == 36) zl_k2_chunk_simple<MODE, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 28) == 4)    zl_k2_chunk_simple<MODE, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 20) == 4)    zl_k2_chunk_simple<MODE, true, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 60) == 52)   zl_k2_chunk_simple_mono<MODE, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 28) == 20)   zl_k2_chunk_simple_mono<MODE, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 20) == 20)   zl_k2_chunk_simple_mono<MODE, true, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            } else if ((cc & 124) == 100) zl_k2_chunk_simple<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 92) == 68)   zl_k2_chunk_simple<MODE, false, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 28) == 4)    zl_k2_chunk_simple<MODE, false, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 4)    zl_k2_chunk_simple<MODE, true, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 124) == 116) zl_k2_chunk_simple_mono<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 92) == 84)   zl_k2_chunk_simple_mono<MODE, false, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 28) == 20)   zl_k2_chunk_simple_mono<MODE, false, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 20)   zl_k2_chunk_simple_mono<MODE, true, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
             else {
                 // general chunks (events, second segments, mixed layouts, per-frame control) are rare: run them as
                 // two half-chunks so their extra per-voice registers do not set the kernel's register budget

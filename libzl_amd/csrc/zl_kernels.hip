@@ -173,12 +173,15 @@ typedef float zl_f2 __attribute__((ext_vector_type(2)));
 // unit-step blocks (playback at the source rate inside an exact run): integer part of P0 and the constant fraction
 struct ZlUnit { int ipos; float alpha; };
 
+// zl_hermite4 (zl_render.h) on both channels at once: v_pk_fma_f32, one rounding per fused operation
+static __device__ __forceinline__ zl_f2 zl_fma2(zl_f2 a, zl_f2 b, zl_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 static __device__ __forceinline__ zl_f2 zl_hermite4_pk(zl_f2 y0, zl_f2 y1, zl_f2 y2, zl_f2 y3, float a)
 {
+    const zl_f2 aa = {a, a};
     const zl_f2 c1 = 0.5f * (y2 - y0);
-    const zl_f2 c2 = (y0 + 2.0f * y2) - (0.5f * y3 + 2.5f * y1);
-    const zl_f2 c3 = (0.5f * y3 + 1.5f * y1) - (0.5f * y0 + 1.5f * y2);
-    return y1 + a * (c1 + a * (c2 + a * c3));
+    const zl_f2 c2 = zl_fma2((zl_f2){-0.5f, -0.5f}, y3, zl_fma2((zl_f2){2.0f, 2.0f}, y2, zl_fma2((zl_f2){-2.5f, -2.5f}, y1, y0)));
+    const zl_f2 c3 = zl_fma2((zl_f2){1.5f, 1.5f}, y1 - y2, 0.5f * (y3 - y0));
+    return zl_fma2(aa, zl_fma2(aa, zl_fma2(aa, c3, c2), c1), y1);
 }
 
 template <uint32_t MODE>

@@ -24,12 +24,16 @@ ZL_HD inline void zl_eval_control(const ZlBlockPlan &pl, const double *ctlP, con
     env = (float)fma((double)(f - n0), (double)(seg1 ? pl.estep1 : pl.estep0), (double)(seg1 ? pl.E1 : pl.env));   // exact fp32 ramp
 }
 
+// 4-point Catmull-Rom (build-defined extension, absent in the reference): the cubic
+//   y1 + a (c1 + a (c2 + a c3)),  c1 = (y2 - y0) / 2,  c2 = y0 - 5/2 y1 + 2 y2 - y3 / 2,  c3 = (y3 - y0) / 2 + 3/2 (y1 - y2)
+// evaluated with fused multiply-adds in exactly this order (12 operations per channel; every fmaf below is ONE
+// rounding -- the oracle and the numpy restatement do the same).
 ZL_HD inline float zl_hermite4(float y0, float y1, float y2, float y3, float a)
 {
     const float c1 = 0.5f * (y2 - y0);
-    const float c2 = (y0 + 2.0f * y2) - (0.5f * y3 + 2.5f * y1);
-    const float c3 = (0.5f * y3 + 1.5f * y1) - (0.5f * y0 + 1.5f * y2);
-    return y1 + a * (c1 + a * (c2 + a * c3));
+    const float c2 = fmaf(-0.5f, y3, fmaf(2.0f, y2, fmaf(-2.5f, y1, y0)));
+    const float c3 = fmaf(1.5f, y1 - y2, 0.5f * (y3 - y0));
+    return fmaf(a, fmaf(a, fmaf(a, c3, c2), c1), y1);
 }
 
 // The gathered samples of one frame: taps pos, pos+1 (and pos-1, pos+2 for Hermite) of both channels.

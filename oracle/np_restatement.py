@@ -22,6 +22,26 @@ BEAT_SUBDIVISIONS = 96            # SyncTimer.cpp:95
 MODE_FIX_GAIN, MODE_FIX_DELAY, MODE_HERMITE = 1, 2, 4
 
 
+def fma32(a, b, c):
+    """fmaf: a * b + c with ONE rounding to float32.  The product of two float32 is exact in float64; the sum is rounded
+    to odd in float64 (error term from TwoSum), after which the rounding to float32 is the correctly rounded result
+    (53 >= 2 * 24 + 2 bits: Boldo & Melquiond, "Emulation of FMA and correctly rounded sums")."""
+    import struct
+    p = float(a) * float(b)
+    cc = float(c)
+    s = p + cc
+    if s != s or s in (float("inf"), float("-inf")):
+        return np.float32(s)
+    bb = s - p
+    err = (p - (s - bb)) + (cc - bb)
+    if err != 0.0:
+        bits = struct.unpack("<q", struct.pack("<d", s))[0]
+        if (bits & 1) == 0:                                  # make the last bit odd, towards the exact value
+            bits += 1 if (err > 0.0) == (s > 0.0) else -1
+            s = struct.unpack("<d", struct.pack("<q", bits))[0]
+    return np.float32(s)
+
+
 def _u64(x: int) -> int:
     return x & 0xFFFFFFFFFFFFFFFF
 
@@ -280,9 +300,9 @@ class Voice:
                     if wide:
                         y0, y1, y2, y3 = x[pos - 1], x[pos], x[pos + 1], x[pos + 2]
                         c1 = f32(f32(0.5) * f32(y2 - y0))
-                        c2 = f32(f32(y0 + f32(f32(2.0) * y2)) - f32(f32(f32(0.5) * y3) + f32(f32(2.5) * y1)))
-                        c3 = f32(f32(f32(f32(0.5) * y3) + f32(f32(1.5) * y1)) - f32(f32(f32(0.5) * y0) + f32(f32(1.5) * y2)))
-                        return f32(y1 + f32(alpha * f32(c1 + f32(alpha * f32(c2 + f32(alpha * c3))))))
+                        c2 = fma32(f32(-0.5), y3, fma32(f32(2.0), y2, fma32(f32(-2.5), y1, y0)))
+                        c3 = fma32(f32(1.5), f32(y1 - y2), f32(f32(0.5) * f32(y3 - y0)))
+                        return fma32(alpha, fma32(alpha, fma32(alpha, c3, c2), c1), y1)
                     return f32(f32(x[pos] * inv) + f32(x[pos + 1] * alpha))
                 l = f32(f32(f32(interp(inL) * self.lgain) * env) * vol)
                 r = f32(f32(f32(interp(inR) * self.rgain) * env) * vol) if inR is not None else l

@@ -419,13 +419,15 @@ void zlo_voice_stop_note(zlo_voice *v, int allowTailOff, zlo_clip *clips, int64_
     }
 }
 
-/* build-defined Hermite extension: 4-point Catmull-Rom, operation order fixed here */
+/* build-defined Hermite extension (absent in the reference): 4-point Catmull-Rom
+ *   y1 + a (c1 + a (c2 + a c3)),  c1 = (y2 - y0)/2,  c2 = y0 - 5/2 y1 + 2 y2 - y3/2,  c3 = (y3 - y0)/2 + 3/2 (y1 - y2)
+ * with the operation order and the fused multiply-adds fixed here (fmaf = one rounding, C99 7.12.13.1) */
 static float hermite4(float y0, float y1, float y2, float y3, float a)
 {
     const float c1 = 0.5f * (y2 - y0);
-    const float c2 = (y0 + 2.0f * y2) - (0.5f * y3 + 2.5f * y1);
-    const float c3 = (0.5f * y3 + 1.5f * y1) - (0.5f * y0 + 1.5f * y2);
-    return y1 + a * (c1 + a * (c2 + a * c3));
+    const float c2 = fmaf(-0.5f, y3, fmaf(2.0f, y2, fmaf(-2.5f, y1, y0)));
+    const float c3 = fmaf(1.5f, y1 - y2, 0.5f * (y3 - y0));
+    return fmaf(a, fmaf(a, fmaf(a, c3, c2), c1), y1);
 }
 
 void zlo_voice_process(zlo_voice *v, float *leftBuffer, float *rightBuffer, uint32_t nframes, const zlo_clock *clk,

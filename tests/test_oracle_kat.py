@@ -72,6 +72,23 @@ def test_kat_iii_half_speed_alternating_alpha(lib):
     assert bus[0, 0, 4] == exp
 
 
+def test_kat_vii_hermite_reproduces_quadratics(lib):
+    """Build-defined Hermite mode: a Catmull-Rom cubic through samples of a quadratic IS that quadratic (c1 = 2n, c2 = 1,
+    c3 = 0 for x[n] = n^2), and every intermediate of the fused evaluation is exact for small integers and alpha = 1/2:
+    one octave down the output is ((n + alpha)^2) / 4096, delayed one frame (Q2), times 0.5 (mono, pan 0).  At pos = 0
+    the tap pos - 1 does not exist and the frame falls back to the linear form (un-fused)."""
+    n = np.arange(200, dtype=np.float64)
+    x = (n * n / 4096.0).astype(np.float32)                      # exact in fp32
+    sc = one_voice_scene(x, None, note=48, nframes=64, nblocks=1, beats=3.7, mode=4)
+    bus, _, _ = run_oracle(sc)
+    for f in range(2, 63):
+        pos, a = f // 2, 0.5 * (f % 2)
+        exp = f32(0.5) * f32((pos + a) ** 2 / 4096.0)
+        assert bus[0, 0, f + 1] == exp and bus[0, 1, f + 1] == exp, f
+    lin = f32(x[0] * f32(0.5)) + f32(x[1] * f32(0.5))            # f = 1: pos 0, alpha 1/2, linear fallback
+    assert bus[0, 0, 2] == f32(0.5) * lin
+
+
 def test_kat_iv_fractional_beat_wrap_index_exact(lib):
     """(iv) non-integer lengthInBeats: wrap when P >= stopPosition, P restarts at the exact integer start (Q9b)."""
     x = np.random.default_rng(1).uniform(-1, 1, 3000).astype(np.float32)
@@ -216,3 +233,32 @@ def test_passthrough(lib):
     p.muted = 1
     lib.zlo_passthrough_process(C.byref(p), inL.ctypes.data, inR.ctypes.data, arr, 32)
     assert all(not o.any() for o in outs)
+
+
+def test_numpy_restatement_fma_is_one_rounding():
+    """oracle/np_restatement.fma32 (the Hermite mode's fused multiply-add in the golden generator) against exact
+    rational arithmetic: random operands, exact cancellation, near-ties."""
+    from fractions import Fraction
+    from oracle.np_restatement import fma32
+    rng = np.random.default_rng(5)
+
+    def exact32(a, b, c):
+        x = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+        if x == 0:
+            return f32(float(a) * float(b) + float(c))
+        g = f32(float(x))
+        cands = [g, np.nextafter(g, f32(np.inf)), np.nextafter(g, f32(-np.inf))]
+        return min(cands, key=lambda t: (abs(Fraction(float(t)) - x), int(f32(t).view(np.int32)) & 1))     # nearest, ties to even
+    for i in range(20000):
+        k = i % 4
+        if k == 0:
+            a, b, c = (f32(v) for v in rng.uniform(-1, 1, 3))
+        elif k == 1:
+            a, b = f32(rng.uniform(-2, 2)), f32(rng.uniform(-2, 2)); c = f32(-float(a) * float(b))
+        elif k == 2:
+            a, b = f32(1 + 2.0 ** -int(rng.integers(1, 24))), f32(1 + 2.0 ** -int(rng.integers(1, 24)))
+            c = f32(float(rng.choice([1, -1])) * 2.0 ** -int(rng.integers(0, 30)))
+        else:
+            a = f32(rng.uniform(-1, 1) * 2.0 ** int(rng.integers(-20, 20))); b = f32(rng.uniform(-1, 1))
+            c = f32(rng.uniform(-1, 1) * 2.0 ** int(rng.integers(-30, 10)))
+        assert fma32(a, b, c).view(np.int32) == exact32(a, b, c).view(np.int32), (a, b, c)

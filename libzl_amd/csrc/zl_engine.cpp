@@ -263,7 +263,9 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         // size reach the kernel's steady-state bandwidth) or of plan_window_blocks blocks when that is given; the
         // K1 -> K2 records are sized for one window and double buffered
         e->windowBlocks = cfg->plan_window_blocks > 0 ? cfg->plan_window_blocks : 0;
-        e->windowFrames = (size_t)2048 * 256;
+        // ... for 1024 voices; engines with fewer voices get proportionally longer windows (the same number of
+        // voice-frames per K2 launch, the same record memory), up to 16 Mi frames
+        e->windowFrames = std::min<size_t>((size_t)16 << 20, std::max<size_t>((size_t)2048 * 256, ((size_t)2048 * 256 * 1024) / V));
         int w = e->windowBlocks > 0 ? e->windowBlocks : (int)(e->windowFrames / 64);
         if (w > cfg->max_batch_blocks) w = cfg->max_batch_blocks;
         e->windowCap = w;

@@ -67,19 +67,25 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
     if (mine) pl.begin(A, v);
     for (int kb = 0; kb < A.K; kb += ZL_K1_CLOCKS) {
         const int nk = (A.K - kb < ZL_K1_CLOCKS) ? A.K - kb : ZL_K1_CLOCKS;
-        __syncthreads();
-        if (A.inline_clock) {
-            if (threadIdx.x == 0) s_clk[0] = A.clock0;             // a single real-time block: no clock upload
-        } else {
-            const uint4 *g = reinterpret_cast<const uint4 *>(A.clocks + kb);
-            uint4 *sh = reinterpret_cast<uint4 *>(s_clk);
-            for (int i = threadIdx.x; i < nk * (int)(sizeof(ZlClock) / 16); i += blockDim.x) sh[i] = g[i];
-        }
-        __syncthreads();
-        if (mine) {
-            // idle voices leave at once (ZlRunList::dead_from); the others run the planner's state machine, whose
-            // iterations are the same straight-line code for every lane (zl_plan.h)
-            while (pl.t < (kb + nk) * A.N) pl.iterate(A, kb + nk, s_clk, kb, force_slow);
+        // every voice of this wave has reached the end of the window (idle, stopped, or a periodic loop whose remaining
+        // passes are implied): the rest of the clocks is not needed.  (The workgroup is one wavefront; written as a
+        // skipped body rather than a break, which crashes the register allocator of this compiler.)
+        const bool lane_done = !mine || !(pl.valid && pl.st.playing) || pl.t >= A.K * A.N;
+        if (__ballot(!lane_done) != 0ull) {
+            __syncthreads();
+            if (A.inline_clock) {
+                if (threadIdx.x == 0) s_clk[0] = A.clock0;         // a single real-time block: no clock upload
+            } else {
+                const uint4 *g = reinterpret_cast<const uint4 *>(A.clocks + kb);
+                uint4 *sh = reinterpret_cast<uint4 *>(s_clk);
+                for (int i = threadIdx.x; i < nk * (int)(sizeof(ZlClock) / 16); i += blockDim.x) sh[i] = g[i];
+            }
+            __syncthreads();
+            if (mine) {
+                // idle voices leave at once (ZlRunList::dead_from); the others run the planner's state machine, whose
+                // iterations are the same straight-line code for every lane (zl_plan.h)
+                while (pl.t < (kb + nk) * A.N) pl.iterate(A, kb + nk, s_clk, kb, force_slow);
+            }
         }
     }
     if (mine) {

@@ -644,7 +644,10 @@ struct ZlPlanner {
                     if (perState == 0 && st.adsr_state == ZL_ADSR_SUSTAIN) { perState = 1; tcap = t1; jcap = nts; }
                     else if (perState == 1) {
                         perState = 2;
-                        if (nts - jcap >= 3 && nts - jcap <= 64) {  // passes of one or two segments are cheaper as inline runs
+                        // passes of one or two segments are cheaper as inline runs (K2 needs no record for their blocks) --
+                        // unless more passes are left than the run list could hold: then the window is finished here too
+                        const bool many = (A.K * N - t1) / (t1 - tcap) >= ZL_MAXRUNS;
+                        if (nts - jcap <= 64 && (nts - jcap >= 3 || many)) {
                             per_t0 = tcap; per_M = t1 - tcap; per_j0 = jcap; per_n = nts - jcap;
                             jump = true;
                         }

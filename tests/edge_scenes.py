@@ -166,7 +166,27 @@ def random_envelopes(seed):
     return sc
 
 
-SCENES = {f.__name__: f for f in (beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
+def unit_step_loops_many_passes():
+    """Playback at the source rate from an integer start (a pass is ONE exact linear run), 1500 blocks of 64 frames in
+    one window: dozens of passes per voice -- more than the inline run list holds, so the periodic descriptor takes over."""
+    rng = np.random.default_rng(77)
+    sc = Scene(num_buses=2, voices_per_bus=4, fs=48000.0, nframes=64, nblocks=1500)
+    for i in range(6):
+        n = int(rng.integers(700, 1500))
+        L, R = rand_source(rng, n, stereo=bool(i % 2))
+        sc.sounds.append((L, R, 48000.0))
+
+        def setup(lib, clip, n=n, i=i):
+            lib.zlo_clip_set_length(clip, C.c_float(0.0217 + 0.0031 * i), 120)      # fractional beats: sample-space loop
+            if clip.lengthInSeconds > n / 48000.0 * 0.9:
+                clip.lengthInSeconds = float(np.float32(n / 48000.0 * 0.6))
+            lib.zlo_clip_set_volume_absolute(clip, C.c_float(0.7))
+        sc.clip_setup[i] = setup
+    sc.events[0] = [("cmd", play_cmd(i, midi_channel=(i % 2) - 2, loop=True, note=60, volume=0.8), 0) for i in range(6)]
+    return sc
+
+
+SCENES = {f.__name__: f for f in (unit_step_loops_many_passes, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
                                   envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}
 for _seed in range(8):
     SCENES[f"random_envelopes_{_seed}"] = (lambda _seed=_seed: random_envelopes(9100 + _seed))

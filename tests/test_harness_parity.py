@@ -106,6 +106,23 @@ def test_periodic_loops_are_planned_once_per_window(Sim):
     compare_runs(ref_bus, ref_rep, ref_syn, bus2, rep2, sc.num_buses * sc.voices_per_bus)
 
 
+def test_unit_step_loops_over_many_passes_are_planned_once(Sim):
+    """Playback at the source rate from an integer start: a pass is ONE exact linear run.  A few passes per window are
+    described by inline runs; a window with more passes than the run list holds is finished by the periodic descriptor
+    after two passes (K1 stays O(1) per window however long the window is)."""
+    from edge_scenes import unit_step_loops_many_passes
+    sc = unit_step_loops_many_passes()
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Sim, batch=1500)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 8)
+    playing = [v for v in range(syn.num_voices) if rep[v].playing]
+    assert len(playing) == 6
+    assert all(1 <= syn.l.zlsim_periodic_segments(syn.s, v) <= 2 for v in playing)
+    assert all(syn.l.zlsim_num_tsegs(syn.s, v) < 12 for v in playing)
+    bus2, rep2, _, _ = run_backend(sc, Sim, batch=211)            # several windows: fewer passes each, inline runs + descriptor
+    compare_runs(ref_bus, ref_rep, ref_syn, bus2, rep2, 8)
+
+
 def test_no_free_voice_drops_command_like_reference(Sim):
     """More starts than voices on one channel: the surplus commands are dropped (SamplerSynth.cpp:204-215)."""
     sc = random_scene(600, num_buses=1, voices_per_bus=2, nclips=5, nblocks=6, events=False)

@@ -60,6 +60,7 @@ struct zlhip_engine {
         double *ctlP = nullptr; float *ctlEnv = nullptr;
         float *partials = nullptr;
         hipEvent_t planned = nullptr, rendered = nullptr, k1done = nullptr;
+        hipEvent_t renderedEv = nullptr; // the event that marks the end of the last rendering from this set (rendered, or a profiling event)
         bool used = false;               // `rendered` has been recorded at least once
     } ps[2];
     int windowBlocks = 0;                // plan_window_blocks when given (a fixed number of blocks per plan window)
@@ -708,7 +709,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         Aw.ctl_P = q.ctlP; Aw.ctl_env = q.ctlEnv; Aw.partials = q.partials;
         if (w > 0) { Aw.n_op_ranges = 0; Aw.ops = nullptr; Aw.op_ranges = nullptr; }     // commands apply before the first block only
         // planning may not overwrite a record set while an earlier window (of this or the previous call) still renders from it
-        if (ps != s && q.used) ZL_HIP(e, hipStreamWaitEvent(ps, q.rendered, 0));
+        if (ps != s && q.used) ZL_HIP(e, hipStreamWaitEvent(ps, q.renderedEv, 0));
         ZL_KERNEL(e, zl_launch_apply_ops(Aw, ps));
         ZL_KERNEL(e, zl_launch_plan(Aw, e->forceSlow, ps));
         if (ps != s && e->asmStream && !Aw.fuse_assemble) {
@@ -729,8 +730,12 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         ZL_KERNEL(e, zl_launch_render(Aw, s));
         if (e->profiling) ZL_HIP(e, hipEventRecord(c.evK2[2 * (size_t)w + 1], s));
         // K2 scans the block for AudioLevels itself when one workgroup holds the whole block of the final mix
-        if (!(Aw.groups == 1 && nframes <= 256)) ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
-        ZL_HIP(e, hipEventRecord(q.rendered, s));
+        const bool k3 = !(Aw.groups == 1 && nframes <= 256);
+        if (k3) ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
+        // (every event record is a packet the command processor handles between two K2 launches: when profiling, the
+        // event that closes the K2 timing doubles as the set's "rendered" event)
+        if (e->profiling && !k3) q.renderedEv = c.evK2[2 * (size_t)w + 1];
+        else { ZL_HIP(e, hipEventRecord(q.rendered, s)); q.renderedEv = q.rendered; }
         q.used = true;
     }
     c.windows = nwin;

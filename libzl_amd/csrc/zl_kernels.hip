@@ -136,6 +136,34 @@ static __device__ __forceinline__ int zl_sample_to_peak_int(float x)
     return (int)v;
 }
 
+// Wavefront reductions on the VALU (DPP row shifts / broadcasts, no LDS round trips): quad permutes, row_shr 4 and 8
+// leave each 16-lane row's result in its last lane, row_bcast 15 / 31 carry it across the rows; the result of the
+// whole wave is in lane 63.  `ident` fills lanes without a source (0 for max over non-negative ints and for sums).
+template <int CTRL, int ROWMASK>
+static __device__ __forceinline__ int zl_dpp_i(int ident, int v) { return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROWMASK, 0xf, false); }
+static __device__ __forceinline__ int zl_wave_max_nonneg(int v)
+{
+    int t;
+    t = zl_dpp_i<0xB1, 0xf>(0, v);  v = t > v ? t : v;             // quad_perm [1,0,3,2]
+    t = zl_dpp_i<0x4E, 0xf>(0, v);  v = t > v ? t : v;             // quad_perm [2,3,0,1]
+    t = zl_dpp_i<0x114, 0xf>(0, v); v = t > v ? t : v;             // row_shr 4
+    t = zl_dpp_i<0x118, 0xf>(0, v); v = t > v ? t : v;             // row_shr 8
+    t = zl_dpp_i<0x142, 0xa>(0, v); v = t > v ? t : v;             // row_bcast 15 -> rows 1, 3
+    t = zl_dpp_i<0x143, 0xc>(0, v); v = t > v ? t : v;             // row_bcast 31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+static __device__ __forceinline__ float zl_wave_sum(float x)
+{
+    int v = __float_as_int(x), t;
+    t = zl_dpp_i<0xB1, 0xf>(0, v);  v = __float_as_int(__int_as_float(v) + __int_as_float(t));
+    t = zl_dpp_i<0x4E, 0xf>(0, v);  v = __float_as_int(__int_as_float(v) + __int_as_float(t));
+    t = zl_dpp_i<0x114, 0xf>(0, v); v = __float_as_int(__int_as_float(v) + __int_as_float(t));
+    t = zl_dpp_i<0x118, 0xf>(0, v); v = __float_as_int(__int_as_float(v) + __int_as_float(t));
+    t = zl_dpp_i<0x142, 0xa>(0, v); v = __float_as_int(__int_as_float(v) + __int_as_float(t));
+    t = zl_dpp_i<0x143, 0xc>(0, v); v = __float_as_int(__int_as_float(v) + __int_as_float(t));
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+
 static __device__ __forceinline__ float zl_wave_max(float x)
 {
 #pragma unroll
@@ -589,12 +617,8 @@ __global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_D
         if (A.groups == 1 && gridDim.x == 1 && A.levels) {
             int pkL = written ? zl_sample_to_peak_int(accL) : 0, pkR = written ? zl_sample_to_peak_int(accR) : 0;
             float sqL = written ? accL * accL : 0.0f, sqR = written ? accR * accR : 0.0f;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int a = __shfl_xor(pkL, o, 64), b = __shfl_xor(pkR, o, 64);
-                pkL = a > pkL ? a : pkL; pkR = b > pkR ? b : pkR;
-                sqL += __shfl_xor(sqL, o, 64); sqR += __shfl_xor(sqR, o, 64);
-            }
+            pkL = zl_wave_max_nonneg(pkL); pkR = zl_wave_max_nonneg(pkR);
+            sqL = zl_wave_sum(sqL); sqR = zl_wave_sum(sqR);
             const int w = threadIdx.x >> 6;
             if ((threadIdx.x & 63) == 0) { s_pk[0][w] = pkL; s_pk[1][w] = pkR; s_sq[0][w] = sqL; s_sq[1][w] = sqR; }
             __syncthreads();

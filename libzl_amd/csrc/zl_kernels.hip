@@ -176,6 +176,7 @@ typedef float zl_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef float zl_f2a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 #define ZL_K2_CHUNK 128      // voice records staged in LDS per pass
+#define ZL_K2_MAXNB 16       // narrow buses per workgroup (128 voices / the minimum bus width of 8)
 #ifndef ZL_K2_U
 #define ZL_K2_U     8        // gathers in flight per wavefront
 #endif
@@ -533,8 +534,8 @@ __global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_D
     __shared__ int s_cls_[BPW][ZL_K2_CHUNK];          // per voice: 1 = plays this block, 2 = per-frame control
     __shared__ int s_chunk_[BPW][ZL_K2_CHUNK / U];    // class of each chunk of U voices
     __shared__ ZlUnit s_unit_[BPW][ZL_K2_CHUNK];
-    __shared__ int   s_pk[2][4];                      // fused level scan: per-wave partial results
-    __shared__ float s_sq[2][4];
+    __shared__ int   s_pk[2][ZL_K2_MAXNB][4];         // fused level scan: per-wave partial results of each of the workgroup's buses
+    __shared__ float s_sq[2][ZL_K2_MAXNB][4];
 
     const int N = A.N, V = A.V;
     const int blk = (BPW > 1) ? (int)threadIdx.x / N : 0;          // which of the workgroup's blocks this lane renders
@@ -619,22 +620,29 @@ __global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_D
             float sqL = written ? accL * accL : 0.0f, sqR = written ? accR * accR : 0.0f;
             pkL = zl_wave_max_nonneg(pkL); pkR = zl_wave_max_nonneg(pkR);
             sqL = zl_wave_sum(sqL); sqR = zl_wave_sum(sqR);
-            const int w = threadIdx.x >> 6;
-            if ((threadIdx.x & 63) == 0) { s_pk[0][w] = pkL; s_pk[1][w] = pkR; s_sq[0][w] = sqL; s_sq[1][w] = sqR; }
-            __syncthreads();
-            if (f == 0 && live) {
-                // the waves of this lane's block: all of the workgroup's (BPW == 1) or N / 64 of them
-                const int w0 = (BPW > 1) ? blk * (N >> 6) : 0;
-                const int nw = (BPW > 1) ? (N >> 6) : (int)((blockDim.x + 63) >> 6);
-                ZlBlockLevels lv; lv.peak_l = 0; lv.peak_r = 0; lv.sumsq_l = 0.0f; lv.sumsq_r = 0.0f;
-                for (int i = w0; i < w0 + nw; ++i) {
-                    lv.peak_l = s_pk[0][i] > lv.peak_l ? s_pk[0][i] : lv.peak_l;
-                    lv.peak_r = s_pk[1][i] > lv.peak_r ? s_pk[1][i] : lv.peak_r;
-                    lv.sumsq_l += s_sq[0][i]; lv.sumsq_r += s_sq[1][i];
-                }
-                A.levels[(size_t)k * A.B + bus] = lv;
+            // each wave leaves its partial result of this bus; they are combined once, after the last bus (no barrier here)
+            const int w = threadIdx.x >> 6, bi = bus - bus0;
+            if ((threadIdx.x & 63) == 0) { s_pk[0][bi][w] = pkL; s_pk[1][bi][w] = pkR; s_sq[0][bi][w] = sqL; s_sq[1][bi][w] = sqR; }
+        }
+    };
+    // the block levels of the workgroup's buses from the per-wave partial results: one lane per (bus, block)
+    auto combine_levels = [&](int nbus) {
+        if (!(A.groups == 1 && gridDim.x == 1 && A.levels)) return;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nbus * BPW; idx += blockDim.x) {
+            const int bi = idx / BPW, b = idx - bi * BPW;
+            const int kk = yb * BPW + b;
+            if (kk >= A.K) continue;
+            // the waves of block b: all of the workgroup's (BPW == 1) or N / 64 of them
+            const int w0 = (BPW > 1) ? b * (N >> 6) : 0;
+            const int nw = (BPW > 1) ? (N >> 6) : (int)((blockDim.x + 63) >> 6);
+            ZlBlockLevels lv; lv.peak_l = 0; lv.peak_r = 0; lv.sumsq_l = 0.0f; lv.sumsq_r = 0.0f;
+            for (int i = w0; i < w0 + nw; ++i) {
+                lv.peak_l = s_pk[0][bi][i] > lv.peak_l ? s_pk[0][bi][i] : lv.peak_l;
+                lv.peak_r = s_pk[1][bi][i] > lv.peak_r ? s_pk[1][bi][i] : lv.peak_r;
+                lv.sumsq_l += s_sq[0][bi][i]; lv.sumsq_r += s_sq[1][bi][i];
             }
-            if (NB > 1) __syncthreads();                           // the partial results are reused for the next bus
+            A.levels[(size_t)kk * A.B + bus0 + bi] = lv;
         }
     };
 
@@ -734,7 +742,8 @@ __global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_D
         st[3] = zl_paths;
     }
 #endif
-    if (NB == 1) store_bus(bus0);
+    if (NB == 1) { store_bus(bus0); combine_levels(1); }
+    else combine_levels(curBus - bus0);
 }
 
 // ------------------------------------------------------------------------------------------------

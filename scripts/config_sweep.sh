@@ -7,6 +7,8 @@ mkdir -p gpurun_out
 : > $out
 run() { echo "### $*" >> $out; timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/config_sweep_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/config_sweep_err.log >> $out; return 1; }; }
 run --voices 64 --buses 8 --frames 256 &&
+run --voices 64 --buses 8 --frames 256 --source-rate 44100 --notes 48,72 &&
+run --voices 96 --buses 12 --frames 256 &&
 run --voices 1024 --buses 8 --frames 128 &&
 run --voices 1024 --buses 8 --notes 48,72 &&
 run --voices 1024 --buses 8 --notes 48,72 --hermite &&

@@ -27,6 +27,16 @@ def main(root, out):
         lines.append(f"## kernel trace ({os.path.relpath(f, root)}): name, calls, avg_ns, min_ns, max_ns, meta")
         for name, d in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
             lines.append(f"{name[:90]}, {len(d)}, {sum(d) / len(d):.0f}, {min(d)}, {max(d)}, {meta[name]}")
+        # the engine's kernels by launch shape (a call's plan windows differ in size: compare like with like)
+        shaped = defaultdict(list)
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("Kernel_Name", "?")
+                if "zl_k" in name and "interleave" not in name:
+                    shaped[(name, row.get("Grid_Size_X"), row.get("Grid_Size_Y"), row.get("Grid_Size_Z"))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        lines.append("## engine kernels by grid (threads x, y, z): name, grid, calls, avg_ns, min_ns, max_ns")
+        for (name, gx, gy, gz), d in sorted(shaped.items(), key=lambda kv: (kv[0][0], -len(kv[1]))):
+            lines.append(f"{name[:60]}, {gx}x{gy}x{gz}, {len(d)}, {sum(d) / len(d):.0f}, {min(d)}, {max(d)}")
     for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(lambda: defaultdict(list))
         with open(f) as fh:

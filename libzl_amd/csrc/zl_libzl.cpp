@@ -310,22 +310,24 @@ int libzl_wav_read(const char *path, float **left, float **right, int *length, d
     int fmt = 0, channels = 0, bits = 0; uint32_t rate = 0; const unsigned char *data = nullptr; uint32_t dataBytes = 0;
     for (size_t pos = 12; pos + 8 <= buf.size();) {
         const uint32_t csz = rd32(&buf[pos + 4]);
-        const unsigned char *body = &buf[pos + 8];
+        const unsigned char *body = buf.data() + pos + 8;
         if (!std::memcmp(&buf[pos], "fmt ", 4) && csz >= 16 && pos + 8 + 16 <= buf.size()) {
             fmt = rd16(body); channels = rd16(body + 2); rate = rd32(body + 4); bits = rd16(body + 14);
-            if (fmt == 0xFFFE && csz >= 26) fmt = rd16(body + 24);            // WAVE_FORMAT_EXTENSIBLE sub-format
+            if (fmt == 0xFFFE && csz >= 26 && pos + 8 + 26 <= buf.size()) fmt = rd16(body + 24);   // WAVE_FORMAT_EXTENSIBLE sub-format
         } else if (!std::memcmp(&buf[pos], "data", 4)) {
             data = body; dataBytes = (uint32_t)std::min<size_t>(csz, buf.size() - (pos + 8));
         }
         pos += 8 + (size_t)csz + (csz & 1);
     }
     if (!data || channels < 1 || rate == 0 || !(fmt == 1 || fmt == 3)) return ZLHIP_ERR_INVALID;
+    // sample formats of the decode side: integer PCM 8 / 16 / 24 / 32 bits, IEEE float 32 / 64 bits
+    if (!((fmt == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) || (fmt == 3 && (bits == 32 || bits == 64)))) return ZLHIP_ERR_INVALID;
     const int bytesPer = bits / 8;
-    if (bytesPer < 1 || bytesPer > 8) return ZLHIP_ERR_INVALID;
     const int frames = (int)(dataBytes / (uint32_t)(bytesPer * channels));
     const int outCh = std::min(2, channels);                                   // jmin(2, numChannels), SamplerSynthSound.cpp:45
     float *planes[2] = { (float *)std::malloc(sizeof(float) * (size_t)std::max(frames, 1)),
                          outCh > 1 ? (float *)std::malloc(sizeof(float) * (size_t)std::max(frames, 1)) : nullptr };
+    if (!planes[0] || (outCh > 1 && !planes[1])) { std::free(planes[0]); std::free(planes[1]); return ZLHIP_ERR_CAPACITY; }
     for (int i = 0; i < frames; ++i) {
         for (int c = 0; c < outCh; ++c) {
             const unsigned char *p = data + ((size_t)i * channels + c) * bytesPer;

@@ -46,6 +46,63 @@ def test_wav_roundtrip_float_and_pcm16(zl, tmp_path):
     assert zl.ClipAudioSource_new(b"/nonexistent.wav", False) is None       # reference: failures are logged, not raised
 
 
+def test_wav_reader_formats_and_malformed_files(zl, tmp_path):
+    """Hand-built RIFF files: PCM 8 / 24 / 32, float64, WAVE_FORMAT_EXTENSIBLE, three channels (the first two are kept,
+    SamplerSynthSound.cpp:45) -- and files the reader must refuse without reading past their end."""
+    import struct
+
+    def riff(fmt_tag, channels, rate, bits, payload, ext_sub=None, fmt_extra=b""):
+        block = channels * bits // 8
+        fmt = struct.pack("<HHIIHH", fmt_tag, channels, rate, rate * block, block, bits)
+        if ext_sub is not None:
+            fmt += struct.pack("<HHIH", 22, bits, 0, ext_sub) + b"\x00" * 14
+        fmt += fmt_extra
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(payload)) + payload
+        return b"RIFF" + struct.pack("<I", len(body)) + body
+
+    def read(blob, name):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        Lp, Rp = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        n, sr = C.c_int(), C.c_double()
+        rc = zl.libzl_wav_read(str(p).encode(), C.byref(Lp), C.byref(Rp), C.byref(n), C.byref(sr))
+        if rc != 0:
+            return rc, None, None
+        L = np.ctypeslib.as_array(Lp, (n.value,)).copy()
+        R = np.ctypeslib.as_array(Rp, (n.value,)).copy() if Rp else None
+        zl.libzl_wav_free(Lp); zl.libzl_wav_free(Rp)
+        return 0, L, R
+
+    scale = f32(1.0 / 2147483648.0)
+    rc, L, R = read(riff(1, 1, 8000, 8, bytes([0, 128, 255, 64])), "u8.wav")
+    assert rc == 0 and R is None
+    np.testing.assert_array_equal(L, (np.array([-128, 0, 127, -64], dtype=np.int32) << 24).astype(np.float32) * scale)
+    s24 = [0x123456, -0x123456, 0x7fffff, -0x800000]
+    rc, L, R = read(riff(1, 1, 48000, 24, b"".join(struct.pack("<i", v)[:3] for v in s24)), "s24.wav")
+    np.testing.assert_array_equal(L, (np.array(s24, dtype=np.int32) << 8).astype(np.float32) * scale)
+    rc, L, R = read(riff(1, 2, 48000, 32, struct.pack("<4i", 1 << 30, -(1 << 30), 5, -5)), "s32.wav")
+    np.testing.assert_array_equal(L, np.array([1 << 30, 5], dtype=np.float32) * scale)
+    np.testing.assert_array_equal(R, np.array([-(1 << 30), -5], dtype=np.float32) * scale)
+    rc, L, R = read(riff(3, 1, 44100, 64, struct.pack("<3d", 0.25, -1.5, 1e-3)), "f64.wav")
+    np.testing.assert_array_equal(L, np.array([0.25, -1.5, 1e-3], dtype=np.float64).astype(np.float32))
+    rc, L, R = read(riff(0xFFFE, 3, 48000, 16, struct.pack("<6h", 100, 200, 300, -100, -200, -300), ext_sub=1), "ext3ch.wav")
+    assert rc == 0
+    np.testing.assert_array_equal(L, (np.array([100, -100], dtype=np.int32) << 16).astype(np.float32) * scale)
+    np.testing.assert_array_equal(R, (np.array([200, -200], dtype=np.int32) << 16).astype(np.float32) * scale)
+    # refused: float with 16 bits, PCM with 12 bits, a compressed format tag, a truncated header, an extensible header cut short
+    assert read(riff(3, 1, 48000, 16, b"\x00" * 8), "f16.wav")[0] != 0
+    assert read(riff(1, 1, 48000, 12, b"\x00" * 8), "s12.wav")[0] != 0
+    assert read(riff(0x55, 2, 44100, 16, b"\x00" * 64), "mp3.wav")[0] != 0
+    assert read(riff(1, 1, 48000, 16, b"\x00" * 8)[:30], "cut.wav")[0] != 0
+    ext = riff(0xFFFE, 1, 48000, 16, b"", ext_sub=1)
+    assert read(ext[:12 + 8 + 20], "extcut.wav")[0] != 0
+    # a data chunk that claims more bytes than the file holds is clamped to the file
+    blob = bytearray(riff(1, 1, 48000, 16, struct.pack("<4h", 1, 2, 3, 4)))
+    blob[-12:-8] = struct.pack("<I", 4000)
+    rc, L, _ = read(bytes(blob), "long.wav")
+    assert rc == 0 and len(L) == 4
+
+
 def test_setters_follow_the_reference_semantics(zl, tmp_path):
     """Every setter of the bridge against the oracle's restatement of ClipAudioSource.cpp (no GPU needed: without
     initJuce the clips only hold parameters)."""

@@ -128,7 +128,11 @@ class OverlappedBusReduce:
         if self.work[j] is not None:
             if self.work[j] is True:
                 if self.cuda:
-                    torch.cuda.current_stream(self.bus[j].device).wait_event(self.done[j])
+                    dev = self.bus[j].device
+                    (torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev)).wait_event(self.done[j])
+            elif self.cuda and stream:
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.bus[j].device)):
+                    self.work[j].wait()               # the render stream waits for the collective
             else:
                 self.work[j].wait()                   # the current stream waits for the collective
             self.work[j] = None
@@ -143,13 +147,19 @@ class OverlappedBusReduce:
         self._finish(j, stream)                       # buffer j was reduced two steps ago
         self.synth.render_batch(nblocks, nframes, clocks, bus_out_dev=self.bus[j].data_ptr(), stream=stream)
         if self.algorithm == "reduce":
-            self.work[j] = dist.reduce(self.bus[j], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.cuda and stream:                  # RCCL orders the collective behind torch's *current* stream
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.bus[j].device)):
+                    self.work[j] = dist.reduce(self.bus[j], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                self.work[j] = dist.reduce(self.bus[j], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             fn = (lambda: reduce_bus_mesh(self.bus[j], dst=self.dst, group=self.group, scratch=self.scratch[j])) \
                 if self.algorithm == "mesh" else (lambda: reduce_bus_in_rank_order(self.bus[j], dst=self.dst, group=self.group))
             if self.cuda:
                 # the exchange, the ordered sum and the gather run on the communication stream, behind the render
-                self.comm.wait_stream(torch.cuda.current_stream(self.bus[j].device))
+                # (queued on `stream` when one is given, else on torch's current stream)
+                dev = self.bus[j].device
+                self.comm.wait_stream(torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev))
                 with torch.cuda.stream(self.comm):
                     fn()
                     self.done[j].record(self.comm)

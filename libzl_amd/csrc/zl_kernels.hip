@@ -808,6 +808,37 @@ __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const flo
     }
 }
 
+// K3 without partials to sum (the scan of an existing bus: N > 256, or a bus reduced over several GPUs): one WAVE per
+// (block, bus), 16-byte loads, reductions on the VALU -- no LDS, no barrier.  N is a multiple of 64.
+__global__ void __launch_bounds__(256) zl_k3_scan(const ZlBatch A, const float *bus)
+{
+    const int N = A.N;
+    const long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (block, bus) pairs, bus fastest
+    if (pair >= (long long)A.K * A.B) return;                                     // whole waves leave
+    const int k = (int)(pair / A.B), b = (int)(pair - (long long)k * A.B);
+    const int lane = threadIdx.x & 63;
+    const size_t KN = (size_t)A.Ktot * N;
+    const float4 *inL = reinterpret_cast<const float4 *>(bus + ((size_t)b * 2) * KN + (size_t)(A.k0 + k) * N);
+    const float4 *inR = reinterpret_cast<const float4 *>(bus + ((size_t)b * 2 + 1) * KN + (size_t)(A.k0 + k) * N);
+    int pkL = 0, pkR = 0; float sqL = 0.0f, sqR = 0.0f;
+    for (int i = lane; i < (N >> 2); i += 64) {
+        const float4 l = inL[i], r = inR[i];
+        const float lv[4] = { l.x, l.y, l.z, l.w }, rv[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = zl_sample_to_peak_int(lv[j]), c = zl_sample_to_peak_int(rv[j]);
+            pkL = a > pkL ? a : pkL; pkR = c > pkR ? c : pkR;
+            sqL += lv[j] * lv[j]; sqR += rv[j] * rv[j];
+        }
+    }
+    pkL = zl_wave_max_nonneg(pkL); pkR = zl_wave_max_nonneg(pkR);
+    sqL = zl_wave_sum(sqL); sqR = zl_wave_sum(sqR);
+    if (lane == 0) {
+        ZlBlockLevels out; out.peak_l = pkL; out.peak_r = pkR; out.sumsq_l = sqL; out.sumsq_r = sqR;
+        A.levels[(size_t)k * A.B + b] = out;
+    }
+}
+
 // AudioLevels::timerCallback state update for every bus (AudioLevels.cpp:359-360, 367-383 via the
 // block scan of K3, 385, 395-396).  dBFS conversion (log10f) stays on the host, as in the reference.
 __global__ void zl_k_levels_tick(ZlLevelsState *state, const ZlBlockLevels *levels, int B, int N, int with_hold_bus)
@@ -926,11 +957,18 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s)
     const int bpw = (A.N < 256 && 256 % A.N == 0 && A.K > 1) ? 256 / A.N : 1;
     const int tpb = bpw > 1 ? 256 : (A.N < 256 ? A.N : 256);
     const dim3 grid(bpw > 1 ? 1 : A.N / tpb, (A.K + bpw - 1) / bpw, A.NB > 1 ? (A.B + A.NB - 1) / A.NB : A.B * A.groups), block(tpb);
+    // One-block-per-workgroup kernels fill every SIMD's register file (6 waves x 80 VGPRs; 5 x 96 with 4 taps) and
+    // leave no room for a planning wave (88 VGPRs): a K1 launch that arrives after K2 has filled the machine then
+    // crawls (measured 550 instead of 130 us).  Unused dynamic LDS caps K2 at 5 workgroups per CU (27 KB each of
+    // 160 KB) -- one wave slot per SIMD stays free for the planner, and K2 itself is 0.5 % faster that way.
+    static const int pad_env = [] { const char *e = getenv("ZL_K2_LDS_PAD"); return e ? atoi(e) : -1; }();
+    static const int pad_env_h = [] { const char *e = getenv("ZL_K2_LDS_PAD_HERMITE"); return e ? atoi(e) : -1; }();
+    const int pad = (A.mode & ZL_MODE_HERMITE) ? (pad_env_h >= 0 ? pad_env_h : 0) : (pad_env >= 0 ? pad_env : 10240);
     switch (A.mode & 7u) {
 #define ZL_CASE(M) case M: \
         if (bpw == 4)      hipLaunchKernelGGL((zl_k2_render<M, 4>), grid, block, 0, s, A); \
         else if (bpw == 2) hipLaunchKernelGGL((zl_k2_render<M, 2>), grid, block, 0, s, A); \
-        else               hipLaunchKernelGGL((zl_k2_render<M, 1>), grid, block, 0, s, A); \
+        else               hipLaunchKernelGGL((zl_k2_render<M, 1>), grid, block, pad, s, A); \
         break;
         ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
 #undef ZL_CASE
@@ -941,7 +979,14 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s)
 
 int zl_launch_finalize(const ZlBatch &A, const float *bus_in, hipStream_t s)
 {
-    hipLaunchKernelGGL(zl_k3_finalize, dim3(A.K, A.B), dim3(A.N < 256 ? A.N : 256), 0, s, A, bus_in);
+    // nothing to sum (K2 wrote the bus, or the caller hands one over) and 16-byte aligned rows: the wave-per-block scan
+    const float *scan = bus_in ? bus_in : (A.groups == 1 ? A.bus : nullptr);
+    if (scan && (((uintptr_t)scan & 15u) == 0) && (A.N % 64) == 0 && (((size_t)A.Ktot * A.N) % 4) == 0) {
+        const long long pairs = (long long)A.K * A.B;
+        hipLaunchKernelGGL(zl_k3_scan, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, A, scan);
+    } else {
+        hipLaunchKernelGGL(zl_k3_finalize, dim3(A.K, A.B), dim3(A.N < 256 ? A.N : 256), 0, s, A, bus_in);
+    }
     ZL_LAUNCH_CHECK();
     return 0;
 }

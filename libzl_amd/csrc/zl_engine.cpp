@@ -68,6 +68,7 @@ struct zlhip_engine {
     int windowCap = 0;                   // blocks the K1 -> K2 record arrays hold
     hipStream_t planStream = nullptr;    // K0 + K1 (sequential per voice)
     hipStream_t lastPlanStream = nullptr; hipEvent_t evPlanTail = nullptr;   // where the previous call planned (voice-state order)
+    hipEvent_t lastPlanEvent = nullptr;  // marks the end of that planning: evPlanTail, or the call's `done` event when it planned on its render stream
     hipStream_t asmStream = nullptr;     // K1c of window w runs here, next to K1 of window w+1
     std::vector<std::pair<int, int>> wins;
     // Per-call resources, double buffered so that consecutive zlhip_render_batch calls pipeline: the host prepares
@@ -686,7 +687,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     // with the planning of the previous call, so window 0 of this call is planned while the previous call still renders.
     // the voice state is carried from call to call by K1: when this call plans on another stream than the previous one
     // did, order it behind that call's last planning kernel
-    if (e->lastPlanStream && e->lastPlanStream != ps) ZL_HIP(e, hipStreamWaitEvent(ps, e->evPlanTail, 0));
+    if (e->lastPlanStream && e->lastPlanStream != ps && e->lastPlanEvent) ZL_HIP(e, hipStreamWaitEvent(ps, e->lastPlanEvent, 0));
     if (nblocks == 1) { A.inline_clock = 1; A.clock0 = c.hClocks[0]; A.fuse_assemble = 1; }   // a real-time block: fewer commands
     else ZL_HIP(e, hipMemcpyAsync(c.dClocks, c.hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, ps));
     if (fan_out_dev) {                                             // the rendering stream is ordered behind ps by the window events
@@ -738,12 +739,18 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         if (k3) ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
         // (every event record is a packet the command processor handles between two K2 launches: when profiling, the
         // event that closes the K2 timing doubles as the set's "rendered" event)
-        if (e->profiling && !k3) q.renderedEv = c.evK2[2 * (size_t)w + 1];
-        else { ZL_HIP(e, hipEventRecord(q.rendered, s)); q.renderedEv = q.rendered; }
-        q.used = true;
+        // (an engine with a single record set never plans on another stream: nobody waits for "rendered")
+        if (e->ps[1].hdr != nullptr) {
+            if (e->profiling && !k3) q.renderedEv = c.evK2[2 * (size_t)w + 1];
+            else { ZL_HIP(e, hipEventRecord(q.rendered, s)); q.renderedEv = q.rendered; }
+            q.used = true;
+        }
     }
     c.windows = nwin;
-    ZL_HIP(e, hipEventRecord(e->evPlanTail, ps));
+    // the end of this call's planning, for a next call that plans on another stream: an event on the planning stream, or
+    // -- when the call planned on its render stream -- simply its `done` event (recorded below; one packet fewer)
+    if (ps != s) { ZL_HIP(e, hipEventRecord(e->evPlanTail, ps)); e->lastPlanEvent = e->evPlanTail; }
+    else e->lastPlanEvent = c.done;
     e->lastPlanStream = ps;
     if (e->ps[1].hdr != nullptr) e->setPhase = (phase + (unsigned)nwin) & 1u;
     // results go straight to mapped host memory (a copy command here would make the runtime wait for the stream)

@@ -225,7 +225,8 @@ void zlhip_passthrough_params_default(zlhip_passthrough_params *p);
 int zlhip_passthrough_process(zlhip_engine *e, const zlhip_passthrough_params *params, const float *in_dev,
                               float *out_dev, int64_t frames, void *stream);
 
-/* zlhip_render_batch with the fan-out fused into the bus write: the JackPassthrough client is the next node after a
+/* zlhip_render_batch with the fan-out (JackPassthroughPrivate::process, JackPassthrough.cpp:45-115) fused into the bus
+ * write: the JackPassthrough client is the next node after a
  * SamplerSynth bus in the reference's graph, and its three output pairs are computed from the registers that hold the
  * finished mix (24 more bytes written per bus frame, no second pass over the bus).  fan_params: host [num_buses];
  * fan_out_dev: DEVICE [num_buses][6][nblocks*nframes] in the order of zlhip_passthrough_process.  Bit-identical to

@@ -186,7 +186,31 @@ def unit_step_loops_many_passes():
     return sc
 
 
-SCENES = {f.__name__: f for f in (unit_step_loops_many_passes, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
+def positions_beyond_2_to_24():
+    """A 17.2 M-frame source (6 minutes at 48 kHz) played from just below frame 2^24: the position crosses a binade of
+    the fp64 recurrence inside the first blocks, alpha = (float)(P - pos) has to come from a P whose spacing is 2^-28, and
+    the unit-step / interior variants index with 25-bit positions.  Four voices: playback rate, two pitched, a loop that
+    restarts back below 2^24."""
+    rng = np.random.default_rng(24)
+    n = 17_200_000
+    L = rng.uniform(-1, 1, n).astype(np.float32)
+    sc = Scene(num_buses=2, voices_per_bus=4, fs=48000.0, nframes=128, nblocks=12)
+    sc.sounds.append((L, None, 48000.0))                          # one mono source shared by the four clips' sounds
+    for i in range(1, 4):
+        sc.sounds.append((L, None, 48000.0))
+    starts = [349.5250, 349.5249, 349.5251, 349.5240]             # seconds: 16 777 200 +- a few frames
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            lib.zlo_clip_set_start_position(clip, C.c_float(starts[i]))
+            clip.lengthInBeats = 0.37                              # fractional: sample-space loop
+            clip.lengthInSeconds = float(np.float32([5.0, 5.0, 5.0, 0.011][i]))   # the last one loops every 528 frames
+            lib.zlo_clip_set_volume_absolute(clip, C.c_float(0.8))
+        sc.clip_setup[i] = setup
+    sc.events[0] = [("cmd", play_cmd(i, midi_channel=(i % 2) - 2, loop=True, note=[60, 67, 53, 60][i], volume=0.7), 0) for i in range(4)]
+    return sc
+
+
+SCENES = {f.__name__: f for f in (unit_step_loops_many_passes, positions_beyond_2_to_24, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
                                   envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}
 for _seed in range(8):
     SCENES[f"random_envelopes_{_seed}"] = (lambda _seed=_seed: random_envelopes(9100 + _seed))

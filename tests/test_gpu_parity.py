@@ -118,7 +118,7 @@ def test_segment_table_overflow(Engine, window):
     syn.close()
 
 
-@pytest.mark.parametrize("nframes", [64, 128, 192, 256, 512, 1024])
+@pytest.mark.parametrize("nframes", [64, 128, 192, 256, 512, 1024, 4096])      # 4096 = the largest block the engine accepts
 @pytest.mark.parametrize("batch", [1, 5, 1 << 30])
 def test_block_sizes(Engine, nframes, batch):
     """Every supported block size: 64 / 128 frames render 4 / 2 blocks per workgroup in batches, 192 and 256 one, 512 and

@@ -731,9 +731,9 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
                 ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
             }
         }
-        if (e->profiling) ZL_HIP(e, hipEventRecord(c.evK2[2 * (size_t)w], s));
-        ZL_KERNEL(e, zl_launch_render(Aw, s));
-        if (e->profiling) ZL_HIP(e, hipEventRecord(c.evK2[2 * (size_t)w + 1], s));
+        // profiling: the K2 dispatch carries its own start / stop events (hipExtLaunchKernel)
+        if (e->profiling) ZL_KERNEL(e, zl_launch_render(Aw, s, c.evK2[2 * (size_t)w], c.evK2[2 * (size_t)w + 1]));
+        else ZL_KERNEL(e, zl_launch_render(Aw, s));
         // K2 scans the block for AudioLevels itself when one workgroup holds the whole block of the final mix
         const bool k3 = !(Aw.groups == 1 && nframes <= 256);
         if (k3) ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));

@@ -6,7 +6,7 @@
 int zl_launch_apply_ops(const ZlBatch &A, hipStream_t s);
 int zl_launch_plan(const ZlBatch &A, int force_slow, hipStream_t s);
 int zl_launch_assemble(const ZlBatch &A, hipStream_t s);
-int zl_launch_render(const ZlBatch &A, hipStream_t s);
+int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int zl_launch_finalize(const ZlBatch &A, const float *bus_in, hipStream_t s);
 int zl_launch_reports(const ZlReport *reports, int V, float *gain_out, ZlReport *host_reports, float *host_gain,
                       const ZlBatchStats *stats, ZlBatchStats *host_stats, hipStream_t s);

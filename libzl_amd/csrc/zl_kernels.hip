@@ -15,6 +15,7 @@
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (the oracle defines an un-fused rounding
 // sequence; see zl_render.h).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "zl_types.h"
 #include "zl_plan.h"
 #include "zl_render.h"
@@ -951,7 +952,7 @@ int zl_launch_assemble(const ZlBatch &A, hipStream_t s)
     return 0;
 }
 
-int zl_launch_render(const ZlBatch &A, hipStream_t s)
+int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     // blocks shorter than 256 frames: 256 / N blocks per workgroup (batches only; a single block keeps its small workgroup)
     const int bpw = (A.N < 256 && 256 % A.N == 0 && A.K > 1) ? 256 / A.N : 1;
@@ -964,11 +965,13 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s)
     static const int pad_env = [] { const char *e = getenv("ZL_K2_LDS_PAD"); return e ? atoi(e) : -1; }();
     static const int pad_env_h = [] { const char *e = getenv("ZL_K2_LDS_PAD_HERMITE"); return e ? atoi(e) : -1; }();
     const int pad = (A.mode & ZL_MODE_HERMITE) ? (pad_env_h >= 0 ? pad_env_h : 0) : (pad_env >= 0 ? pad_env : 10240);
+    // ev_start / ev_stop (profiling): the kernel's own begin / end timestamps, taken by the dispatch packet itself -- no
+    // event packets around the launch for the command processor to handle
     switch (A.mode & 7u) {
 #define ZL_CASE(M) case M: \
-        if (bpw == 4)      hipLaunchKernelGGL((zl_k2_render<M, 4>), grid, block, 0, s, A); \
-        else if (bpw == 2) hipLaunchKernelGGL((zl_k2_render<M, 2>), grid, block, 0, s, A); \
-        else               hipLaunchKernelGGL((zl_k2_render<M, 1>), grid, block, pad, s, A); \
+        if (bpw == 4)      hipExtLaunchKernelGGL((zl_k2_render<M, 4>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
+        else if (bpw == 2) hipExtLaunchKernelGGL((zl_k2_render<M, 2>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
+        else               hipExtLaunchKernelGGL((zl_k2_render<M, 1>), grid, block, pad, s, ev_start, ev_stop, 0, A); \
         break;
         ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
 #undef ZL_CASE

@@ -311,7 +311,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             for (auto &x : c.evK2) chk(hipEventCreate(&x), "hipEventCreate");
             chk(hipEventCreate(&c.evBegin), "hipEventCreate");
             chk(hipEventCreate(&c.evEnd), "hipEventCreate");
-            chk(hipEventCreateWithFlags(&c.done, hipEventDisableTiming), "hipEventCreate");
+            chk(hipEventCreate(&c.done), "hipEventCreate");        // (it can ride on a kernel dispatch as its stop event)
             chk(dalloc(&c.dClocks, K), "clocks");
             chk(dalloc(&c.dReports, V), "reports");
             chk(dalloc(&c.dStats, 1), "stats");
@@ -754,9 +754,9 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     e->lastPlanStream = ps;
     if (e->ps[1].hdr != nullptr) e->setPhase = (phase + (unsigned)nwin) & 1u;
     // results go straight to mapped host memory (a copy command here would make the runtime wait for the stream)
-    ZL_KERNEL(e, zl_launch_reports(c.dReports, e->V, e->dGain, c.hReportsDev, c.hGainDev, c.dStats, c.hStatsDev, s));
-    if (e->profiling) { ZL_HIP(e, hipEventRecord(c.evEnd, s)); c.profiled = true; }
-    ZL_HIP(e, hipEventRecord(c.done, s));
+    // (the report kernel is the call's last packet: its stop event is the call's completion event)
+    ZL_KERNEL(e, zl_launch_reports(c.dReports, e->V, e->dGain, c.hReportsDev, c.hGainDev, c.dStats, c.hStatsDev, s, e->profiling ? nullptr : c.done));
+    if (e->profiling) { ZL_HIP(e, hipEventRecord(c.evEnd, s)); c.profiled = true; ZL_HIP(e, hipEventRecord(c.done, s)); }
     c.inflight = true;
     if (s != e->stream) e->joins[0] = c.done;                      // later engine work (levels, read-back) waits for it on the host
     e->latest = &c;

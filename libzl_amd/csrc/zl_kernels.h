@@ -9,7 +9,7 @@ int zl_launch_assemble(const ZlBatch &A, hipStream_t s);
 int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int zl_launch_finalize(const ZlBatch &A, const float *bus_in, hipStream_t s);
 int zl_launch_reports(const ZlReport *reports, int V, float *gain_out, ZlReport *host_reports, float *host_gain,
-                      const ZlBatchStats *stats, ZlBatchStats *host_stats, hipStream_t s);
+                      const ZlBatchStats *stats, ZlBatchStats *host_stats, hipStream_t s, hipEvent_t ev_done = nullptr);
 int zl_launch_levels_tick(ZlLevelsState *state, const ZlBlockLevels *levels, int B, int N, int with_hold_bus, hipStream_t s);
 int zl_launch_passthrough(const void *params_dev, const float *in, float *out, int B, long long frames, hipStream_t s);
 int zl_launch_interleave(const float *L, const float *R, float *dst, int length, int pad, hipStream_t s);

@@ -995,9 +995,10 @@ int zl_launch_finalize(const ZlBatch &A, const float *bus_in, hipStream_t s)
 }
 
 int zl_launch_reports(const ZlReport *reports, int V, float *gain_out, ZlReport *host_reports, float *host_gain,
-                      const ZlBatchStats *stats, ZlBatchStats *host_stats, hipStream_t s)
+                      const ZlBatchStats *stats, ZlBatchStats *host_stats, hipStream_t s, hipEvent_t ev_done)
 {
-    hipLaunchKernelGGL(zl_k_reports, dim3((V + 255) / 256), dim3(256), 0, s, reports, V, gain_out, host_reports, host_gain, stats, host_stats);
+    // ev_done: the call's completion event rides on this dispatch (its stop event) instead of a packet of its own
+    hipExtLaunchKernelGGL(zl_k_reports, dim3((V + 255) / 256), dim3(256), 0, s, nullptr, ev_done, 0, reports, V, gain_out, host_reports, host_gain, stats, host_stats);
     ZL_LAUNCH_CHECK();
     return 0;
 }

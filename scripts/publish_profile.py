@@ -62,10 +62,10 @@ hdr = f"""# rocprofv3 summary, round 1, final state (profiles/{name}_*; written 
 # the scene set-up of bench.py (source generation, clip upload), outside the timed region.
 #
 # K2 zl_k2_render<0u, 1> (MODE 0 = faithful linear, 1 block per workgroup).  bench.py times the K2 launches of its timed
-#   steps with HIP events on the launch stream: {lm:.1f} us per 2048-block launch (unprofiled run, {name}_bench_line.json):
+#   steps with the dispatches' own start / stop events (hipExtLaunchKernel) on the launch stream: {lm:.1f} us per 2048-block launch (unprofiled run, {name}_bench_line.json):
 #   {ab:.3f} GB algorithmic / {lm:.1f} us = {ach / 1e3:.2f} TB/s = {ach / 80:.1f} % of 8 TB/s.  rocprofv3, same launch shape
 #   (section "engine kernels by grid", {grid} threads): {avg_big / 1e3:.1f} us average over {n_big} dispatches (min {min_big / 1e3:.1f},
-#   max {max_big / 1e3:.1f}) = {ab / (avg_big / 1e9) / 1e3:.2f} TB/s -- the two agree.  (The --stats average over all {ndisp} dispatches,
+#   max {max_big / 1e3:.1f}) = {ab / (avg_big / 1e9) / 1e3:.2f} TB/s -- within {abs(avg_big / 1e3 - lm) / lm * 100:.1f} % of each other (kernels run a little slower under the profiler).  (The --stats average over all {ndisp} dispatches,
 #   {avg_ns / 1e3:.1f} us, mixes in the shorter windows.)
 # HBM traffic of K2 (PMC, separate passes), summed over the {fetch[0]} dispatches: FETCH_SIZE {fetch[2]:,.0f} KiB; on gfx950
 #   FETCH_SIZE counts one half of the bytes of 16-byte-per-lane streaming loads (MI355X_MICROARCH.md, HBM), so reads =

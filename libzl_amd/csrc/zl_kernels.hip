@@ -111,13 +111,16 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
 // more than two position segments (the block after a loop restart at a small position crosses ~log2(N) binades)
 // are expanded into per-frame control by the whole wave, lanes over frames, so that K2 keeps one pipelined path.
 #define ZL_K1C_BLOCKS 8
-__global__ void __launch_bounds__(64) zl_k1c_assemble(const ZlBatch A)
+// Few voices = few waves, each walking its blocks one after the other: engines with fewer than 512 voices give a lane 2
+// blocks instead of 8 (four times the waves, a quarter of the latency; the kernel is hidden behind K2 only if it is short)
+static inline int zl_k1c_blocks_per_lane(const ZlBatch &A) { return A.V >= 512 ? ZL_K1C_BLOCKS : 2; }
+__global__ void __launch_bounds__(64) zl_k1c_assemble(const ZlBatch A, int blocks_per_lane)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x;
     const bool mine = v < A.V;
-    const int kbeg = blockIdx.y * ZL_K1C_BLOCKS;
-    const int kend = kbeg + ZL_K1C_BLOCKS < A.K ? kbeg + ZL_K1C_BLOCKS : A.K;
+    const int kbeg = blockIdx.y * blocks_per_lane;
+    const int kend = kbeg + blocks_per_lane < A.K ? kbeg + blocks_per_lane : A.K;
     ZlAssembler as;
     as.begin(A, mine ? v : 0, kbeg, mine ? kend : kbeg);
     for (int k = kbeg; k < kend; ++k) zl_k1c_block(A, as, v, lane, k);
@@ -947,7 +950,8 @@ int zl_launch_plan(const ZlBatch &A, int force_slow, hipStream_t s)
 
 int zl_launch_assemble(const ZlBatch &A, hipStream_t s)
 {
-    hipLaunchKernelGGL(zl_k1c_assemble, dim3((A.V + 63) / 64, (A.K + ZL_K1C_BLOCKS - 1) / ZL_K1C_BLOCKS), dim3(64), 0, s, A);
+    const int bpl = zl_k1c_blocks_per_lane(A);
+    hipLaunchKernelGGL(zl_k1c_assemble, dim3((A.V + 63) / 64, (A.K + bpl - 1) / bpl), dim3(64), 0, s, A, bpl);
     ZL_LAUNCH_CHECK();
     return 0;
 }

@@ -92,6 +92,7 @@ struct zlhip_engine {
     CallSlot *latest = nullptr;          // slot of the most recent call
     zlhip_timings totals{}; int totalCalls = 0;   // sums over harvested calls (zlhip_profile_totals)
     float *dGain = nullptr;
+    ZlPassCache *dPassCache = nullptr;   // per voice: the recorded pass of its loop (zl_plan.h, replay_cached_pass)
     float *dBus = nullptr;
     ZlBlockLevels *dLevels = nullptr; ZlLevelsState *dLevelState = nullptr;
     int32_t *dTrace = nullptr; ZlPassParams *dPass = nullptr;
@@ -199,7 +200,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->planStream) (void)hipStreamSynchronize(e->planStream);
     if (e->asmStream) (void)hipStreamSynchronize(e->asmStream);
-    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dTrace, e->dPass };
+    void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dTrace, e->dPass, e->dPassCache };
     for (void *p : dev) if (p) (void)hipFree(p);
     for (auto &q : e->ps) {
         void *pd[] = { q.vconst, q.runs, q.tsegs, q.hdr, q.seg0, q.seg1, q.ctlP, q.ctlEnv, q.partials };
@@ -329,6 +330,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         }
     }
     chk(dalloc(&e->dGain, V), "gain");
+    chk(dalloc(&e->dPassCache, V), "pass cache");
     chk(dalloc(&e->dBus, B * 2 * K * N), "bus");
     chk(dalloc(&e->dLevels, K * B), "levels");
     chk(dalloc(&e->dLevelState, B), "levelState");
@@ -342,6 +344,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         chk(hipMemsetAsync(e->dSounds, 0, (size_t)cfg->max_sounds * sizeof(ZlSound), e->stream), "memset sounds");
         chk(hipMemsetAsync(e->dClips, 0, (size_t)cfg->max_sounds * sizeof(ZlClip), e->stream), "memset clips");
         chk(hipMemsetAsync(e->dVoices, 0, V * sizeof(ZlVoiceState), e->stream), "memset voices");
+        chk(hipMemsetAsync(e->dPassCache, 0, V * sizeof(ZlPassCache), e->stream), "memset pass cache");
         chk(hipMemsetAsync(e->dLevelState, 0, B * sizeof(ZlLevelsState), e->stream), "memset levels");
         for (auto &c : e->slots) chk(hipMemsetAsync(c.dReports, 0, V * sizeof(ZlReport), e->stream), "memset reports");
         for (auto &c : e->slots) chk(hipMemsetAsync(c.dStats, 0, sizeof(ZlBatchStats), e->stream), "memset stats");
@@ -634,7 +637,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     A.clocks_regular = regular ? 1 : 0;
     A.mode = e->cfg.mode;
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
-    A.voices = e->dVoices; A.reports = c.dReports;
+    A.voices = e->dVoices; A.reports = c.dReports; A.pass_cache = e->dPassCache;
     A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.stats = c.dStats;
     A.trace = 0; A.pos_trace = nullptr;
     int32_t *traceBase = nullptr;

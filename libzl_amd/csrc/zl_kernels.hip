@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     const bool mine = v < A.V;
     ZlPlanner pl;
-    if (mine) pl.begin(A, v);
+    if (mine) pl.begin(A, v, force_slow);
     for (int kb = 0; kb < A.K; kb += ZL_K1_CLOCKS) {
         const int nk = (A.K - kb < ZL_K1_CLOCKS) ? A.K - kb : ZL_K1_CLOCKS;
         // every voice of this wave has reached the end of the window (idle, stopped, or a periodic loop whose remaining

@@ -399,10 +399,13 @@ struct ZlPlanner {
     // jcap), 2 = done / given up
     int perState, tcap, jcap;
     int per_t0, per_M, per_j0, per_n;
+    // loop phase (frames since the last restart) for the pass cache: last restart seen in this window, or lost
+    int lastRestartT; bool phaseLost, phaseSet;
 
-    ZL_HD void begin(const ZlBatch &A, int voice)
+    ZL_HD void begin(const ZlBatch &A, int voice, int force_slow = 0)
     {
         v = voice;
+        lastRestartT = -1; phaseLost = false; phaseSet = false;
         perState = 0; tcap = 0; jcap = 0; per_t0 = 0; per_M = 0; per_j0 = 0; per_n = 0;
         st = A.voices[v];
         stats.source_bytes = 0; stats.slow_blocks = 0; stats.active_frames = 0;
@@ -455,6 +458,40 @@ struct ZlPlanner {
         clockMode = st.looping && c.beat_locked;
         X = posLoop ? (double)c.stop_pos : (oneShot ? ((st.release > 0.0f) ? c.tail_T : (double)c.stop_pos) : INFINITY);
         posMode = posLoop || oneShot;
+        if (posLoop && !force_slow && A.pass_cache) replay_cached_pass(A);
+    }
+
+    // The steady state of a sample-space loop costs no planning at all: when the voice sits ON the pass recorded for its
+    // (start, stop, ratio, sustain) -- same position, bit for bit, at the recorded offset -- its future is that pass
+    // from that offset, repeated.  The window's stream is the cached pass shifted back by the offset (per_t0 < 0); the
+    // state at the window's end comes from (offset + window) mod M.  Anything else falls through to the planner.
+    ZL_HD void replay_cached_pass(const ZlBatch &A)
+    {
+        const ZlPassCache &pc = A.pass_cache[v];
+        const int r = st.loop_phase1 - 1;
+        if (!(pc.valid && r >= 0 && r < pc.M && st.adsr_state == ZL_ADSR_SUSTAIN && st.env == st.sustain)) return;
+        if (!(pc.ratio == st.pitch_ratio && pc.start_int == c.start_int && pc.stop_pos == c.stop_pos && pc.sustain == st.sustain)) return;
+        const long long TW = (long long)A.K * A.N;
+        // passes of one or two segments are cheaper as inline runs, unless the window holds more of them than the list
+        if (!(pc.n >= 3 || TW / pc.M >= ZL_MAXRUNS)) return;
+        int j = pc.n - 1;
+        while (j > 0 && pc.seg[j].t > r) --j;
+        if (!(fma((double)(r - pc.seg[j].t), pc.seg[j].step, pc.seg[j].P) == st.P)) return;   // not on the recorded pass
+        ZlTSeg *ts = A.tsegs + (size_t)v * ZL_MAXTSEG;
+        for (int i = 0; i < pc.n; ++i) { ZlTSeg e = pc.seg[i]; e.t -= r; ts[i] = e; }
+        nts = pc.n; per_t0 = -r; per_M = pc.M; per_j0 = 0; per_n = pc.n; perState = 2;
+        const ZlClock &ck = A.inline_clock ? A.clock0 : A.clocks[0];
+        if (st.next_loop_usecs == 0)                                   // :179-182, at the start of the first block
+            st.next_loop_usecs = ck.playhead_usecs + ((st.next_loop_tick - ck.playhead) * ck.subbeat_usecs);
+        const int re = (int)(((long long)r + TW) % pc.M);
+        int je = pc.n - 1;
+        while (je > 0 && pc.seg[je].t > re) --je;
+        st.P = fma((double)(re - pc.seg[je].t), pc.seg[je].step, pc.seg[je].P);   // exact: on the segment's line
+        st.env = st.sustain;
+        st.loop_phase1 = re + 1; phaseSet = true;
+        stats.active_frames += (unsigned long long)TW;
+        stats.source_bytes += blockBytes * (unsigned long long)A.K;
+        t = (int)TW;
     }
 
     // The block that starts at tb (= the block containing t) has to be simulated per frame after all: forget what
@@ -512,6 +549,7 @@ struct ZlPlanner {
                 haveRun = false; haveERun = false; endAfter = false;
                 zl_plan_store(A, pidx, pl);
                 stats.slow_blocks += 1;
+                phaseLost = true;                                   // restarts inside a simulated block are not seen here
                 stats.source_bytes += blockBytes;
                 stats.active_frames += (unsigned long long)pl.n_active;
                 if (!st.playing) { t_end = t + pl.n_active; dead_from = kcur + 1; }
@@ -639,11 +677,21 @@ struct ZlPlanner {
             haveRun = false;
             if (st.looping) {
                 zl_loop_restart(st, c, clk0[ke - kb], clockMode);
+                lastRestartT = t1;
                 if (posMode && !force_slow) {                       // (force_slow bit 1: test hook, plan every pass)
                     // sample-space loop: the pass that begins now repeats exactly (same integer start, same ratio)
                     if (perState == 0 && st.adsr_state == ZL_ADSR_SUSTAIN) { perState = 1; tcap = t1; jcap = nts; }
                     else if (perState == 1) {
                         perState = 2;
+                        if (A.pass_cache && nts - jcap >= 1 && nts - jcap <= ZL_PASS_MAXSEG) {
+                            // the pass just completed (restart to restart, all in sustain) is the voice's steady state
+                            ZlPassCache &pc = A.pass_cache[v];
+                            pc.valid = 0;
+                            pc.ratio = st.pitch_ratio; pc.start_int = c.start_int; pc.stop_pos = c.stop_pos; pc.sustain = st.sustain;
+                            pc.M = t1 - tcap; pc.n = nts - jcap;
+                            for (int i = 0; i < pc.n; ++i) { ZlTSeg e = ts[jcap + i]; e.t -= tcap; e.flags = 0; pc.seg[i] = e; }
+                            pc.valid = 1;
+                        }
                         // passes of one or two segments are cheaper as inline runs (K2 needs no record for their blocks) --
                         // unless more passes are left than the run list could hold: then the window is finished here too
                         const bool many = (A.K * N - t1) / (t1 - tcap) >= ZL_MAXRUNS;
@@ -704,6 +752,7 @@ struct ZlPlanner {
             while (j > per_j0 && ts[j].t - per_t0 > rem) --j;
             st.P = fma((double)(rem - (ts[j].t - per_t0)), ts[j].step, ts[j].P);   // exact: on the segment's line
             st.env = st.sustain;
+            st.loop_phase1 = rem + 1; phaseSet = true;
             haveRun = false; haveERun = false;
             stats.active_frames += (unsigned long long)Rm;
             stats.source_bytes += blockBytes * (unsigned long long)(A.K - (k1 + (t1 > k1 * N ? 1 : 0)));
@@ -719,6 +768,12 @@ struct ZlPlanner {
         if (valid && st.playing && t >= A.K * A.N) {
             rep.valid = 1;
             rep.progress = (float)(st.P / st.src_len);
+        }
+        if (!phaseSet) {
+            const long long TW = (long long)A.K * A.N;
+            if (phaseLost || !(valid && st.playing && t >= TW)) st.loop_phase1 = 0;
+            else if (lastRestartT >= 0) st.loop_phase1 = (int)(TW - lastRestartT) + 1;
+            else if (st.loop_phase1 > 0) st.loop_phase1 = (st.loop_phase1 - 1 + TW < 0x7fffffffLL) ? (int)(st.loop_phase1 + TW) : 0;
         }
         A.reports[v] = rep;
         A.voices[v] = st;
@@ -892,7 +947,7 @@ ZL_HD inline double zl_expand_frame(const ZlSegStream &ss, int N, int k, int idx
 ZL_HD inline void zl_plan_voice(const ZlBatch &A, int v, int force_slow, ZlPlanStats &stats)
 {
     ZlPlanner pl;
-    pl.begin(A, v);
+    pl.begin(A, v, force_slow);
     while (pl.t < A.K * A.N) pl.iterate(A, A.K, A.clocks, 0, force_slow);
     pl.end(A);
     stats = pl.stats;

@@ -58,7 +58,8 @@ struct ZlVoiceState {
     int32_t  slice;
     int32_t  looping;
     int32_t  playing;             // isPlaying && clipCommand != nullptr
-    int32_t  pad;
+    int32_t  loop_phase1;         // 1 + frames since the last loop restart at the end of the last window; 0 = unknown (a hint for
+                                  // the pass cache, verified against P before it is used)
 };
 
 // Host -> device voice operations, applied in order before the next block is planned.
@@ -157,6 +158,17 @@ struct ZlLevelsState {            // AudioLevelsChannel meter state per bus
 // JackPassthrough parameters of one bus (JackPassthrough.cpp:27-31)
 struct ZlPassParams { float dry, fx1, fx2, pan; int muted; };
 
+// A sample-space loop in sustain repeats exactly: the segments of one pass (restart to restart, times relative to the
+// restart), kept per voice across windows and calls and valid for the key (start, stop, ratio, sustain level).
+#define ZL_PASS_MAXSEG 64
+struct ZlPassCache {
+    double  ratio;
+    int32_t start_int, stop_pos;
+    float   sustain;
+    int32_t M, n, valid;
+    ZlTSeg  seg[ZL_PASS_MAXSEG];
+};
+
 struct ZlBatchStats {
     unsigned long long source_bytes;
     unsigned long long slow_blocks;
@@ -196,6 +208,7 @@ struct ZlBatch {
     ZlReport           *reports;  // [V]
     float              *partials; // [K][B][groups][2][N]  (only when groups > 1)
     float              *bus;      // [B][2][Ktot*N]
+    ZlPassCache        *pass_cache; // [V] or nullptr
     const ZlPassParams *pass;     // [B] JackPassthrough parameters of the fused fan-out (with fan)
     float              *fan;      // [B][6][Ktot*N] dry L,R / wetFx1 L,R / wetFx2 L,R of every bus, or nullptr
     ZlBlockLevels      *levels;   // [K][B]

@@ -22,6 +22,7 @@ struct ZlSim {
     std::vector<ZlSound> sounds;
     std::vector<ZlClip> clips;
     std::vector<ZlVoiceState> voices;
+    std::vector<ZlPassCache> passCache;
     std::vector<ZlVoiceConst> vconst; std::vector<ZlRunList> runs; std::vector<ZlTSeg> tsegs;
     std::vector<ZlPlanHdr> planHdr; std::vector<ZlPlanSeg0> planSeg0; std::vector<ZlPlanSeg1> planSeg1;
     std::vector<double> ctlP; std::vector<float> ctlEnv;
@@ -98,6 +99,7 @@ ZlSim *zlsim_create(int B, int VPB, int max_sounds, double fs, uint32_t mode, in
     S->sounds.assign((size_t)max_sounds, ZlSound{0, 0, 0, 0.0});
     S->clips.assign((size_t)max_sounds, ZlClip{});
     S->voices.assign((size_t)S->V, ZlVoiceState{});
+    S->passCache.assign((size_t)S->V, ZlPassCache{});
     S->vconst.assign((size_t)S->V, ZlVoiceConst{}); S->runs.assign((size_t)S->V, ZlRunList{}); S->tsegs.assign((size_t)S->V * ZL_MAXTSEG, ZlTSeg{});
     S->reports.assign((size_t)S->V, ZlReport{});
     return S;
@@ -166,7 +168,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     ZlBatch A; std::memset(&A, 0, sizeof A);
     A.V = S->V; A.B = S->B; A.VPB = S->VPB; A.K = K; A.N = N; A.k0 = 0; A.Ktot = K; A.G = S->G; A.groups = (S->VPB + S->G - 1) / S->G; A.mode = S->mode; A.clocks_regular = regular ? 1 : 0;
     A.clocks = ck.data(); A.sounds = S->sounds.data(); A.clips = S->clips.data(); A.arena = S->arena.data();
-    A.voices = S->voices.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.tsegs = S->tsegs.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data();
+    A.voices = S->voices.data(); A.pass_cache = S->passCache.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.tsegs = S->tsegs.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data();
     A.ctl_P = S->ctlP.data(); A.ctl_env = S->ctlEnv.data(); A.reports = S->reports.data();
 
     for (const ZlOpRange &rg : ranges) {                          // K0
@@ -236,6 +238,7 @@ void zlsim_get_tseg(ZlSim *S, int v, int j, double *out)
     out[0] = g.P; out[1] = g.step; out[2] = g.t; out[3] = g.flags; out[4] = g.E; out[5] = g.estep;
 }
 int zlsim_periodic_segments(ZlSim *S, int v) { return S->runs[(size_t)v].per_n; }
+int zlsim_period_start(ZlSim *S, int v) { return S->runs[(size_t)v].per_t0; }   // < 0: the window replayed the voice's cached pass
 int zlsim_plan_flags(ZlSim *S, int k, int v) { return S->planHdr[(size_t)k * S->V + v].flags; }
 
 // ---- direct fuzz of the exact-linear-run machinery against the naive recurrence -----------------

@@ -106,6 +106,29 @@ def test_periodic_loops_are_planned_once_per_window(Sim):
     compare_runs(ref_bus, ref_rep, ref_syn, bus2, rep2, sc.num_buses * sc.voices_per_bus)
 
 
+def test_steady_loops_replay_their_recorded_pass(Sim):
+    """From the second window on, a looping voice in sustain is not planned at all: K1 finds it on the pass recorded for
+    it (same position, bit for bit) and hands K1c that pass shifted back by the voice's offset into it (per_t0 < 0).  Same
+    audio as the oracle for every split of the scene into calls; parameter changes fall back to the planner."""
+    sc = _short_pitched_loops()
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    for batch in (97, 300, 13):
+        bus, rep, syn, _ = run_backend(sc, Sim, batch=batch)
+        compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+        playing = [v for v in range(syn.num_voices) if rep[v].playing]
+        replayed = [v for v in playing if syn.l.zlsim_periodic_segments(syn.s, v) > 0 and syn.l.zlsim_period_start(syn.s, v) < 0]
+        assert len(replayed) >= len(playing) // 2, (batch, len(replayed), len(playing))     # (beat-locked loops are clock-driven)
+        assert all(syn.l.zlsim_num_tsegs(syn.s, v) <= 64 for v in replayed)
+    # with events (volume changes, restarts, stops, clip edits between blocks): still the oracle's audio
+    sc2 = random_scene(511, nclips=8, min_len=700, max_len=1500, nblocks=600, nframes=64, events=True)
+    for ev in sc2.events[0]:
+        ev[1]["looping"] = 1
+    ref2 = run_oracle(sc2)
+    for batch in (50, 1 << 30):
+        bus, rep, _, _ = run_backend(sc2, Sim, batch=batch)
+        compare_runs(ref2[0], ref2[1], ref2[2], bus, rep, sc2.num_buses * sc2.voices_per_bus)
+
+
 def test_unit_step_loops_over_many_passes_are_planned_once(Sim):
     """Playback at the source rate from an integer start: a pass is ONE exact linear run.  A few passes per window are
     described by inline runs; a window with more passes than the run list holds is finished by the periodic descriptor

@@ -210,7 +210,45 @@ def positions_beyond_2_to_24():
     return sc
 
 
-SCENES = {f.__name__: f for f in (unit_step_loops_many_passes, positions_beyond_2_to_24, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
+def loop_edits_while_playing():
+    """Steady pitched loops (their recorded pass is being replayed) whose clip is edited between blocks: a longer loop, a
+    shorter one, a moved start, a different sustain level, a loop turned beat-locked and back.  Every edit must drop the
+    recorded pass (its key no longer matches, or the voice is no longer on it) and the planner must take over."""
+    rng = np.random.default_rng(91)
+    sc = Scene(num_buses=2, voices_per_bus=4, fs=48000.0, nframes=64, nblocks=420)
+    for i in range(4):
+        L, R = rand_source(rng, 9000 + 500 * i, stereo=bool(i % 2))
+        sc.sounds.append((L, R, 44100.0))
+
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = 0.37 + 0.01 * i
+            clip.lengthInSeconds = float(np.float32(0.021 + 0.004 * i))       # loops of ~1000 source frames
+            lib.zlo_clip_set_volume_absolute(clip, C.c_float(0.6))
+        sc.clip_setup[i] = setup
+    sc.events[0] = [("cmd", play_cmd(i, midi_channel=(i % 2) - 2, loop=True, note=[57, 64, 60, 67][i], volume=0.7), 0) for i in range(4)]
+
+    def set_len(sec):
+        return lambda lib, clip: setattr(clip, "lengthInSeconds", float(np.float32(sec)))
+
+    def set_start(sec):
+        return lambda lib, clip: lib.zlo_clip_set_start_position(clip, C.c_float(sec))
+
+    def set_beats(b):
+        return lambda lib, clip: setattr(clip, "lengthInBeats", b)
+
+    def set_sustain(x):
+        def f(lib, clip):
+            clip.adsr.p.sustain = x
+        return f
+    sc.events[90] = [("clip", 0, set_len(0.035))]                 # longer loop
+    sc.events[150] = [("clip", 1, set_len(0.012)), ("clip", 2, set_start(0.004))]
+    sc.events[210] = [("clip", 3, set_beats(1.0))]                # integer beats: clock-driven restarts from now on
+    sc.events[260] = [("clip", 3, set_beats(0.41)), ("clip", 0, set_sustain(0.8))]   # (sustain of a playing voice stays: set at noteOn)
+    sc.events[330] = [("cmd", dict(clip=1, midiChannel=-1, midiNote=64, changeVolume=1, volume=0.3), 0), ("clip", 2, set_start(0.0))]
+    return sc
+
+
+SCENES = {f.__name__: f for f in (unit_step_loops_many_passes, positions_beyond_2_to_24, loop_edits_while_playing, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
                                   envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}
 for _seed in range(8):
     SCENES[f"random_envelopes_{_seed}"] = (lambda _seed=_seed: random_envelopes(9100 + _seed))

@@ -129,6 +129,28 @@ def test_steady_loops_replay_their_recorded_pass(Sim):
         compare_runs(ref2[0], ref2[1], ref2[2], bus, rep, sc2.num_buses * sc2.voices_per_bus)
 
 
+def test_clip_edits_drop_the_recorded_pass(Sim):
+    """edge_scenes.loop_edits_while_playing in windows of 40 blocks: passes are recorded and replayed, and every clip edit
+    (loop length, start, beat-locking, a volume command) sends the voice back to the planner -- the oracle's audio."""
+    from edge_scenes import loop_edits_while_playing
+    sc = loop_edits_while_playing()
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    hits = []
+    orig = Sim.render_batch
+
+    def counting(self, *a, **k):
+        orig(self, *a, **k)
+        hits.append(sum(1 for v in range(self.num_voices)
+                        if self.l.zlsim_periodic_segments(self.s, v) > 0 and self.l.zlsim_period_start(self.s, v) < 0))
+    Sim.render_batch = counting
+    try:
+        bus, rep, syn, _ = run_backend(sc, Sim, batch=40)
+    finally:
+        Sim.render_batch = orig
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    assert sum(hits) >= 2 * len(hits) and min(hits[1:]) < 4 <= max(hits)      # replayed most of the time, not right after an edit
+
+
 def test_unit_step_loops_over_many_passes_are_planned_once(Sim):
     """Playback at the source rate from an integer start: a pass is ONE exact linear run.  A few passes per window are
     described by inline runs; a window with more passes than the run list holds is finished by the periodic descriptor

@@ -65,7 +65,8 @@ typedef struct zlhip_config {
     int32_t  voices_per_task;        /* voices summed sequentially by one wavefront (mix group); 0 = the whole bus,
                                         i.e. the reference's order.  Smaller groups = two-level order, more parallelism */
     int32_t  plan_window_blocks;     /* blocks planned per window (planning of window i+1 overlaps rendering of window i);
-                                        0 = min(2048, max_batch_blocks) */
+                                        0 = automatic: 512 Ki frames at 1024 voices (2048 blocks of 256), proportionally
+                                        more frames for fewer voices (up to 16 Mi), never more than max_batch_blocks */
 } zlhip_config;
 
 /* clock inputs of one block: JACK cycle times + SyncTimer playhead getters

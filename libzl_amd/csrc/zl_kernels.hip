@@ -768,7 +768,18 @@ __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const flo
         if (A.groups > 1 && !bus_in) {
             l = 0.0f; r = 0.0f;
             const float *p = A.partials + (((size_t)k * A.B + bus) * A.groups) * 2 * (size_t)N;
-            for (int g = 0; g < A.groups; ++g) { l += p[f]; r += p[N + f]; p += 2 * (size_t)N; }
+            // the adds are sequential (group order = the summation order), the loads are not: eight groups' partials are
+            // requested at once (voices_per_task = 1 makes every voice a group and this loop 128 long)
+            int g = 0;
+            for (; g + 8 <= A.groups; g += 8) {
+                float pl[8], pr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { pl[u] = p[(size_t)u * 2 * N + f]; pr[u] = p[(size_t)u * 2 * N + N + f]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { l += pl[u]; r += pr[u]; }
+                p += 16 * (size_t)N;
+            }
+            for (; g < A.groups; ++g) { l += p[f]; r += p[N + f]; p += 2 * (size_t)N; }
             outL[f] = l; outR[f] = r;
             if (A.fan) {                                           // fused JackPassthrough fan-out, as in K2
                 const ZlPassParams pp = A.pass[bus];

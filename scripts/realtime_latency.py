@@ -32,3 +32,5 @@ run(64, 8, 256)           # BASELINE config 1
 run(1024, 8, 128)         # config 2 shape
 run(1024, 8, 256)
 run(1024, 8, 256, vpt=16)
+run(1024, 8, 256, vpt=1)  # one voice per task: every voice rendered by its own workgroup, K3 sums them in voice order (= the reference's order)
+run(1024, 8, 256, vpt=4)

@@ -457,6 +457,32 @@ def test_fused_fanout_is_the_passthrough_of_the_bus(Engine, case):
     syn.close()
 
 
+@pytest.mark.parametrize("batch", [1, 1 << 30])
+def test_one_voice_per_task_keeps_the_reference_order(Engine, batch):
+    """voices_per_task = 1: every voice is rendered by its own workgroup and K3 adds the voices in voice order -- the
+    reference's summation order exactly (0 + v0 + v1 + ...), with the parallelism a wide bus lacks in real time.  Same bits
+    as the oracle's default (whole-bus) order."""
+    sc = random_scene(7300, num_buses=2, voices_per_bus=24, nclips=30, nframes=128, nblocks=14, events=True)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)                       # mix_group = 0: sequential over the whole bus
+    sc.mix_group = 1
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=batch)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    syn.close()
+
+
+def test_real_time_blocks_of_wide_buses_are_split_per_voice(Engine):
+    """Single-block calls on buses of 32 voices and more: the engine renders one voice per workgroup and adds them in
+    voice order (pick_group) -- no configuration, same bits as the whole-bus walk of the oracle; zlhip_render too."""
+    sc = random_scene(7400, num_buses=2, voices_per_bus=40, nclips=60, nframes=128, nblocks=10, events=True)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=1)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    peaks = syn.block_peaks()                                      # levels of the last block come from K3 on this path
+    exp = np.abs(np.float32(131072.0) * ref_bus[:, :, -128:]).astype(np.int64).max(axis=2)
+    assert np.array_equal(peaks[-1].astype(np.int64), exp)
+    syn.close()
+
+
 def test_errors_are_reported(Engine):
     from libzl_amd import ZlHipError
     from libzl_amd.engine import synthetic_clocks

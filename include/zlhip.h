@@ -63,7 +63,9 @@ typedef struct zlhip_config {
     double   playback_sample_rate;   /* jack_get_sample_rate, SamplerSynth.cpp:271-272 */
     uint64_t sound_arena_bytes;      /* HBM reserved for decoded sources */
     int32_t  voices_per_task;        /* voices summed sequentially by one wavefront (mix group); 0 = the whole bus,
-                                        i.e. the reference's order.  Smaller groups = two-level order, more parallelism */
+                                        i.e. the reference's order.  Smaller groups = two-level order, more parallelism.
+                                        (With 0, single real-time blocks of buses of >= 32 voices are rendered one voice
+                                        per workgroup and added in voice order: the same order, bit for bit.) */
     int32_t  plan_window_blocks;     /* blocks planned per window (planning of window i+1 overlaps rendering of window i);
                                         0 = automatic: 512 Ki frames at 1024 voices (2048 blocks of 256), proportionally
                                         more frames for fewer voices (up to 16 Mi), never more than max_batch_blocks */

@@ -470,15 +470,16 @@ def test_one_voice_per_task_keeps_the_reference_order(Engine, batch):
     syn.close()
 
 
-def test_real_time_blocks_of_wide_buses_are_split_per_voice(Engine):
+@pytest.mark.parametrize("nframes", [128, 512])
+def test_real_time_blocks_of_wide_buses_are_split_per_voice(Engine, nframes):
     """Single-block calls on buses of 32 voices and more: the engine renders one voice per workgroup and adds them in
     voice order (pick_group) -- no configuration, same bits as the whole-bus walk of the oracle; zlhip_render too."""
-    sc = random_scene(7400, num_buses=2, voices_per_bus=40, nclips=60, nframes=128, nblocks=10, events=True)
+    sc = random_scene(7400, num_buses=2, voices_per_bus=40, nclips=60, nframes=nframes, nblocks=10, events=True)
     ref_bus, ref_rep, ref_syn = run_oracle(sc)
     bus, rep, syn, _ = run_backend(sc, Engine, batch=1)
     compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
     peaks = syn.block_peaks()                                      # levels of the last block come from K3 on this path
-    exp = np.abs(np.float32(131072.0) * ref_bus[:, :, -128:]).astype(np.int64).max(axis=2)
+    exp = np.abs(np.float32(131072.0) * ref_bus[:, :, -nframes:]).astype(np.int64).max(axis=2)
     assert np.array_equal(peaks[-1].astype(np.int64), exp)
     syn.close()
 

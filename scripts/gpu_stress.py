@@ -33,11 +33,11 @@ for seed in range(first, first + count):
     N = int(rng.choice([64, 128, 192, 256, 512]))
     nb = int(rng.integers(20, 700))
     ml = int(rng.choice([300, 1500, 20000]))
-    B, VPB, G = [(3, 8, 0), (5, 8, 0), (2, 16, 0), (2, 12, 0), (1, 24, 0), (3, 8, 4), (2, 16, 8)][int(rng.integers(0, 7))]   # buses, width, mix group
+    B, VPB, G = [(3, 8, 0), (5, 8, 0), (2, 16, 0), (2, 12, 0), (1, 24, 0), (3, 8, 4), (2, 16, 8), (2, 40, 0), (1, 64, 0)][int(rng.integers(0, 9))]   # buses, width, mix group
     sc = random_scene(seed, nframes=N, nblocks=nb, nclips=int(rng.integers(4, 14)), min_len=ml, max_len=ml + int(rng.choice([500, 5000, 40000])),
                       events=bool(rng.random() < 0.6), mode=int(rng.choice([0, 3, 4])), num_buses=B, voices_per_bus=VPB, mix_group=G)
     ref_bus, ref_rep, ref_syn = run_oracle(sc)
-    batch = int(rng.choice([7, 64, 300, 1 << 30]))
+    batch = int(rng.choice([1, 7, 64, 300, 1 << 30]))          # 1: every call a real-time block
     kw = dict(batch=batch, plan_window_blocks=int(rng.choice([0, 0, 5, 64, 300])), pipelined=bool(rng.random() < 0.5))
     fan = None
     if rng.random() < 0.3:                                    # the fused JackPassthrough fan-out next to the bus

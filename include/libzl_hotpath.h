@@ -95,6 +95,10 @@ void libzl_hotpath_configure(const zlhip_config *cfg);
 /* 0 if the engine is up, else the zlhip status that initJuce() hit (e.g. ZLHIP_ERR_NO_DEVICE) */
 int  libzl_hotpath_status(void);
 zlhip_engine *libzl_hotpath_engine(void);
+/* the millisecond clock behind the 30 ms / 100 ms rate limits and the positions model's time stamps (the reference reads
+ * QDateTime::currentMSecsSinceEpoch(), ClipAudioSource.cpp:89,111,226,238): NULL = the wall clock.  A host that renders
+ * faster or slower than real time (offline bounce, deterministic tests) installs its own. */
+void libzl_hotpath_set_clock_ms(int64_t (*clock_ms)(void));
 /* a clip from memory instead of a file (planar fp32, right == NULL for mono) */
 ClipAudioSource *ClipAudioSource_newFromBuffer(const float *left, const float *right, int length, double sampleRate, const char *name);
 /* the per-cycle seam: what SamplerChannel::process does for every channel (SamplerSynth.cpp:116-148).

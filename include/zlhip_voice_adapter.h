@@ -17,6 +17,13 @@
  *   pitchWheelMoved / controllerMoved   -> no-ops, as :171-172
  *   process(...)                        -> nothing to do per voice: SamplerChannel::process calls zlhip_render once for
  *                                          all channels; kept so call sites compile
+ *   renderNextBlock(buffer, start, num) -> the juce::SynthesiserVoice rendering callback (juce::SamplerVoice overrides it;
+ *                                          the reference's class inherits that override, lib/SamplerSynthVoice.h:9-29, and
+ *                                          never reaches it: nothing calls Synthesiser::renderNextBlock).  A host that DOES
+ *                                          drive the JUCE Synthesiser gets the engine's result through it: the channel
+ *                                          publishes the block zlhip_render produced for this bus (BusBlock), voice slot 0
+ *                                          adds it into the output buffer, the other slots add nothing -- the Synthesiser
+ *                                          calls every voice, so the buffer receives the bus mix exactly once
  *   isPlaying                           -> refreshed from the engine by syncFromEngine()
  *
  * The class is a template over the JUCE / libzl types it touches, so this header needs no JUCE include itself and is
@@ -26,7 +33,7 @@
  *       static void fill(const ClipCommand &c, int engineClipId, zlhip_clip_command &o);
  *   };
  *   using SamplerSynthVoice = zlhip::VoiceAdapter<juce::SamplerVoice, juce::SynthesiserSound, SamplerSynthSound,
- *                                                 ClipCommand, ZlCommandFields>;
+ *                                                 ClipCommand, ZlCommandFields, juce::AudioBuffer<float>>;
  */
 #ifndef ZLHIP_VOICE_ADAPTER_H
 #define ZLHIP_VOICE_ADAPTER_H
@@ -36,11 +43,19 @@
 
 namespace zlhip {
 
-/* SoundT must offer `int engineClipId() const` (the id zlhip_sound_upload returned for the clip's source). */
-template <class SamplerVoiceBase, class SynthesiserSoundT, class SoundT, class ClipCommandT, class CommandFields>
+/* The block zlhip_render produced for one bus, published by the channel once per cycle (host memory, [nframes] each). */
+struct BusBlock {
+    const float *left = nullptr, *right = nullptr;
+    int nframes = 0;
+};
+
+/* SoundT must offer `int engineClipId() const` (the id zlhip_sound_upload returned for the clip's source).
+ * AudioBufferT is juce::AudioBuffer<float> (used: getNumChannels(), addFrom(channel, destStart, const float *, num)). */
+template <class SamplerVoiceBase, class SynthesiserSoundT, class SoundT, class ClipCommandT, class CommandFields, class AudioBufferT>
 class VoiceAdapter : public SamplerVoiceBase {
 public:
-    VoiceAdapter(zlhip_engine *engine, int bus, int slot) : engine_(engine), bus_(bus), slot_(slot) {}
+    VoiceAdapter(zlhip_engine *engine, int bus, int slot, const BusBlock *busBlock = nullptr)
+        : engine_(engine), bus_(bus), slot_(slot), busBlock_(busBlock) {}
     ~VoiceAdapter() override {}
 
     bool canPlaySound(SynthesiserSoundT *sound) override { return dynamic_cast<const SoundT *>(sound) != nullptr; }
@@ -87,6 +102,17 @@ public:
     void process(float * /*leftBuffer*/, float * /*rightBuffer*/, uint32_t /*nframes*/, uint32_t /*current_frames*/,
                  uint64_t /*current_usecs*/, uint64_t /*next_usecs*/, float /*period_usecs*/) {}
 
+    /* juce::SynthesiserVoice::renderNextBlock: ADDS this voice's output to outputBuffer[startSample, startSample + numSamples).
+     * The voices of a bus are mixed on the device, so slot 0 delivers the whole bus and the other slots deliver silence. */
+    void renderNextBlock(AudioBufferT &outputBuffer, int startSample, int numSamples) override
+    {
+        if (slot_ != 0 || !busBlock_ || !busBlock_->left || startSample < 0 || numSamples <= 0) return;
+        if (startSample + numSamples > busBlock_->nframes) return;          /* the channel has not rendered this range */
+        const int channels = outputBuffer.getNumChannels();
+        if (channels > 0) outputBuffer.addFrom(0, startSample, busBlock_->left + startSample, numSamples);
+        if (channels > 1) outputBuffer.addFrom(1, startSample, busBlock_->right + startSample, numSamples);
+    }
+
     /* a voice that ended on the device (tail finished, one-shot reached its stop position) frees itself here, as
      * stopNote(0, false) does inside the reference's process() (:249-252,258-261); call once per rendered block */
     void syncFromEngine()
@@ -99,6 +125,7 @@ public:
 private:
     zlhip_engine *engine_;
     int bus_, slot_;
+    const BusBlock *busBlock_;
     ClipCommandT *command_ = nullptr;
     SoundT *sound_ = nullptr;
     uint64_t startTick_ = 0;

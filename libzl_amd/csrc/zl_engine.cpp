@@ -53,7 +53,11 @@ struct zlhip_engine {
     char devname[256] = {0};
 
     // HBM
-    float *arena = nullptr; size_t arenaFloats = 0, arenaUsed = 0;
+    float *arena = nullptr; size_t arenaFloats = 0;
+    // arena allocator: free extents (offset, floats), sorted by offset, neighbours coalesced on release -- clips are
+    // loaded and destroyed freely (SamplerSynth::registerClip / unregisterClip, SamplerSynth.cpp:285-312)
+    std::vector<std::pair<size_t, size_t>> arenaFree;
+    std::vector<size_t> soundFloats;     // per sound slot: floats it holds in the arena
     ZlSound *dSounds = nullptr; ZlClip *dClips = nullptr;
     ZlVoiceState *dVoices = nullptr;
     // K1 -> K2 records, double buffered so that planning window i+1 overlaps rendering window i
@@ -365,6 +369,8 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         return rc;
     }
     e->hc.init(cfg->num_buses, cfg->voices_per_bus, cfg->max_sounds, cfg->playback_sample_rate);
+    e->soundFloats.assign((size_t)cfg->max_sounds, 0);
+    e->arenaFree.assign(1, { (size_t)0, e->arenaFloats & ~(size_t)3 });
     for (auto &c : e->slots) { std::memset(c.hReports, 0, V * sizeof(ZlReport)); std::memset(c.hStats, 0, sizeof(ZlBatchStats)); }
     e->latest = &e->slots[0];
     *out = e;
@@ -393,14 +399,38 @@ static int alloc_sound_slot(zlhip_engine *e, int32_t length, int channels, doubl
     const size_t pad = 8;
     size_t floats = ((size_t)length + pad) * (size_t)channels;
     floats = (floats + 3) & ~(size_t)3;                           // keep every source 16-byte aligned
-    if (e->arenaUsed + floats > e->arenaFloats) return fail(e, ZLHIP_ERR_CAPACITY, "sound arena full");
-    ZlSound s; s.offset = e->arenaUsed; s.length = length; s.channels = channels; s.sample_rate = sample_rate;
-    *dst = e->arena + e->arenaUsed;
-    e->arenaUsed += floats;
+    // first fit over the free extents (offsets and sizes are multiples of 4 floats, so every source stays aligned)
+    size_t off = (size_t)-1;
+    for (size_t i = 0; i < e->arenaFree.size(); ++i) {
+        if (e->arenaFree[i].second >= floats) {
+            off = e->arenaFree[i].first;
+            e->arenaFree[i].first += floats; e->arenaFree[i].second -= floats;
+            if (e->arenaFree[i].second == 0) e->arenaFree.erase(e->arenaFree.begin() + (long)i);
+            break;
+        }
+    }
+    if (off == (size_t)-1) return fail(e, ZLHIP_ERR_CAPACITY, "sound arena full");
+    ZlSound s; s.offset = off; s.length = length; s.channels = channels; s.sample_rate = sample_rate;
+    *dst = e->arena + off;
     e->hc.sounds[id] = s;
     e->hc.soundUsed[id] = 1;
+    e->soundFloats[(size_t)id] = floats;
     *out_id = id;
     return ZLHIP_OK;
+}
+
+// the arena extent of a sound slot goes back to the free list (coalesced with its neighbours); the slot is free again
+static void free_sound_slot(zlhip_engine *e, int id)
+{
+    const size_t off = (size_t)e->hc.sounds[id].offset, n = e->soundFloats[(size_t)id];
+    e->hc.soundUsed[id] = 0;
+    e->hc.sounds[id] = ZlSound{0, 0, 0, 0.0};
+    e->soundFloats[(size_t)id] = 0;
+    if (n == 0) return;
+    auto it = std::lower_bound(e->arenaFree.begin(), e->arenaFree.end(), std::make_pair(off, (size_t)0));
+    it = e->arenaFree.insert(it, {off, n});
+    if (it + 1 != e->arenaFree.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; e->arenaFree.erase(it + 1); }
+    if (it != e->arenaFree.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; e->arenaFree.erase(it); }
 }
 
 static int publish_sound(zlhip_engine *e, int id)
@@ -418,10 +448,22 @@ int zlhip_sound_upload_device(zlhip_engine *e, const float *left_dev, const floa
     if (!e || !left_dev) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
     float *dst = nullptr;
+    // queued batches may still gather from an extent that was freed and is handed out again here
+    if (e->outstanding) { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     int rc = alloc_sound_slot(e, length, right_dev ? 2 : 1, sample_rate, out_id, &dst);
     if (rc != ZLHIP_OK) return rc;
-    ZL_KERNEL(e, zl_launch_interleave(left_dev, right_dev, dst, length, 8, e->stream));
-    return publish_sound(e, *out_id);
+    // left_dev / right_dev were produced on a stream this call knows nothing about (the engine's stream is
+    // non-blocking: not even the null stream orders it): a one-off upload can afford to wait for the whole device
+    hipError_t st = hipDeviceSynchronize();
+    int krc = st == hipSuccess ? zl_launch_interleave(left_dev, right_dev, dst, length, 8, e->stream) : (int)st;
+    if (krc != 0) {
+        free_sound_slot(e, *out_id); *out_id = -1;
+        e->err = std::string("sound_upload_device: ") + hipGetErrorString((hipError_t)krc);
+        return ZLHIP_ERR_HIP;
+    }
+    rc = publish_sound(e, *out_id);
+    if (rc != ZLHIP_OK) { free_sound_slot(e, *out_id); *out_id = -1; }
+    return rc;
 }
 
 int zlhip_sound_upload(zlhip_engine *e, const float *left, const float *right, int32_t length, double sample_rate, int32_t *out_id)
@@ -430,14 +472,18 @@ int zlhip_sound_upload(zlhip_engine *e, const float *left, const float *right, i
     ZL_HIP(e, hipSetDevice(e->device));
     float *dst = nullptr;
     const int ch = right ? 2 : 1;
+    if (e->outstanding) { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }     // see zlhip_sound_upload_device
     int rc = alloc_sound_slot(e, length, ch, sample_rate, out_id, &dst);
     if (rc != ZLHIP_OK) return rc;
     std::vector<float> tmp(((size_t)length + 8) * ch, 0.0f);
     if (right) for (int32_t i = 0; i < length; ++i) { tmp[2 * (size_t)i] = left[i]; tmp[2 * (size_t)i + 1] = right[i]; }
     else std::memcpy(tmp.data(), left, (size_t)length * sizeof(float));
-    ZL_HIP(e, hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
-    return publish_sound(e, *out_id);
+    hipError_t st = hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    rc = st == hipSuccess ? engine_wait(e) : ZLHIP_ERR_HIP;
+    if (st != hipSuccess) e->err = std::string("sound_upload: ") + hipGetErrorString(st);
+    if (rc == ZLHIP_OK) rc = publish_sound(e, *out_id);
+    if (rc != ZLHIP_OK) { free_sound_slot(e, *out_id); *out_id = -1; }   // a failed upload keeps neither the slot nor its extent
+    return rc;
 }
 
 int zlhip_sound_release(zlhip_engine *e, int32_t id)
@@ -445,8 +491,7 @@ int zlhip_sound_release(zlhip_engine *e, int32_t id)
     if (!e || id < 0 || id >= e->cfg.max_sounds || !e->hc.soundUsed[id]) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
     if (e->outstanding) { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }     // queued batches still read the table
-    e->hc.soundUsed[id] = 0;
-    e->hc.sounds[id] = ZlSound{0, 0, 0, 0.0};
+    free_sound_slot(e, id);
     ZL_HIP(e, hipMemcpyAsync(e->dSounds + id, &e->hc.sounds[id], sizeof(ZlSound), hipMemcpyHostToDevice, e->stream));
     { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     return ZLHIP_OK;
@@ -887,6 +932,9 @@ int zlhip_levels_tick(zlhip_engine *e, int32_t block_index, int32_t with_hold_bu
         lv = e->dLevels + (size_t)k * e->cfg.num_buses;
     }
     const int B = e->cfg.num_buses;
+    // the block levels may still be in flight on a caller's stream (zlhip_render_batch / zlhip_levels_scan_device with
+    // stream != NULL): the engine's stream is non-blocking and nothing else orders it behind that work
+    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     ZL_KERNEL(e, zl_launch_levels_tick(e->dLevelState, lv, B, e->lastN, with_hold_bus, e->stream));
     ZL_HIP(e, hipMemcpyAsync(e->hLevelState, e->dLevelState, (size_t)B * sizeof(ZlLevelsState), hipMemcpyDeviceToHost, e->stream));
     { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }

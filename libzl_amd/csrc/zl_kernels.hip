@@ -750,6 +750,30 @@ __global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_D
     else combine_levels(curBus - bus0);
 }
 
+// The AudioLevels scan of one (block, bus) row pair by ONE wave: integer peaks (AudioLevels.cpp:361-383) and the sums of
+// squares of the RMS extension in their defined order (oracle/zl_oracle.c zlo_block_sumsq): tiles of 64 frames from frame
+// `off` (1 with quirk Q2: frame 0 of a bus is the constant 0 and lane f of K2 holds out[f + 1]; 0 with FIX_DELAY), the
+// wave's DPP tree inside a tile, tiles added in order -- the same bits as K2's fused scan.  N is a multiple of 64.
+static __device__ __forceinline__ ZlBlockLevels zl_scan_rows(const float *inL, const float *inR, int N, int off, int lane)
+{
+    int pkL = 0, pkR = 0; float sqL = 0.0f, sqR = 0.0f;
+    if (off) {                                                     // the frames in front of the first tile (uniform loads)
+        const float l0 = inL[0], r0 = inR[0];
+        pkL = zl_sample_to_peak_int(l0); pkR = zl_sample_to_peak_int(r0);
+        sqL = l0 * l0; sqR = r0 * r0;
+    }
+    for (int t0 = off; t0 < N; t0 += 64) {
+        const int i = t0 + lane;
+        const float l = i < N ? inL[i] : 0.0f, r = i < N ? inR[i] : 0.0f;
+        const int a = zl_sample_to_peak_int(l), c = zl_sample_to_peak_int(r);
+        pkL = a > pkL ? a : pkL; pkR = c > pkR ? c : pkR;
+        sqL += zl_wave_sum(l * l); sqR += zl_wave_sum(r * r);      // wave-uniform running sums, tile order
+    }
+    ZlBlockLevels out;
+    out.peak_l = zl_wave_max_nonneg(pkL); out.peak_r = zl_wave_max_nonneg(pkR); out.sumsq_l = sqL; out.sumsq_r = sqR;
+    return out;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: one workgroup per (block, bus).  Sums the mix-group partials in group order (when there are
 // any), writes the bus, and scans it for the AudioLevels integer peak and the RMS extension.
@@ -762,10 +786,9 @@ __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const flo
     const float *inL = bus_in ? bus_in + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N : outL;
     const float *inR = inL + KN;
 
-    int pkL = 0, pkR = 0; float sqL = 0.0f, sqR = 0.0f;
-    for (int f = threadIdx.x; f < N; f += blockDim.x) {
+    for (int f = threadIdx.x; f < N && A.groups > 1 && !bus_in; f += blockDim.x) {
         float l, r;
-        if (A.groups > 1 && !bus_in) {
+        {
             l = 0.0f; r = 0.0f;
             const float *p = A.partials + (((size_t)k * A.B + bus) * A.groups) * 2 * (size_t)N;
             // the adds are sequential (group order = the summation order), the loads are not: eight groups' partials are
@@ -793,38 +816,19 @@ __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const flo
                     o[(size_t)(2 * c) * KN + f] = ol; o[(size_t)(2 * c + 1) * KN + f] = orr;
                 }
             }
-        } else {
-            l = inL[f]; r = inR[f];
         }
-        const int a = zl_sample_to_peak_int(l), b = zl_sample_to_peak_int(r);
-        pkL = a > pkL ? a : pkL; pkR = b > pkR ? b : pkR;
-        sqL += l * l; sqR += r * r;
     }
-    __shared__ int   s_pk[2][4];
-    __shared__ float s_sq[2][4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int a = __shfl_xor(pkL, o, 64), b = __shfl_xor(pkR, o, 64);
-        pkL = a > pkL ? a : pkL; pkR = b > pkR ? b : pkR;
-        sqL += __shfl_xor(sqL, o, 64); sqR += __shfl_xor(sqR, o, 64);
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_pk[0][w] = pkL; s_pk[1][w] = pkR; s_sq[0][w] = sqL; s_sq[1][w] = sqR; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nw = (blockDim.x + 63) >> 6;
-        ZlBlockLevels lv; lv.peak_l = 0; lv.peak_r = 0; lv.sumsq_l = 0.0f; lv.sumsq_r = 0.0f;
-        for (int i = 0; i < nw; ++i) {
-            lv.peak_l = s_pk[0][i] > lv.peak_l ? s_pk[0][i] : lv.peak_l;
-            lv.peak_r = s_pk[1][i] > lv.peak_r ? s_pk[1][i] : lv.peak_r;
-            lv.sumsq_l += s_sq[0][i]; lv.sumsq_r += s_sq[1][i];
-        }
-        A.levels[(size_t)k * A.B + bus] = lv;
+    // the rows of this (block, bus) are complete: wave 0 scans them in the defined order (zl_scan_rows) -- the workgroup
+    // reads back its own stores (workgroup-scope fence + barrier; when nothing was summed the rows are the input's)
+    if (A.groups > 1 && !bus_in) { __threadfence_block(); __syncthreads(); }
+    if (threadIdx.x < 64) {
+        const ZlBlockLevels lv = zl_scan_rows(inL, inR, N, (A.mode & ZL_MODE_FIX_DELAY) ? 0 : 1, (int)threadIdx.x);
+        if (threadIdx.x == 0) A.levels[(size_t)k * A.B + bus] = lv;
     }
 }
 
 // K3 without partials to sum (the scan of an existing bus: N > 256, or a bus reduced over several GPUs): one WAVE per
-// (block, bus), 16-byte loads, reductions on the VALU -- no LDS, no barrier.  N is a multiple of 64.
+// (block, bus), reductions on the VALU -- no LDS, no barrier.  N is a multiple of 64.
 __global__ void __launch_bounds__(256) zl_k3_scan(const ZlBatch A, const float *bus)
 {
     const int N = A.N;
@@ -833,25 +837,9 @@ __global__ void __launch_bounds__(256) zl_k3_scan(const ZlBatch A, const float *
     const int k = (int)(pair / A.B), b = (int)(pair - (long long)k * A.B);
     const int lane = threadIdx.x & 63;
     const size_t KN = (size_t)A.Ktot * N;
-    const float4 *inL = reinterpret_cast<const float4 *>(bus + ((size_t)b * 2) * KN + (size_t)(A.k0 + k) * N);
-    const float4 *inR = reinterpret_cast<const float4 *>(bus + ((size_t)b * 2 + 1) * KN + (size_t)(A.k0 + k) * N);
-    int pkL = 0, pkR = 0; float sqL = 0.0f, sqR = 0.0f;
-    for (int i = lane; i < (N >> 2); i += 64) {
-        const float4 l = inL[i], r = inR[i];
-        const float lv[4] = { l.x, l.y, l.z, l.w }, rv[4] = { r.x, r.y, r.z, r.w };
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int a = zl_sample_to_peak_int(lv[j]), c = zl_sample_to_peak_int(rv[j]);
-            pkL = a > pkL ? a : pkL; pkR = c > pkR ? c : pkR;
-            sqL += lv[j] * lv[j]; sqR += rv[j] * rv[j];
-        }
-    }
-    pkL = zl_wave_max_nonneg(pkL); pkR = zl_wave_max_nonneg(pkR);
-    sqL = zl_wave_sum(sqL); sqR = zl_wave_sum(sqR);
-    if (lane == 0) {
-        ZlBlockLevels out; out.peak_l = pkL; out.peak_r = pkR; out.sumsq_l = sqL; out.sumsq_r = sqR;
-        A.levels[(size_t)k * A.B + b] = out;
-    }
+    const float *inL = bus + ((size_t)b * 2) * KN + (size_t)(A.k0 + k) * N;
+    const ZlBlockLevels out = zl_scan_rows(inL, inL + KN, N, (A.mode & ZL_MODE_FIX_DELAY) ? 0 : 1, lane);
+    if (lane == 0) A.levels[(size_t)k * A.B + b] = out;
 }
 
 // AudioLevels::timerCallback state update for every bus (AudioLevels.cpp:359-360, 367-383 via the

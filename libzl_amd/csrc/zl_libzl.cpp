@@ -8,6 +8,9 @@
 //   JackPassthrough parameter bridge                lib/libzl.cpp:476-575
 // No Qt, JUCE or tracktion: sources are decoded by the RIFF/WAVE reader below, audio is rendered by
 // the HIP kernels behind zlhip_render, and this file only keeps parameters and forwards commands.
+// -DZLHIP_NO_LIBZL_NAMES leaves this translation unit empty: libzlhip.so then exports only the zlhip_* engine ABI and a libzl
+// build keeps its own ClipAudioSource_* / JackPassthrough_* bodies, calling the engine from them.
+#ifndef ZLHIP_NO_LIBZL_NAMES
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -22,16 +25,23 @@
 
 namespace {
 
+// QDateTime::currentMSecsSinceEpoch() of the reference (ClipAudioSource.cpp:89,111,226,238; ClipAudioSourcePositionsModel.cpp):
+// the wall clock, or the host's clock when libzl_hotpath_set_clock_ms installed one (deterministic tests, offline bounces)
+int64_t (*g_clock_ms)(void) = nullptr;
 int64_t now_ms()
 {
-    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (g_clock_ms) return g_clock_ms();
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
 }
 
 // ---- tracktion_engine volume fader curve (third-party, absent from /root/reference; restated from the
 //      public tracktion_engine source, version unpinned): used only by setVolume(dB) / dBFromVolume ----
 float decibelsToVolumeFaderPosition(float db) { return (db > -100.0f) ? std::exp((db - 6.0f) * (1.0f / 20.0f)) : 0.0f; }
 float volumeFaderPositionToDB(float pos) { return (pos > 0.0f) ? (20.0f * std::log(pos)) + 6.0f : -100.0f; }
-float gainToDecibels(float gain) { return gain > 0.0f ? std::max(-100.0f, (float)std::log10(gain) * 20.0f) : -100.0f; }   // juce::Decibels
+// juce::Decibels (third-party template, restated from the public JUCE source): instantiated on the ARGUMENT type -- float for
+// positionsModel->peakGain() (ClipAudioSource.cpp:92), double for prevLeveldB and prevLevel * 0.94 (:98,101)
+float gainToDecibels(float gain) { return gain > 0.0f ? std::max(-100.0f, (float)std::log10(gain) * 20.0f) : -100.0f; }
+double gainToDecibels(double gain) { return gain > 0.0 ? std::max(-100.0, std::log10(gain) * 20.0) : -100.0; }
 double decibelsToGain(double db) { return db > -100.0 ? std::pow(10.0, db * 0.05) : 0.0; }
 
 struct AdsrParams { float attack = 0.1f, decay = 0.1f, sustain = 1.0f, release = 0.1f; };   // juce::ADSR::Parameters defaults
@@ -188,7 +198,15 @@ ClipAudioSource *make_clip(const float *L, const float *R, int length, double sr
     set_slices(c, 16);                                             // :204
     if (G.engine) {
         int32_t id = -1;
-        if (zlhip_sound_upload(G.engine, L, R, length, sr, &id) == ZLHIP_OK) c->engineClip = id;
+        const int rc = zlhip_sound_upload(G.engine, L, R, length, sr, &id);
+        if (rc == ZLHIP_OK) c->engineClip = id;
+        else {
+            // the reference logs and carries on (libzl.cpp has no error returns); a clip without a source would be silent
+            // for ever, so the bridge refuses it: ClipAudioSource_new* return NULL
+            std::fprintf(stderr, "libzl hot path: cannot load %s into the engine: %s (%s)\n", c->filePath.c_str(), zlhip_strerror(rc), zlhip_last_error(G.engine));
+            delete c;
+            return nullptr;
+        }
     }
     c->id = G.nextClipId++;                                        // libzl.cpp:122-124
     G.clips.push_back(c);
@@ -251,7 +269,7 @@ void sync_audio_level(ClipAudioSource *c, int64_t now)             // ClipAudioS
         c->prevLeveldB = c->currentLeveldB;
         c->currentLeveldB = gainToDecibels(c->positions.peakGain());   // the tracktion LevelMeasurer client stays silent here
         const double prevLevel = decibelsToGain(c->prevLeveldB);
-        if (c->prevLeveldB > c->currentLeveldB) c->currentLeveldB = gainToDecibels((float)(prevLevel * 0.94));
+        if (c->prevLeveldB > c->currentLeveldB) c->currentLeveldB = gainToDecibels(prevLevel * 0.94);   // double form, :100-101
         if (std::fabs(c->currentLeveldB - c->prevLeveldB) > 0.1 && c->levelCb) c->levelCb((float)c->currentLeveldB);
         c->nextGainUpdateTime = now + 30;
     }
@@ -390,6 +408,7 @@ void libzl_hotpath_configure(const zlhip_config *cfg)
 }
 
 int libzl_hotpath_status(void) { return G.engine ? ZLHIP_OK : G.status; }
+void libzl_hotpath_set_clock_ms(int64_t (*clock_ms)(void)) { std::lock_guard<std::mutex> lk(G.mu); g_clock_ms = clock_ms; }
 zlhip_engine *libzl_hotpath_engine(void) { return G.engine; }
 
 void initJuce(void)                                                 // libzl.cpp:358-410
@@ -425,6 +444,7 @@ void shutdownJuce(void)                                             // libzl.cpp
 // ---- ClipAudioSource bridge -------------------------------------------------------------------------
 ClipAudioSource *ClipAudioSource_byID(int id)                      // libzl.cpp:107-116
 {
+    std::lock_guard<std::mutex> lk(G.mu);
     for (ClipAudioSource *c : G.clips) if (c->id == id) return c;
     return nullptr;
 }
@@ -449,7 +469,7 @@ ClipAudioSource *ClipAudioSource_new(const char *filepath, bool muted)   // libz
         c = make_clip(L, R, n, sr, filepath);
     }
     libzl_wav_free(L); libzl_wav_free(R);
-    if (muted) ClipAudioSource_setVolume(c, -100.0f);              // ClipAudioSource.cpp:178-181
+    if (c && muted) ClipAudioSource_setVolume(c, -100.0f);         // ClipAudioSource.cpp:178-181
     return c;
 }
 
@@ -468,8 +488,8 @@ void ClipAudioSource_destroy(ClipAudioSource *c)                   // libzl.cpp:
 
 int ClipAudioSource_id(ClipAudioSource *c) { return c->id; }
 int ClipAudioSource_engineClip(ClipAudioSource *c) { return c->engineClip; }
-void ClipAudioSource_setProgressCallback(ClipAudioSource *c, void (*functionPtr)(float)) { c->progressCb = functionPtr; }
-void ClipAudioSource_setAudioLevelChangedCallback(ClipAudioSource *c, void (*functionPtr)(float)) { c->levelCb = functionPtr; }
+void ClipAudioSource_setProgressCallback(ClipAudioSource *c, void (*functionPtr)(float)) { std::lock_guard<std::mutex> lk(G.mu); c->progressCb = functionPtr; }
+void ClipAudioSource_setAudioLevelChangedCallback(ClipAudioSource *c, void (*functionPtr)(float)) { std::lock_guard<std::mutex> lk(G.mu); c->levelCb = functionPtr; }
 
 void ClipAudioSource_play(ClipAudioSource *c, bool loop) { std::lock_guard<std::mutex> lk(G.mu); clip_play(c, loop, -2); }            // play(loop) default channel -2
 void ClipAudioSource_stop(ClipAudioSource *c) { std::lock_guard<std::mutex> lk(G.mu); clip_stop(c, -3); }                          // stop() default -3: everywhere
@@ -482,30 +502,34 @@ const char *ClipAudioSource_getFileName(ClipAudioSource *c) { return c->fileName
 
 void ClipAudioSource_setStartPosition(ClipAudioSource *c, float s)  // ClipAudioSource.cpp:255-259
 {
+    std::lock_guard<std::mutex> lk(G.mu);
     c->startPositionInSeconds = std::max(0.0f, s);
     push_params(c);
 }
 
 void ClipAudioSource_setLength(ClipAudioSource *c, float beat, int bpm)   // ClipAudioSource.cpp:352-360
 {
+    std::lock_guard<std::mutex> lk(G.mu);
     c->lengthInSeconds = subbeat_count_to_seconds((uint64_t)bpm, f32_to_u64_sat(beat * ZLHIP_BEAT_SUBDIVISIONS));
     c->lengthInBeats = beat;
     push_params(c);
 }
 
-void ClipAudioSource_setPan(ClipAudioSource *c, float pan) { if (c->pan != pan) { c->pan = pan; push_params(c); } }                // :623-629
+void ClipAudioSource_setPan(ClipAudioSource *c, float pan) { std::lock_guard<std::mutex> lk(G.mu); if (c->pan != pan) { c->pan = pan; push_params(c); } }                // :623-629
 void ClipAudioSource_setSpeedRatio(ClipAudioSource *c, float v) { c->speedRatio = v; }                                             // :292-303 (offline re-render, out of scope)
 void ClipAudioSource_setPitch(ClipAudioSource *c, float v) { c->pitchChange = v; }                                                 // :279-290
 void ClipAudioSource_setGain(ClipAudioSource *c, float db) { c->gainDb = db; }                                                     // :305-311
 
 void ClipAudioSource_setVolume(ClipAudioSource *c, float vol)      // ClipAudioSource.cpp:313-326
 {
+    std::lock_guard<std::mutex> lk(G.mu);
     c->volumeAbsolute = (vol <= -40.0f) ? 0.0f : decibelsToVolumeFaderPosition(vol);
     push_params(c);
 }
 
 void ClipAudioSource_setVolumeAbsolute(ClipAudioSource *c, float vol)   // ClipAudioSource.cpp:328-336
 {
+    std::lock_guard<std::mutex> lk(G.mu);
     c->volumeAbsolute = std::max(0.0f, std::min(vol, 1.0f));
     push_params(c);
 }
@@ -513,26 +537,26 @@ void ClipAudioSource_setVolumeAbsolute(ClipAudioSource *c, float vol)   // ClipA
 float ClipAudioSource_volumeAbsolute(ClipAudioSource *c) { return c->volumeAbsolute; }
 float dBFromVolume(float vol) { return volumeFaderPositionToDB(vol); }                                                              // libzl.cpp:429
 
-void ClipAudioSource_setSlices(ClipAudioSource *c, int slices) { set_slices(c, slices); push_params(c); }
+void ClipAudioSource_setSlices(ClipAudioSource *c, int slices) { std::lock_guard<std::mutex> lk(G.mu); set_slices(c, slices); push_params(c); }
 int  ClipAudioSource_keyZoneStart(ClipAudioSource *c) { return c->keyZoneStart; }
 void ClipAudioSource_setKeyZoneStart(ClipAudioSource *c, int v) { c->keyZoneStart = v; }
 int  ClipAudioSource_keyZoneEnd(ClipAudioSource *c) { return c->keyZoneEnd; }
 void ClipAudioSource_setKeyZoneEnd(ClipAudioSource *c, int v) { c->keyZoneEnd = v; }
 int  ClipAudioSource_rootNote(ClipAudioSource *c) { return c->rootNote; }
-void ClipAudioSource_setRootNote(ClipAudioSource *c, int v) { if (c->rootNote != v) { c->rootNote = v; push_params(c); } }
+void ClipAudioSource_setRootNote(ClipAudioSource *c, int v) { std::lock_guard<std::mutex> lk(G.mu); if (c->rootNote != v) { c->rootNote = v; push_params(c); } }
 
 // quirk Q13: every ADSR setter starts from a fresh default Parameters (ClipAudioSource.cpp:636-685)
 float ClipAudioSource_adsrAttack(ClipAudioSource *c) { return c->adsr.attack; }
-void  ClipAudioSource_setADSRAttack(ClipAudioSource *c, float v) { if (c->adsr.attack != v) { AdsrParams p; p.attack = v; c->adsr = p; push_params(c); } }
+void  ClipAudioSource_setADSRAttack(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> lk(G.mu); if (c->adsr.attack != v) { AdsrParams p; p.attack = v; c->adsr = p; push_params(c); } }
 float ClipAudioSource_adsrDecay(ClipAudioSource *c) { return c->adsr.decay; }
-void  ClipAudioSource_setADSRDecay(ClipAudioSource *c, float v) { if (c->adsr.decay != v) { AdsrParams p; p.decay = v; c->adsr = p; push_params(c); } }
+void  ClipAudioSource_setADSRDecay(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> lk(G.mu); if (c->adsr.decay != v) { AdsrParams p; p.decay = v; c->adsr = p; push_params(c); } }
 float ClipAudioSource_adsrSustain(ClipAudioSource *c) { return c->adsr.sustain; }
-void  ClipAudioSource_setADSRSustain(ClipAudioSource *c, float v) { if (c->adsr.sustain != v) { AdsrParams p; p.sustain = v; c->adsr = p; push_params(c); } }
+void  ClipAudioSource_setADSRSustain(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> lk(G.mu); if (c->adsr.sustain != v) { AdsrParams p; p.sustain = v; c->adsr = p; push_params(c); } }
 float ClipAudioSource_adsrRelease(ClipAudioSource *c) { return c->adsr.release; }
-void  ClipAudioSource_setADSRRelease(ClipAudioSource *c, float v) { if (c->adsr.release != v) { AdsrParams p; p.release = v; c->adsr = p; push_params(c); } }
+void  ClipAudioSource_setADSRRelease(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> lk(G.mu); if (c->adsr.release != v) { AdsrParams p; p.release = v; c->adsr = p; push_params(c); } }
 
-float ClipAudioSource_peakGain(ClipAudioSource *c) { return c->positions.peakGain(); }
-double ClipAudioSource_firstProgress(ClipAudioSource *c) { return c->positions.firstProgress(); }
+float ClipAudioSource_peakGain(ClipAudioSource *c) { std::lock_guard<std::mutex> lk(G.mu); return c->positions.peakGain(); }
+double ClipAudioSource_firstProgress(ClipAudioSource *c) { std::lock_guard<std::mutex> lk(G.mu); return c->positions.firstProgress(); }
 
 int SyncTimer_getMultiplier(void) { return ZLHIP_BEAT_SUBDIVISIONS; }   // SyncTimer.cpp:946-948
 
@@ -598,3 +622,4 @@ int   JackPassthrough_getParams(int channel, zlhip_passthrough_params *out)
 }
 
 }  // extern "C"
+#endif  // ZLHIP_NO_LIBZL_NAMES

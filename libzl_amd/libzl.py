@@ -9,6 +9,7 @@ from ._abi import Clock, PassthroughParams
 
 _P = C.c_void_p
 CB = C.CFUNCTYPE(None, C.c_float)
+CLOCK_MS = C.CFUNCTYPE(C.c_int64)
 
 SIGNATURES = {
     "ClipAudioSource_byID": (_P, [C.c_int]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "libzl_hotpath_configure": (None, [C.POINTER(_abi.Config)]),
     "libzl_hotpath_status": (C.c_int, []),
     "libzl_hotpath_engine": (_P, []),
+    "libzl_hotpath_set_clock_ms": (None, [CLOCK_MS]),
     "ClipAudioSource_newFromBuffer": (_P, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_char_p]),
     "libzl_hotpath_process": (C.c_int, [C.c_uint32, C.POINTER(Clock), C.c_void_p, C.c_void_p]),
     "ClipAudioSource_peakGain": (C.c_float, [_P]),

@@ -96,10 +96,19 @@ def render_sharded(synth, nblocks: int, nframes: int, clocks, bus, dst: int = 0,
     on the root the reduced bus is scanned for AudioLevels.  `synth` is a libzl_amd.SamplerSynth."""
     import torch.distributed as dist
     synth.render_batch(nblocks, nframes, clocks, bus_out_dev=bus.data_ptr(), stream=stream)
+    _order_collective_behind_render(synth, bus, stream)
     reduce_bus(bus, dst=dst, group=group)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == dst:
         synth.levels_scan_device(bus.data_ptr(), nblocks, nframes, stream=stream)
     return bus
+
+
+def _order_collective_behind_render(synth, bus, stream):
+    """The collective is ordered behind torch's CURRENT stream.  A render queued with stream=None runs on the engine's own
+    non-blocking stream, which torch knows nothing about: wait for it on the host.  With an explicit stream the caller
+    makes that stream current (bench.py) or the classes below order their communication stream behind it."""
+    if stream is None and getattr(bus, "is_cuda", False):
+        synth.synchronize()
 
 
 class OverlappedBusReduce:
@@ -146,6 +155,7 @@ class OverlappedBusReduce:
         j = self.i & 1
         self._finish(j, stream)                       # buffer j was reduced two steps ago
         self.synth.render_batch(nblocks, nframes, clocks, bus_out_dev=self.bus[j].data_ptr(), stream=stream)
+        _order_collective_behind_render(self.synth, self.bus[j], stream)
         if self.algorithm == "reduce":
             if self.cuda and stream:                  # RCCL orders the collective behind torch's *current* stream
                 with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.bus[j].device)):

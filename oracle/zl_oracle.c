@@ -318,6 +318,61 @@ void zlo_clip_set_adsr_release(zlo_clip *c, float v)
     if (c->adsr.p.release != v) { zlo_adsr_params p; zlo_adsr_default_params(&p); p.release = v; zlo_adsr_set_parameters(&c->adsr, &p); }
 }
 
+/* ====================== per-clip level / progress chain ======================= */
+
+/* juce::Decibels::gainToDecibels<Type> / decibelsToGain<Type> (juce_Decibels.h, third-party, version unpinned):
+ *   gain > 0 ? jmax(minusInfinityDb, static_cast<Type>(std::log10(gain)) * Type(20.0)) : minusInfinityDb
+ *   decibels > minusInfinityDb ? std::pow(Type(10.0), decibels * Type(0.05)) : Type()
+ * with minusInfinityDb = -100. */
+static float  zlo_gain_to_db_f(float gain)   { if (!(gain > 0.0f)) return -100.0f; const float d = (float)log10f(gain) * 20.0f; return d > -100.0f ? d : -100.0f; }
+static double zlo_gain_to_db_d(double gain)  { if (!(gain > 0.0)) return -100.0; const double d = log10(gain) * 20.0; return d > -100.0 ? d : -100.0; }
+static double zlo_db_to_gain_d(double db)    { return db > -100.0 ? pow(10.0, db * 0.05) : 0.0; }
+
+void zlo_clip_meter_init(zlo_clip_meter *m)
+{
+    m->currentLeveldB = -400.0; m->prevLeveldB = -400.0;            /* :68-69 */
+    m->firstPositionProgress = 0.0;                                /* :85 */
+    m->nextPositionUpdateTime = 0; m->nextGainUpdateTime = 0;      /* :84,87 */
+}
+
+int zlo_sync_audio_level(zlo_clip_meter *m, zlo_clip *clip, int64_t now_ms, float *value)   /* ClipAudioSource.cpp:88-113 */
+{
+    int fired = 0;
+    if (m->nextGainUpdateTime < now_ms) {                          /* :89 */
+        m->prevLeveldB = m->currentLeveldB;                        /* :90 */
+        /* :92 -- qMax(gainToDecibels(float peakGain), levelClient dB): the tracktion level client never sees the
+         * sampler's audio (SamplerSynth plays straight to JACK), it reads -100 dB = the floor of gainToDecibels */
+        m->currentLeveldB = (double)zlo_gain_to_db_f(zlo_positions_peak_gain(&clip->positions));
+        const double prevLevel = zlo_db_to_gain_d(m->prevLeveldB); /* :98 */
+        if (m->prevLeveldB > m->currentLeveldB)                    /* :100-101 */
+            m->currentLeveldB = zlo_gain_to_db_d(prevLevel * 0.94);
+        if (fabs(m->currentLeveldB - m->prevLeveldB) > 0.1) {      /* :104 */
+            *value = (float)m->currentLeveldB;                     /* :108: void (*)(float) called with a double */
+            fired = 1;
+        }
+        m->nextGainUpdateTime = now_ms + 30;                       /* :111 */
+    }
+    return fired;
+}
+
+int zlo_sync_progress(zlo_clip_meter *m, const zlo_clip *clip, int has_callback, int64_t now_ms, float *value)   /* :225-240 */
+{
+    int fired = 0;
+    if (m->nextPositionUpdateTime < now_ms) {                      /* :226 */
+        double newPosition = clip->startPositionInSeconds / clip->duration;   /* :227, float / float -> double */
+        if (has_callback && zlo_positions_first_progress(&clip->positions) > -1.0f)   /* :228 */
+            newPosition = zlo_positions_first_progress(&clip->positions);
+        if (fabs(m->firstPositionProgress - newPosition) > 0.001) {           /* :231 */
+            m->firstPositionProgress = newPosition;
+            /* :234 calls the callback unconditionally (a null pointer is the host's bug there); the restatement fires
+             * only with a callback installed */
+            if (has_callback) { *value = (float)(m->firstPositionProgress * clip->duration); fired = 1; }
+            m->nextPositionUpdateTime = now_ms + 100;              /* :238 */
+        }
+    }
+    return fired;
+}
+
 /* =============================== ClipCommand ================================================= */
 
 void zlo_clip_command_clear(zlo_clip_command *c)    /* ClipCommand.h:13-32 defaults, :74-91 clear */
@@ -649,11 +704,32 @@ void zlo_levels_tick(zlo_levels_channel *c, const float *L, const float *R, uint
     }
 }
 
-float zlo_block_rms(const float *x, uint32_t n)                 /* build-defined extension */
+/* RMS extension (build-defined, absent in the reference; north_star "AudioLevels RMS/peak").  The order of the sum
+ * of squares is part of the definition, so that every implementation gives the same bits:
+ *   - the block is cut into tiles of 64 consecutive frames starting at frame `off` (off = 1 in the modes with quirk Q2,
+ *     where frame 0 of a bus is the constant 0 and frame f of a voice lands in out[f + 1]; off = 0 with
+ *     ZLO_MODE_FIX_DELAY); frames past the end count as 0;
+ *   - a tile is summed by the balanced pairwise tree over its 64 squares (x0^2 + x1^2) + (x2^2 + x3^2) ... -- the
+ *     tree a 64-lane wavefront reduction forms;
+ *   - the tiles are added one after the other in tile order, starting from the sum of the squares of the frames before
+ *     `off` (0 or x[0]^2). */
+float zlo_block_sumsq(const float *x, uint32_t n, uint32_t off)
 {
     float acc = 0.0f;
-    for (uint32_t i = 0; i < n; ++i) acc += x[i] * x[i];
-    return n ? sqrtf(acc / (float)n) : 0.0f;
+    for (uint32_t i = 0; i < off && i < n; ++i) acc += x[i] * x[i];
+    for (uint32_t t0 = off; t0 < n; t0 += 64) {
+        float a[64];
+        for (uint32_t l = 0; l < 64; ++l) { const float v = (t0 + l < n) ? x[t0 + l] : 0.0f; a[l] = v * v; }
+        for (uint32_t s_ = 1; s_ < 64; s_ *= 2)
+            for (uint32_t i = 0; i < 64; i += 2 * s_) a[i] = a[i] + a[i + s_];
+        acc += a[0];
+    }
+    return acc;
+}
+
+float zlo_block_rms(const float *x, uint32_t n, uint32_t off)
+{
+    return n ? sqrtf(zlo_block_sumsq(x, n, off) / (float)n) : 0.0f;
 }
 
 /* =============================== JackPassthrough ============================================= */

@@ -120,6 +120,21 @@ void  zlo_clip_set_adsr_sustain(zlo_clip *c, float v);                          
 void  zlo_clip_set_adsr_release(zlo_clip *c, float v);                              /* :678-685 */
 float zlo_subbeat_count_to_seconds(uint64_t bpm, uint64_t subbeats);                /* SyncTimer.cpp:180-183,936-939 */
 
+/* ---- per-clip level / progress chain (ClipAudioSource.cpp:68-69,84-113,225-240) ----
+ * The meter state of ClipAudioSource::Private and the two rate-limited notifiers.  `now_ms` stands for
+ * QDateTime::currentMSecsSinceEpoch().  Each returns 1 when the reference would have called the C callback and
+ * stores the callback's float argument in *value.  juce::Decibels (third-party, restated from the public JUCE
+ * source) is a template on its argument type: float for peakGain() (:92), double for :98 and :101. */
+typedef struct zlo_clip_meter {
+    double  currentLeveldB, prevLeveldB;      /* :68-69, both -400 */
+    double  firstPositionProgress;            /* :85 */
+    int64_t nextPositionUpdateTime;           /* :84 */
+    int64_t nextGainUpdateTime;               /* :87 */
+} zlo_clip_meter;
+void zlo_clip_meter_init(zlo_clip_meter *m);
+int  zlo_sync_audio_level(zlo_clip_meter *m, zlo_clip *clip, int64_t now_ms, float *value);                 /* :88-113 */
+int  zlo_sync_progress(zlo_clip_meter *m, const zlo_clip *clip, int has_callback, int64_t now_ms, float *value);   /* :225-240 */
+
 /* ---- ClipCommand (ClipCommand.h:11-39) ---------------------------------------------------- */
 typedef struct zlo_clip_command {
     int32_t clip;            /* index of the clip (stands for the ClipAudioSource* identity) */
@@ -215,9 +230,11 @@ int32_t zlo_sample_to_peak_int(float x);                        /* :367 / :378 *
 /* one 50 ms tick for one channel over its latest block (:359-398).  L/R may be NULL with n = 0
  * (bufferReadSize == 0).  with_hold mirrors the channelIndex == 1 branch (:391-398). */
 void    zlo_levels_tick(zlo_levels_channel *c, const float *L, const float *R, uint32_t n, int with_hold);
-/* build-defined extension (absent in reference): block RMS = sqrtf(sum_f x[f]*x[f] / n), sum in
- * frame order in fp32. */
-float   zlo_block_rms(const float *x, uint32_t n);
+/* build-defined extension (absent in reference): block RMS = sqrtf(sumsq / n) in fp32; the sum of squares has a
+ * fixed order -- tiles of 64 frames from frame `off` (1 with quirk Q2, 0 with ZLO_MODE_FIX_DELAY), a balanced pairwise
+ * tree inside a tile, tiles added in order (zl_oracle.c) -- so that it is bit-exact across implementations. */
+float   zlo_block_sumsq(const float *x, uint32_t n, uint32_t off);
+float   zlo_block_rms(const float *x, uint32_t n, uint32_t off);
 
 /* ---- JackPassthrough (JackPassthrough.cpp:45-115) ------------------------------------------ */
 typedef struct zlo_passthrough {

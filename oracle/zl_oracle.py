@@ -52,6 +52,11 @@ class Clip(C.Structure):
     ]
 
 
+class ClipMeter(C.Structure):
+    _fields_ = [("currentLeveldB", C.c_double), ("prevLeveldB", C.c_double), ("firstPositionProgress", C.c_double),
+                ("nextPositionUpdateTime", C.c_int64), ("nextGainUpdateTime", C.c_int64)]
+
+
 class ClipCommand(C.Structure):
     _fields_ = [
         ("clip", C.c_int32), ("midiNote", C.c_int32), ("midiChannel", C.c_int32),
@@ -129,6 +134,9 @@ _SIGS = {
     "zlo_clip_set_adsr_sustain": (None, [C.POINTER(Clip), C.c_float]),
     "zlo_clip_set_adsr_release": (None, [C.POINTER(Clip), C.c_float]),
     "zlo_subbeat_count_to_seconds": (C.c_float, [C.c_uint64, C.c_uint64]),
+    "zlo_clip_meter_init": (None, [C.POINTER(ClipMeter)]),
+    "zlo_sync_audio_level": (C.c_int, [C.POINTER(ClipMeter), C.POINTER(Clip), C.c_int64, C.POINTER(C.c_float)]),
+    "zlo_sync_progress": (C.c_int, [C.POINTER(ClipMeter), C.POINTER(Clip), C.c_int, C.c_int64, C.POINTER(C.c_float)]),
     "zlo_clip_command_clear": (None, [C.POINTER(ClipCommand)]),
     "zlo_clip_command_equivalent": (C.c_int, [C.POINTER(ClipCommand), C.POINTER(ClipCommand)]),
     "zlo_voice_init": (None, [C.POINTER(Voice)]),
@@ -144,7 +152,8 @@ _SIGS = {
     "zlo_add_float_db": (C.c_float, [C.c_float, C.c_float]),
     "zlo_sample_to_peak_int": (C.c_int32, [C.c_float]),
     "zlo_levels_tick": (None, [C.POINTER(LevelsChannel), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
-    "zlo_block_rms": (C.c_float, [C.c_void_p, C.c_uint32]),
+    "zlo_block_sumsq": (C.c_float, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "zlo_block_rms": (C.c_float, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "zlo_passthrough_init": (None, [C.POINTER(Passthrough)]),
     "zlo_passthrough_process": (None, [C.POINTER(Passthrough), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]),
     "zlo_render_batch": (None, [C.POINTER(Channel), C.c_int32, C.POINTER(Sound), C.POINTER(Clip), C.POINTER(Clock), C.c_uint32, C.c_uint32,

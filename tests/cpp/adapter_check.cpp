@@ -14,8 +14,18 @@
 #include "zlhip_voice_adapter.h"
 
 struct FakeSynthesiserSound { virtual ~FakeSynthesiserSound() {} };
-struct FakeSamplerVoice {                                          // the virtuals SamplerSynthVoice overrides
+struct FakeAudioBuffer {                                           // the two juce::AudioBuffer<float> members the adapter uses
+    std::vector<std::vector<float>> ch;
+    FakeAudioBuffer(int channels, int n) : ch((size_t)channels, std::vector<float>((size_t)n, 0.0f)) {}
+    int getNumChannels() const { return (int)ch.size(); }
+    void addFrom(int destChannel, int destStartSample, const float *source, int numSamples)
+    {
+        for (int i = 0; i < numSamples; ++i) ch[(size_t)destChannel][(size_t)(destStartSample + i)] += source[i];
+    }
+};
+struct FakeSamplerVoice {                                          // the virtuals SamplerSynthVoice overrides / inherits
     virtual ~FakeSamplerVoice() {}
+    virtual void renderNextBlock(FakeAudioBuffer &, int startSample, int numSamples) = 0;
     virtual bool canPlaySound(FakeSynthesiserSound *) = 0;
     virtual void startNote(int midiNoteNumber, float velocity, FakeSynthesiserSound *, int currentPitchWheelPosition) = 0;
     virtual void stopNote(float velocity, bool allowTailOff) = 0;
@@ -32,7 +42,7 @@ struct Fields {
         o.change_looping = 1; o.change_volume = c.changeVolume ? 1 : 0; o.volume = c.volume;
     }
 };
-using Voice = zlhip::VoiceAdapter<FakeSamplerVoice, FakeSynthesiserSound, FakeSound, FakeClipCommand, Fields>;
+using Voice = zlhip::VoiceAdapter<FakeSamplerVoice, FakeSynthesiserSound, FakeSound, FakeClipCommand, Fields, FakeAudioBuffer>;
 
 static zlhip_engine *make_engine(const std::vector<float> &L, const std::vector<float> &R, int *clip)
 {
@@ -50,13 +60,15 @@ static zlhip_engine *make_engine(const std::vector<float> &L, const std::vector<
     return e;
 }
 
-static void render(zlhip_engine *e, int k, std::vector<float> &out)
+static float g_l[2 * 128], g_r[2 * 128];                          // the last block of the adapter-driven engine, [bus][frame]
+static void render(zlhip_engine *e, int k, std::vector<float> &out, bool keep = false)
 {
     zlhip_clock ck; std::memset(&ck, 0, sizeof ck);
     ck.current_usecs = (uint64_t)k * 2667; ck.next_usecs = (uint64_t)(k + 1) * 2667; ck.jack_subbeat_length_usecs = 5208;
     float l[2 * 128], r[2 * 128];
     if (zlhip_render(e, 128, &ck, l, r) != ZLHIP_OK) { std::printf("render failed: %s\n", zlhip_last_error(e)); std::exit(1); }
     out.insert(out.end(), l, l + 256); out.insert(out.end(), r, r + 256);
+    if (keep) { std::memcpy(g_l, l, sizeof l); std::memcpy(g_r, r, sizeof r); }
 }
 
 int main()
@@ -68,7 +80,8 @@ int main()
     zlhip_engine *eb = make_engine(L, R, &clipB);                 // driven through channel commands
     FakeSound sound; sound.id = clipA;
     OtherSound other;
-    Voice v0(ea, 0, 0), v1(ea, 0, 1);
+    zlhip::BusBlock block0;                                        // what the channel of bus 0 publishes per cycle
+    Voice v0(ea, 0, 0, &block0), v1(ea, 0, 1, &block0);
     if (!v0.canPlaySound(&sound) || v0.canPlaySound(&other)) { std::printf("canPlaySound wrong\n"); return 1; }
 
     FakeClipCommand c0; c0.midiNote = 60; c0.looping = true;
@@ -81,7 +94,27 @@ int main()
     k.clip = clipB; k.midi_channel = -2; k.start_playback = 1; k.looping = 1; k.change_looping = 1;
     k.midi_note = 60; k.volume = 0.7f; if (zlhip_handle_command(eb, &k, 0) != 1) return 1;
     k.midi_note = 67; k.volume = 0.4f; if (zlhip_handle_command(eb, &k, 0) != 1) return 1;
-    for (int i = 0; i < 3; ++i) { render(ea, i, a); render(eb, i, b); }
+    for (int i = 0; i < 3; ++i) { render(ea, i, a, true); render(eb, i, b); }
+    {
+        // the juce::Synthesiser rendering callback: Synthesiser::renderVoices calls EVERY voice with the same buffer and
+        // range; the buffer must receive bus 0's mix exactly once, only inside the range, added to what it held
+        block0.left = g_l; block0.right = g_r; block0.nframes = 128;
+        FakeAudioBuffer buf(2, 128);
+        for (auto &c : buf.ch) for (float &x : c) x = 0.25f;
+        FakeSamplerVoice *voices[2] = { &v0, &v1 };
+        for (FakeSamplerVoice *v : voices) v->renderNextBlock(buf, 16, 96);
+        double energy = 0.0;
+        for (int i = 0; i < 128; ++i) {
+            const bool in = i >= 16 && i < 112;
+            const float wl = 0.25f + (in ? g_l[i] : 0.0f), wr = 0.25f + (in ? g_r[i] : 0.0f);
+            if (buf.ch[0][(size_t)i] != wl || buf.ch[1][(size_t)i] != wr) { std::printf("renderNextBlock: frame %d wrong\n", i); return 1; }
+            energy += (double)g_l[i] * g_l[i];
+        }
+        if (energy == 0.0) { std::printf("renderNextBlock: the block was silent\n"); return 1; }
+        FakeAudioBuffer mono(1, 128);
+        v0.renderNextBlock(mono, 0, 128); v0.renderNextBlock(mono, 100, 64);   // second call: out of the rendered range, ignored
+        for (int i = 0; i < 128; ++i) if (mono.ch[0][(size_t)i] != g_l[i]) { std::printf("renderNextBlock: mono buffer wrong\n"); return 1; }
+    }
     // block 3: live volume change on voice 0 (setCurrentCommand on a playing voice)
     FakeClipCommand upd; upd.midiNote = 60; upd.looping = true; upd.changeVolume = true; upd.volume = 0.25f;
     v0.setCurrentCommand(&upd);

@@ -1,0 +1,144 @@
+"""GPU tier: engine life-cycle behaviour behind the C-ABI that the audio parity tests do not reach -- the source arena
+under load / release cycles (SamplerSynth::registerClip / unregisterClip, reference lib/SamplerSynth.cpp:285-312) and the
+ordering of engine-stream work behind batches queued on a caller's stream."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from scenario import Scene, compare_runs, play_cmd, rand_source, random_scene, run_backend, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; the engine has no CPU path")
+    from libzl_amd import SamplerSynth
+    return SamplerSynth
+
+
+def test_arena_space_is_reused_after_release(Engine):
+    """Cumulative uploads of 12x the arena: every release returns its extent (coalesced), so loading never fails, and a
+    clip loaded into recycled space renders the same bits as the oracle."""
+    from libzl_amd import ZlHipError, clip_command
+    from libzl_amd.engine import synthetic_clocks
+    from oracle import zl_oracle as zo
+    rng = np.random.default_rng(3)
+    arena = 1 << 20                                                       # 1 MiB = 131072 stereo frames
+    syn = Engine(2, 4, max_frames=128, max_batch_blocks=4, max_sounds=16, sound_arena_bytes=arena)
+    live = []
+    total = 0
+    for i in range(60):
+        n = int(rng.integers(20000, 50000))                               # 160-400 KB each
+        L, R = rand_source(rng, n, stereo=(i % 3 != 0))
+        while True:
+            try:
+                cid = syn.register_clip(L, R, 48000.0)
+                break
+            except ZlHipError:
+                assert live, "the arena is empty and a clip that fits was refused"
+                syn.unregister_clip(live.pop(int(rng.integers(0, len(live))))[0])     # full: the host frees a clip, as zynthbox does
+        live.append((cid, L, R))
+        total += n * (8 if R is not None else 4)
+    assert total > 12 * arena
+    # fragmentation check: free everything, then one clip that needs almost the whole arena must fit (extents coalesced)
+    for cid, _, _ in live:
+        syn.unregister_clip(cid)
+    big = (arena // 8) - 64
+    L, R = rand_source(rng, big, stereo=True)
+    cid = syn.register_clip(L, R, 48000.0)
+    # and it plays correctly from the recycled space
+    osyn = zo.OracleSynth(2, 4, 48000.0, 0)
+    oid = osyn.register_clip(L, R, 48000.0)
+    p = syn.default_clip_params(big / 48000.0); p.length_in_beats = 0.3; p.length_seconds = 0.011
+    syn.set_clip_params(cid, p)
+    osyn.clips[oid].lengthInBeats = 0.3; osyn.clips[oid].lengthInSeconds = float(np.float32(0.011))
+    syn.handle_clip_command(clip_command(clip=cid, midi_note=62, midi_channel=-1, start_playback=1, looping=1, change_volume=1, volume=0.8), 0)
+    osyn.handle_clip_command(zo.clip_command(clip=oid, midiNote=62, midiChannel=-1, startPlayback=1, looping=1, changeVolume=1, volume=0.8), 0)
+    clk = synthetic_clocks(4, 128, 48000.0)
+    syn.render_batch(4, 128, clk)
+    ref, _ = osyn.render_batch(4, 128, clk)
+    assert np.array_equal(syn.read_bus().view(np.int32), ref.view(np.int32))
+    syn.close()
+
+
+def test_failed_upload_keeps_neither_slot_nor_space(Engine):
+    from libzl_amd import ZlHipError
+    rng = np.random.default_rng(4)
+    syn = Engine(1, 2, max_frames=64, max_batch_blocks=1, max_sounds=4, sound_arena_bytes=1 << 16)
+    L, R = rand_source(rng, 100000, stereo=True)                          # 800 KB into a 64 KB arena
+    for _ in range(8):                                                    # more failures than sound slots
+        with pytest.raises(ZlHipError):
+            syn.register_clip(L, R, 48000.0)
+    ids = [syn.register_clip(L[:1000], R[:1000], 48000.0) for _ in range(4)]
+    assert sorted(ids) == [0, 1, 2, 3]
+    syn.close()
+
+
+def test_levels_tick_is_ordered_behind_a_batch_on_the_callers_stream(Engine):
+    """zlhip_render_batch(stream = caller's) followed at once by zlhip_levels_tick: the tick kernel runs on the engine's own
+    (non-blocking) stream and must still see the block levels the batch produces."""
+    import torch
+    from oracle import zl_oracle as zo
+    from scenario import snapshot_clip
+    lib = zo.load()
+    sc = random_scene(77, num_buses=8, voices_per_bus=32, nblocks=256, nframes=256, nclips=40, events=False, min_len=4000, max_len=9000)
+    ref_bus, _, _ = run_oracle(sc, threads=8)
+    ref = zo.OracleSynth(1, 1, sc.fs, sc.mode, max_sounds=64)
+    syn = Engine(num_buses=8, voices_per_bus=32, max_frames=256, max_batch_blocks=256, max_sounds=64,
+                 sound_arena_bytes=sum((s[0].shape[0] + 16) * 8 for s in sc.sounds) + (1 << 16))
+    from scenario import engine_cmd
+    for i, (L, R, sr) in enumerate(sc.sounds):
+        ref.register_clip(L, R, sr); syn.register_clip(L, R, sr)
+        sc.clip_setup[i](ref.lib, ref.clips[i])
+        syn.set_clip_params(i, snapshot_clip(ref.clips[i]))
+    for ev in sc.events[0]:
+        syn.handle_clip_command(engine_cmd(**ev[1]), ev[2])
+    stream = torch.cuda.Stream()
+    out = torch.zeros((8, 2, 256 * 256), device="cuda", dtype=torch.float32)
+    # a long-running kernel in front of the batch on the caller's stream widens the window in which an unordered tick
+    # would read the previous contents of the level buffer
+    with torch.cuda.stream(stream):
+        junk = torch.rand((1 << 27,), device="cuda")
+        for _ in range(4):
+            junk = junk * 1.0001 + 0.5
+    syn.render_batch(256, 256, sc.make_clocks(0, 256), bus_out_dev=out.data_ptr(), stream=stream.cuda_stream)
+    lv = syn.levels_tick(block_index=255, with_hold_bus=-1)              # no synchronisation in between
+    bus = out.cpu().numpy()
+    assert np.array_equal(bus.view(np.int32), ref_bus.view(np.int32))
+    for b in range(8):
+        ch = zo.LevelsChannel()
+        L = np.ascontiguousarray(bus[b, 0, 255 * 256:]); R = np.ascontiguousarray(bus[b, 1, 255 * 256:])
+        lib.zlo_levels_tick(C.byref(ch), L.ctypes.data, R.ctypes.data, 256, 0)
+        assert (lv[b].peak_a, lv[b].peak_b) == (ch.peakA, ch.peakB), b
+    syn.close()
+
+
+def test_device_upload_is_ordered_behind_its_producer(Engine):
+    """zlhip_sound_upload_device right after the kernels that fill the planes, no synchronisation by the caller."""
+    import torch
+    from libzl_amd import clip_command
+    from libzl_amd.engine import synthetic_clocks
+    from oracle import zl_oracle as zo
+    n = 1 << 22
+    syn = Engine(1, 2, max_frames=128, max_batch_blocks=2, max_sounds=2, sound_arena_bytes=(n + 64) * 8)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        src = torch.rand((2, n), generator=g, device="cuda") * 2 - 1
+        for _ in range(6):
+            src = src * 0.999                                           # a chain of kernels still running when upload is called
+        cid = syn.register_clip_device(src[0].data_ptr(), src[1].data_ptr(), n, 48000.0)
+    host = src.cpu().numpy()
+    osyn = zo.OracleSynth(1, 2, 48000.0, 0)
+    oid = osyn.register_clip(np.ascontiguousarray(host[0]), np.ascontiguousarray(host[1]), 48000.0)
+    syn.handle_clip_command(clip_command(clip=cid, midi_note=60, midi_channel=-2, start_playback=1, looping=1, change_volume=1, volume=1.0), 0)
+    osyn.handle_clip_command(zo.clip_command(clip=oid, midiNote=60, midiChannel=-2, startPlayback=1, looping=1, changeVolume=1, volume=1.0), 0)
+    clk = synthetic_clocks(2, 128, 48000.0)
+    syn.render_batch(2, 128, clk)
+    ref, _ = osyn.render_batch(2, 128, clk)
+    assert np.array_equal(syn.read_bus().view(np.int32), ref.view(np.int32))
+    syn.close()

@@ -226,6 +226,15 @@ def test_full_voice_count_bit_exact_against_oracle(Engine):
     peaks = syn.block_peaks()
     exp = np.stack([np.abs(np.float32(131072.0) * bus[:, c].reshape(8, 24, 256)).astype(np.int64).max(axis=2) for c in (0, 1)], axis=-1)
     assert np.array_equal(peaks, exp.transpose(1, 0, 2))                   # AudioLevels integer peaks, every block
+    # RMS extension at the full voice count: exact (defined summation order)
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    for k in (0, 11, 23):
+        lv = syn.levels_tick(block_index=k)
+        for b in range(8):
+            for c, got in ((0, lv[b].rms_a), (1, lv[b].rms_b)):
+                row = np.ascontiguousarray(bus[b, c, k * 256:(k + 1) * 256])
+                assert got == lib.zlo_block_rms(row.ctypes.data, 256, 1), (k, b, c)
     syn.close()
 
 
@@ -265,6 +274,14 @@ def test_config2_shape_1024_loops_128_frames_levels(Engine):
     peaks = syn.block_peaks()
     exp = np.stack([np.abs(np.float32(131072.0) * bus[:, c].reshape(16, 30, 128)).astype(np.int64).max(axis=2) for c in (0, 1)], axis=-1)
     assert np.array_equal(peaks, exp.transpose(1, 0, 2))
+    from oracle import zl_oracle as zo                                      # "AudioLevels RMS/peak": the RMS extension, exact
+    lib = zo.load()
+    for k in (0, 17, 29):
+        lv = syn.levels_tick(block_index=k)
+        for b in range(16):
+            for c, got in ((0, lv[b].rms_a), (1, lv[b].rms_b)):
+                row = np.ascontiguousarray(bus[b, c, k * 128:(k + 1) * 128])
+                assert got == lib.zlo_block_rms(row.ctypes.data, 128, 1), (k, b, c)
     syn.close()
 
 
@@ -379,8 +396,34 @@ def test_levels_tick_matches_oracle(Engine):
             if b == 1:
                 assert lv[b].peak_a_hold_signal == chans[b].peakAHoldSignal and lv[b].hold_db_b == chans[b].holdDbB
             if k != -2:
-                rms = lib.zlo_block_rms(L.ctypes.data, 128)
-                assert abs(lv[b].rms_a - rms) <= 1e-5 * max(rms, 1e-6)      # build-defined RMS extension: different (tree) sum order
+                # build-defined RMS extension: the summation order is part of its definition (oracle zlo_block_sumsq): exact
+                assert lv[b].rms_a == lib.zlo_block_rms(L.ctypes.data, 128, 1) and lv[b].rms_b == lib.zlo_block_rms(R.ctypes.data, 128, 1)
+    syn.close()
+
+
+@pytest.mark.parametrize("shape", [dict(nframes=128), dict(nframes=256), dict(nframes=64), dict(nframes=512),
+                                   dict(nframes=256, mode=2), dict(nframes=128, mode=3), dict(nframes=256, mix_group=4),
+                                   dict(nframes=256, batch=1), dict(nframes=1024, mode=2)])
+def test_rms_extension_is_bit_exact_in_every_kernel_shape(Engine, shape):
+    """The sums of squares come from K2's fused scan (N <= 256), from K3's wave-per-block scan (N > 256, single blocks)
+    and from K3 behind the mix-group sum: all three follow the order the oracle defines, in the modes with and without
+    the one-frame delay (tile offset 1 / 0)."""
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    shape = dict(shape)
+    batch = shape.pop("batch", 5)
+    N = shape["nframes"]
+    sc = random_scene(910 + N, num_buses=4, nblocks=5, events=False, **shape)
+    bus, _, syn, _ = run_backend(sc, Engine, batch=batch)
+    off = 0 if (sc.mode & 2) else 1
+    assert np.abs(bus).max() > 0
+    for k in ([-1] if batch == 1 else [0, 3, 4]):
+        lv = syn.levels_tick(block_index=k, with_hold_bus=-1)
+        kk = 4 if batch == 1 else k
+        for b in range(4):
+            L = np.ascontiguousarray(bus[b, 0, kk * N:(kk + 1) * N]); R = np.ascontiguousarray(bus[b, 1, kk * N:(kk + 1) * N])
+            assert lv[b].rms_a == lib.zlo_block_rms(L.ctypes.data, N, off), (k, b)
+            assert lv[b].rms_b == lib.zlo_block_rms(R.ctypes.data, N, off), (k, b)
     syn.close()
 
 

@@ -204,3 +204,110 @@ def test_play_stop_through_the_libzl_symbols_matches_oracle(zl, tmp_path):
     for c, _ in clips:
         zl.ClipAudioSource_destroy(c)
     zl.shutdownJuce()
+
+
+@pytest.mark.gpu
+def test_level_and_progress_callbacks_match_oracle_block_by_block(zl, tmp_path):
+    """the per-clip level / progress chain (ClipAudioSource.cpp:88-113,225-240) under an injected
+    millisecond clock.  120 JACK cycles of 128 frames (2.67 ms each); the clock advances 3 ms per cycle so the 30 ms and
+    100 ms rate limits open and close many times; a one-shot starts, fades into its release tail and ends; a loop is
+    stopped with a tail.  Every callback value AND the cycle in which it fired must equal the oracle's restatement."""
+    from libzl_amd import libzl
+    from libzl_amd.engine import synthetic_clocks
+    rng = np.random.default_rng(23)
+    lib = zo.load()
+    now = [1_000_000]
+    clock_cb = libzl.CLOCK_MS(lambda: now[0])
+    zl.libzl_hotpath_set_clock_ms(clock_cb)
+    try:
+        zl.initJuce()
+        assert zl.libzl_hotpath_status() == 0
+        osyn = zo.OracleSynth(12, 8, 48000.0, 0)
+        clips, meters, got_lvl, got_prog = [], [], [], []
+        cbs = []
+        cycle = [0]
+        for i in range(3):
+            n = 9000 + 1300 * i
+            env = np.linspace(1.0, 0.05, n).astype(np.float32)               # a decaying clip: the meter has something to follow
+            L = (rng.uniform(-1, 1, n).astype(np.float32) * env); R = (rng.uniform(-1, 1, n).astype(np.float32) * env) if i != 2 else None
+            c = zl.ClipAudioSource_new(_wav(tmp_path, zl, L, R, 48000.0, 32, f"m{i}.wav"), False)
+            oid = osyn.register_clip(L, R, 48000.0)
+            oc = osyn.clips[oid]
+            zl.ClipAudioSource_setLength(c, 0.3 + 0.05 * i, 120); lib.zlo_clip_set_length(C.byref(oc), C.c_float(0.3 + 0.05 * i), 120)
+            zl.ClipAudioSource_setStartPosition(c, 0.01 * i); lib.zlo_clip_set_start_position(C.byref(oc), C.c_float(0.01 * i))
+            zl.ClipAudioSource_setADSRRelease(c, 0.02); lib.zlo_clip_set_adsr_release(C.byref(oc), C.c_float(0.02))
+            m = zo.ClipMeter(); lib.zlo_clip_meter_init(C.byref(m))
+            lv = libzl.CB(lambda db, i=i: got_lvl.append((cycle[0], i, db)))
+            pg = libzl.CB(lambda s, i=i: got_prog.append((cycle[0], i, s)))
+            zl.ClipAudioSource_setAudioLevelChangedCallback(c, lv)
+            if i != 1:
+                zl.ClipAudioSource_setProgressCallback(c, pg)                  # clip 1 has no progress callback (:228)
+            cbs += [lv, pg]
+            clips.append((c, oid)); meters.append(m)
+
+        def ocmd(oid, ch, loop, stop_only=False):
+            f = dict(clip=oid, midiChannel=ch, midiNote=60, stopPlayback=1) if stop_only else \
+                dict(clip=oid, midiChannel=ch, midiNote=60, changeVolume=1, volume=1.0, looping=1 if loop else 0, startPlayback=1, **({"stopPlayback": 1} if loop else {}))
+            osyn.handle_clip_command(zo.clip_command(**f), 0)
+
+        N = 128
+        outL = np.zeros((12, N), dtype=np.float32); outR = np.zeros((12, N), dtype=np.float32)
+        want_lvl, want_prog = [], []
+        val = C.c_float()
+        for k in range(120):
+            cycle[0] = k
+            now[0] += 3
+            osyn.now_ms = now[0]
+            if k == 2:
+                zl.ClipAudioSource_play(clips[0][0], True); ocmd(clips[0][1], -2, True)
+            if k == 10:
+                zl.ClipAudioSource_playOnChannel(clips[1][0], False, 1); ocmd(clips[1][1], 1, False)      # one-shot: ends by itself
+                zl.ClipAudioSource_playOnChannel(clips[2][0], True, 4); ocmd(clips[2][1], 4, True)
+            if k == 70:
+                zl.ClipAudioSource_stopOnChannel(clips[2][0], 4); ocmd(clips[2][1], 4, False, stop_only=True)
+            if k == 90:
+                zl.ClipAudioSource_stop(clips[0][0])
+                for ch in [-2, -1] + list(range(10)):
+                    ocmd(clips[0][1], ch, False, stop_only=True)
+            clk = synthetic_clocks(1, N, 48000.0, start_block=k)
+            assert zl.libzl_hotpath_process(N, clk, outL.ctypes.data, outR.ctypes.data) == 0
+            bus, _ = osyn.render_batch(1, N, clk)
+            assert np.array_equal(outL.view(np.int32), bus[:, 0].view(np.int32)) and np.array_equal(outR.view(np.int32), bus[:, 1].view(np.int32)), k
+            for i, (c, oid) in enumerate(clips):
+                oc = osyn.clips[oid]
+                if lib.zlo_sync_audio_level(C.byref(meters[i]), C.byref(oc), now[0], C.byref(val)):
+                    want_lvl.append((k, i, val.value))
+                if lib.zlo_sync_progress(C.byref(meters[i]), C.byref(oc), 1 if i != 1 else 0, now[0], C.byref(val)):
+                    want_prog.append((k, i, val.value))
+                assert zl.ClipAudioSource_peakGain(c) == lib.zlo_positions_peak_gain(C.byref(oc.positions)), (k, i)
+                assert zl.ClipAudioSource_firstProgress(c) == lib.zlo_positions_first_progress(C.byref(oc.positions)), (k, i)
+        assert len(want_lvl) > 20 and len(want_prog) > 5            # the scene exercises both chains
+        assert {i for _, i, _ in want_lvl} == {0, 1, 2}
+        assert got_lvl == want_lvl
+        assert got_prog == want_prog
+        for c, _ in clips:
+            zl.ClipAudioSource_destroy(c)
+        zl.shutdownJuce()
+    finally:
+        zl.libzl_hotpath_set_clock_ms(libzl.CLOCK_MS())
+
+
+def test_clip_meter_restatement_known_answers():
+    """Hand-derived values of the level chain (ClipAudioSource.cpp:88-113): first tick from -400 dB, the x0.94 fade
+    (20 log10 0.94 = -0.5374 dB per tick), the 30 ms gate and the 0.1 dB notification threshold."""
+    lib = zo.load()
+    oc = zo.Clip(); lib.zlo_clip_init(C.byref(oc), C.c_float(1.0), 48000.0)
+    m = zo.ClipMeter(); lib.zlo_clip_meter_init(C.byref(m))
+    v = C.c_float()
+    pid = lib.zlo_positions_create(C.byref(oc.positions), 0.0, 100)
+    lib.zlo_positions_set_gain_and_progress(C.byref(oc.positions), pid, 0.5, 0.25, 100)
+    assert lib.zlo_sync_audio_level(C.byref(m), C.byref(oc), 100, C.byref(v)) == 1
+    assert abs(v.value - 20 * np.log10(0.5)) < 1e-5                     # -6.0206 dB
+    assert lib.zlo_sync_audio_level(C.byref(m), C.byref(oc), 129, C.byref(v)) == 0   # inside the 30 ms gate
+    lib.zlo_positions_set_gain_and_progress(C.byref(oc.positions), pid, 0.0, 0.5, 131)
+    assert lib.zlo_sync_audio_level(C.byref(m), C.byref(oc), 131, C.byref(v)) == 1   # the bar fades instead of dropping
+    assert abs(v.value - (20 * np.log10(0.5) + 20 * np.log10(0.94))) < 1e-4
+    assert lib.zlo_sync_progress(C.byref(m), C.byref(oc), 1, 131, C.byref(v)) == 1 and v.value == 0.5   # progress 0.5 x 1 s
+    assert lib.zlo_sync_progress(C.byref(m), C.byref(oc), 1, 200, C.byref(v)) == 0                       # 100 ms gate
+    lib.zlo_positions_set_gain_and_progress(C.byref(oc.positions), pid, 0.0, 0.5004, 240)
+    assert lib.zlo_sync_progress(C.byref(m), C.byref(oc), 1, 240, C.byref(v)) == 0                       # moved by < 0.001

@@ -96,7 +96,63 @@ def run_scene(name, *, B, VPB, fs, mode, nframes, nblocks, sounds, clips, events
     print(f"{name}: peak |x| = {max(np.abs(busL).max(), np.abs(busR).max()):.4f}  -> {os.path.relpath(path, ROOT)} ({os.path.getsize(path)} bytes)")
 
 
+def config1_full_shape():
+    """BASELINE configs[0] at its stated shape (SURVEY 8d cfg 1): ONE mono 44.1 kHz source of 176 400 frames (4.0 s = 8 beats
+    at 120 bpm), 256-frame blocks, looping, volumeAbsolute 1, pan 0, default ADSR -- played twice: on bus 0 with
+    lengthInBeats = 8 (an integer number of beats: the loop restarts against the JACK clock, current_usecs = k * 5805,
+    SamplerSynthVoice.cpp:227-241) and on bus 1 with lengthInBeats = 7.5 (fractional: the sample-space wrap of :243-246).
+    1400 blocks = two passes of the loop.  The fixture keeps the inputs (source quantised to 16 bits so that it stores as
+    int16), the expected audio / source indices of the blocks around every loop restart, and SHA-256 digests of the WHOLE
+    expected bus and index trace."""
+    import hashlib
+    rng = np.random.default_rng(0x5A17 + 0)
+    q = rng.integers(-32768, 32768, 176400).astype(np.int16)
+    L = q.astype(np.float32) / f32(32768.0)
+    B, VPB, fs, N, K = 2, 1, 44100.0, 256, 1400
+    syn = nr.Synth(B, VPB, fs, 0)
+    for beats in (8.0, 7.5):
+        i = syn.register(L, None, 44100.0)
+        c = syn.clips[i]
+        c.set_length(beats, 120)
+        c.volume_abs = f32(1.0); c.pan = f32(0.0)
+    for i, ch in ((0, -2), (1, -1)):
+        syn.handle(nr.Command(clip=i, midi_channel=ch, midi_note=60, start=True, stop=True, looping=True, change_volume=True, volume=f32(1.0)), 0)
+    bus = np.zeros((B, 2, K * N), dtype=np.float32)
+    trace = np.full((K, B * VPB, N), -1, dtype=np.int32)
+    clocks = []
+    for k in range(K):
+        clk = clocks_for(k, N, fs, 120)
+        clocks.append([clk.current_usecs, clk.next_usecs, clk.playhead, clk.playhead_usecs, clk.subbeat_usecs])
+        Lo, Ro, reports = syn.process(N, clk)
+        bus[:, 0, k * N:(k + 1) * N] = Lo; bus[:, 1, k * N:(k + 1) * N] = Ro
+        for (b, i), (valid, gain, prog, tr) in reports.items():
+            trace[k, b * VPB + i] = tr
+    # blocks in which a voice's source index steps back = loop restarts; keep them and their neighbours, plus both ends
+    keep = {0, 1, 2, K - 2, K - 1}
+    restarts = {}
+    for v in range(B * VPB):
+        flat = trace[:, v, :].reshape(-1)
+        for idx in np.nonzero(np.diff(flat) < 0)[0]:
+            k = int((idx + 1) // N)
+            restarts.setdefault(v, []).append((k, int((idx + 1) % N)))
+            keep.update(range(max(0, k - 2), min(K, k + 3)))
+    keep = sorted(keep)
+    assert all(len(r) == 2 for r in restarts.values()), restarts
+    state = np.array([[1.0 if syn.voices[b][0].is_playing else 0.0, float(syn.voices[b][0].P)] for b in range(B)])
+    meta = dict(name="c1_config1_shape", B=B, VPB=VPB, fs=fs, nframes=N, nblocks=K, bpm=120, beats=[8.0, 7.5],
+                restarts={str(v): r for v, r in restarts.items()},
+                bus_sha256=hashlib.sha256(bus.tobytes()).hexdigest(), trace_sha256=hashlib.sha256(trace.tobytes()).hexdigest())
+    path = os.path.join(HERE, "c1_config1_shape.npz")
+    np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), source_q15=q,
+                        keep=np.array(keep, dtype=np.int32),
+                        bus_keep=np.stack([bus[:, :, k * N:(k + 1) * N] for k in keep]), trace_keep=trace[keep],
+                        state=state, clocks=np.array(clocks, dtype=np.uint64)[[0, 1, K - 1]])
+    print(f"c1_config1_shape: restarts {restarts}, {len(keep)} blocks kept -> {os.path.relpath(path, ROOT)} ({os.path.getsize(path)} bytes)")
+
+
 def main():
+    if "--config1" in sys.argv:
+        return config1_full_shape()
     rng = np.random.default_rng(0x5A17)
 
     def src(n, stereo=True):
@@ -187,3 +243,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if "--config1" not in sys.argv and "--all" in sys.argv:
+        config1_full_shape()

@@ -15,7 +15,7 @@ _MAP = {"clip": "clip", "midi_channel": "midiChannel", "midi_note": "midiNote", 
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "g[0-9]*.npz")))
 
 
 def load_golden(name):
@@ -63,3 +63,45 @@ def load_golden(name):
     sc.clocks = make_clocks
     expect = dict(bus=np.stack([z["busL"], z["busR"]], axis=1), trace=z["trace"], reports=z["reports"], state=z["state"])
     return sc, expect
+
+
+def load_config1():
+    """tests/golden/c1_config1_shape.npz (make_golden.py --config1): BASELINE configs[0] at its stated shape.  Returns the
+    Scene and the expectations: kept blocks (indices, audio [n][B][2][N], source indices [n][V][N]), SHA-256 of the whole
+    bus / trace, the loop restarts per voice, the final voice state."""
+    z = np.load(os.path.join(GOLDEN_DIR, "c1_config1_shape.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    L = z["source_q15"].astype(np.float32) / np.float32(32768.0)
+    sc = Scene(num_buses=meta["B"], voices_per_bus=meta["VPB"], fs=meta["fs"], mode=0, nframes=meta["nframes"], nblocks=meta["nblocks"], bpm=meta["bpm"])
+    import ctypes as C
+    from scenario import play_cmd
+    for i, beats in enumerate(meta["beats"]):
+        sc.sounds.append((L, None, 44100.0))
+
+        def setup(lib, clip, beats=beats):
+            lib.zlo_clip_set_length(clip, C.c_float(beats), 120)        # ClipAudioSource::setLength, ClipAudioSource.cpp:352-360
+            lib.zlo_clip_set_volume_absolute(clip, C.c_float(1.0))
+            lib.zlo_clip_set_pan(clip, C.c_float(0.0))
+        sc.clip_setup[i] = setup
+    sc.events[0] = [("cmd", play_cmd(0, midi_channel=-2), 0), ("cmd", play_cmd(1, midi_channel=-1), 0)]
+    c = z["clocks"]
+    period = int(c[0][1] - c[0][0])
+    assert int(c[1][0]) == period and int(c[2][0]) == (meta["nblocks"] - 1) * period      # the synthetic clock k * 5805
+    expect = dict(keep=[int(k) for k in z["keep"]], bus_keep=z["bus_keep"], trace_keep=z["trace_keep"], state=z["state"],
+                  bus_sha256=meta["bus_sha256"], trace_sha256=meta["trace_sha256"],
+                  restarts={int(v): [tuple(r) for r in rs] for v, rs in meta["restarts"].items()})
+    return sc, expect
+
+
+def check_config1(bus, trace, expect, N=256):
+    """bus [B][2][K*N], trace [K][V][N] of any implementation against the fixture: the kept blocks bit for bit, the rest through
+    the digests of the whole arrays."""
+    import hashlib
+    for j, k in enumerate(expect["keep"]):
+        got = bus[:, :, k * N:(k + 1) * N]
+        assert np.array_equal(got.view(np.int32), expect["bus_keep"][j].view(np.int32)), f"block {k}: audio differs (max {np.abs(got - expect['bus_keep'][j]).max()})"
+        if trace is not None:
+            assert np.array_equal(trace[k], expect["trace_keep"][j]), f"block {k}: source indices differ"
+    assert hashlib.sha256(np.ascontiguousarray(bus).tobytes()).hexdigest() == expect["bus_sha256"], "whole-bus digest differs"
+    if trace is not None:
+        assert hashlib.sha256(np.ascontiguousarray(trace).tobytes()).hexdigest() == expect["trace_sha256"], "whole-trace digest differs"

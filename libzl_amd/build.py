@@ -36,6 +36,17 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, flags: list, verbose: bool = False) -> str:
+    """A/B and diagnostic builds: libzl_amd/lib/libzlhip_<name>.so with extra -D flags (loaded through the ZLHIP_LIBRARY
+    environment variable by scripts/; never by the package itself)."""
+    global LIB
+    saved, LIB = LIB, os.path.join(LIBDIR, f"libzlhip_{name}.so")
+    try:
+        return _build_engine(False, verbose, list(flags))
+    finally:
+        LIB = saved
+
+
 def build_engine(force: bool = False, verbose: bool = False, stamps: bool = False) -> str:
     """stamps=True builds the diagnostic variant libzlhip_stamps.so (-DZL_STAMPS: per-workgroup
     timestamps in K2; used only by scripts/k2_stamps.py, never by the package)."""

@@ -118,6 +118,7 @@ struct zlhip_engine {
     int lastK = 0, lastN = 0, lastWindows = 0; float *lastBus = nullptr; bool outstanding = false; bool reportsFresh = false;
     bool trace = false; int traceK = 0, traceN = 0;
     int forceSlow = 0;
+    int staged = 0;                      // K2 variant with LDS-staged source windows (zl_kernels.hip), chosen per mode at creation
 
     // profiling
     bool profiling = false; hipEvent_t evJoin = nullptr;
@@ -264,7 +265,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         if (st != hipSuccess && rc == ZLHIP_OK) { e->err = std::string(what) + ": " + hipGetErrorString(st); rc = ZLHIP_ERR_HIP; }
     };
     chk(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
-    chk(dalloc(&e->arena, e->arenaFloats), "arena");
+    chk(dalloc(&e->arena, e->arenaFloats + 1024), "arena");     // + 4 KB: wide loads at the end of the last source stay inside
     chk(dalloc(&e->dSounds, (size_t)cfg->max_sounds), "sounds");
     chk(dalloc(&e->dClips, (size_t)cfg->max_sounds), "clips");
     chk(dalloc(&e->dVoices, V), "voices");
@@ -367,6 +368,13 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         std::fprintf(stderr, "zlhip_engine_create: %s\n", e->err.c_str());
         zlhip_engine_destroy(e);
         return rc;
+    }
+    {
+        // K2 variant with LDS-staged source windows: ZL_K2_STAGED = 0 never (default: the register gather is faster in every
+        // measured configuration, profiles/round2_b_lds_staging_ab.txt), 1 in Hermite mode only, 2 always
+        const char *st = std::getenv("ZL_K2_STAGED");
+        const int sel = st ? std::atoi(st) : 0;
+        e->staged = sel >= 2 ? 1 : (sel == 1 && (cfg->mode & ZLHIP_MODE_HERMITE)) ? 1 : 0;
     }
     e->hc.init(cfg->num_buses, cfg->voices_per_bus, cfg->max_sounds, cfg->playback_sample_rate);
     e->soundFloats.assign((size_t)cfg->max_sounds, 0);
@@ -693,6 +701,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         A.NB = std::max(1, std::min(128 / A.VPB, A.B));
     A.clocks_regular = regular ? 1 : 0;
     A.mode = e->cfg.mode;
+    A.staged = (e->staged && !e->trace) ? 1 : 0;                  // (the position trace lives in the gather paths)
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
     A.voices = e->dVoices; A.reports = c.dReports; A.pass_cache = e->dPassCache;
     A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.stats = c.dStats;

@@ -441,6 +441,135 @@ static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged source windows (north_star: "one wavefront per voice-tile with source samples staged in LDS").
+// For a (voice, block) whose frames advance along one exact line, the 64 frames of a wavefront read the contiguous source
+// window [pos(first) - tb, pos(last) + ta] (tb / ta = taps before / after: 0 / 1 linear, 1 / 2 Hermite).  The wave fetches
+// that window ONCE with a single LDS-DMA instruction (global_load_lds_dwordx4: lane i moves bytes [16 i, 16 i + 16) of the
+// window straight into LDS, no register in between; lanes past the window's end are masked off) into a slot of its own
+// ring, ZL_ST_D voices deep, and its lanes then read their taps from LDS.  Against the register gather this moves each
+// source byte through the texture path once instead of 2x (linear) or 4x (Hermite: two overlapping 16-byte gathers per
+// lane), and keeps ZL_ST_D - ZL_ST_U .. ZL_ST_D voices of every wave in flight without holding them in VGPRs.
+// Windows are private to a wave: no barrier, the wave's own counted s_waitcnt vmcnt orders its reads behind its DMA.
+#ifndef ZL_ST_SLOT
+#define ZL_ST_SLOT 1024      // bytes per ring slot = one LDS-DMA piece: windows of up to 128 stereo frames (ratio <= 1.95)
+#endif
+#ifndef ZL_ST_D
+#define ZL_ST_D 6            // ring depth in voices (slots per wave); measured: 6 > 10 > 16 (occupancy beats depth, profiles/round2_b_*)
+#endif
+#ifndef ZL_ST_U
+#define ZL_ST_U 2            // voices per staged compute step
+#endif
+#ifndef ZL_ST_CHUNK
+#define ZL_ST_CHUNK 64       // voice records per pass in the staged variant (64 or 128)
+#endif
+struct ZlWin { int a; int n16; };   // window of one (voice, wave): first source frame (even: 16-byte aligned), 16-byte pieces; n16 == 0: not staged
+extern __shared__ __attribute__((aligned(16))) char zl_dyn_lds[];
+
+static __device__ __forceinline__ uint32_t zl_lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+// One LDS-DMA piece.  Lane address gaddr (the window's base + this lane's 16 bytes) -> LDS at dst (wave-uniform LDS byte
+// address, in M0) + lane * 16, for the lanes with lane16 < nbytes.  The compiler neither sees the load nor counts it: the
+// caller waits with zl_wait_vm<N>().  s_waitcnt lgkmcnt(0) first: every LDS read this wave has issued (the previous tenant of
+// the slot among them) has returned before the DMA may overwrite it.  M0 is compiler-reserved: saved and restored.
+static __device__ __forceinline__ void zl_glds_piece(const char *gaddr, uint32_t lane16, uint32_t nbytes, uint32_t dst)
+{
+#ifdef ZL_ST_DIAG_NODMA      // timing-only diagnostic build: no DMA (the taps read whatever the ring holds)
+    return;
+#endif
+    unsigned keep; unsigned long long save;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\t"
+                 "v_cmp_lt_u32 vcc, %3, %4\n\t"
+                 "s_and_saveexec_b64 %1, vcc\n\t"
+                 "global_load_lds_dwordx4 %2, off\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(save)
+                 : "v"(gaddr), "v"(lane16), "v"(nbytes), "s"(dst)
+                 : "memory", "vcc", "scc");
+}
+template <int N> static __device__ __forceinline__ void zl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// What a lane needs of a staged voice besides its taps: wave-uniform values, read from the staged records ONE step ahead
+// (they do not depend on the DMA), so that a step's only exposed LDS round trip is the tap read itself.
+struct ZlStParams {
+    double P0, step;
+    int    a;                 // first source frame of this wave's window
+    float  env, vol;
+    zl_f2  gain, pan;         // (l, r) pairs
+};
+static __device__ __forceinline__ ZlStParams zl_st_params(const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlWin *s_win, int i)
+{
+    ZlStParams q;
+    q.P0 = s_plan[i].P0; q.step = s_plan[i].step; q.env = s_plan[i].env;
+    q.a = s_win[i * 4].a;
+    q.gain = (zl_f2){s_vc[i].lgain, s_vc[i].rgain}; q.vol = s_vc[i].clip_volume; q.pan = (zl_f2){s_vc[i].lpan, s_vc[i].rpan};
+    return q;
+}
+// The DMA of voice j of the pass, as per-lane values (no scalar round trip): lane address and bytes of the window.  Voices
+// that are not staged fetch 16 bytes from the start of the arena (always there) by one lane, so that the wave's count of
+// outstanding DMAs stays uniform.
+struct ZlStDma { const char *g; uint32_t nbytes; };
+static __device__ __forceinline__ ZlStDma zl_st_dma(const ZlBatch &A, const ZlVoiceConst *s_vc, const ZlWin *s_win, int j, uint32_t lane16)
+{
+    const ZlWin wn = s_win[j * 4];
+    const uint64_t so = s_vc[j].src_offset;
+    ZlStDma d;
+    d.g = reinterpret_cast<const char *>(A.arena) + (wn.n16 ? (so << 2) + ((uint64_t)(uint32_t)wn.a << 3) + lane16 : 0ull);
+    d.nbytes = wn.n16 ? (uint32_t)wn.n16 << 4 : 16u;
+    return d;
+}
+
+// The taps of one staged voice for this lane, from ring slot `slot` of the wave.
+struct ZlStTaps { zl_f2 xm, x0, x1, x2; float alpha; };
+template <uint32_t MODE>
+static __device__ __forceinline__ ZlStTaps zl_st_taps(const ZlStParams &q, const char *ring, int slot, double fd)
+{
+    constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
+    ZlStTaps t;
+    const double P = fma(fd, q.step, q.P0);                       // exact, see zl_plan.h
+    const int pos = (int)P;                                       // :198-199 (P >= 0)
+    t.alpha = (float)__builtin_amdgcn_fract(P);
+    const char *p = ring + slot * ZL_ST_SLOT + ((pos - (HERM ? 1 : 0) - q.a) << 3);
+    if (HERM) {
+        t.xm = *reinterpret_cast<const zl_f2 *>(p);      t.x0 = *reinterpret_cast<const zl_f2 *>(p + 8);
+        t.x1 = *reinterpret_cast<const zl_f2 *>(p + 16); t.x2 = *reinterpret_cast<const zl_f2 *>(p + 24);
+    } else {
+        t.x0 = *reinterpret_cast<const zl_f2 *>(p); t.x1 = *reinterpret_cast<const zl_f2 *>(p + 8);
+        t.xm = t.x0; t.x2 = t.x1;
+    }
+    return t;
+}
+// :200-221 of one staged voice ("interior": all taps inside the source; stereo, whole block, sustain) -- the same arithmetic
+// as the interior variant of zl_k2_chunk_simple.
+template <uint32_t MODE>
+static __device__ __forceinline__ void zl_st_mix(const ZlBatch &A, const ZlStParams &q, const ZlStTaps &t, int voice, bool wantPeak, zl_f2 &acc)
+{
+    float l, r;
+    if (MODE & ZL_MODE_HERMITE) {
+        const zl_f2 o = zl_mix_frame_pk<MODE>(t.xm, t.x0, t.x1, t.x2, t.alpha, true, true, q.gain, q.env, q.vol, q.pan);
+        acc += o;
+        l = o.x; r = o.y;
+    } else {
+        ZlTaps tt;
+        tt.x0l = t.x0.x; tt.x0r = t.x0.y; tt.x1l = t.x1.x; tt.x1r = t.x1.y;
+        tt.xml = tt.xmr = tt.x2l = tt.x2r = 0.0f;
+        zl_mix_frame<MODE>(tt, t.alpha, true, false, true, q.gain.x, q.gain.y, q.env, q.vol, q.pan.x, q.pan.y, l, r);
+        acc.x += l; acc.y += r;                                   // :218-221 (index shift applied at the store)
+    }
+    if (wantPeak) {                                               // :213-216, signed peak from 0 (Q6)
+        const float ng = l + r;
+        float pk = ng > 0.0f ? ng : 0.0f;
+        pk = zl_wave_max(pk);
+        if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[voice].peak_bits, __float_as_uint(pk));
+    }
+}
+
 template <uint32_t MODE, bool CTL, int U>
 static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc,
                                                     const int *s_cls, int c0, size_t pbase, int vfirst, int f, bool wantPeak,
@@ -527,17 +656,22 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
 // BPW = blocks per workgroup.  Blocks shorter than 256 frames are rendered 256 / N at a time (BPW = 2 or 4: the 256
 // threads are BPW groups of N frames), so the per-workgroup fixed costs -- launch, staging of the voice records -- are
 // paid once per 256 frames whatever the block size is.  A wavefront never straddles two blocks (N is a multiple of 64).
-template <uint32_t MODE, int BPW>
+// ST = the variant with LDS-staged source windows (zl_st_* above): its occupancy is set by the ring in LDS (2-3
+// workgroups per CU), so it may take the registers of 3 waves per SIMD.
+template <uint32_t MODE, int BPW, bool ST>
 // (faithful linear mode, one block per workgroup -- the headline shape: ask for the 6 waves per SIMD its 78 registers
 // allow; left to itself the allocator takes 82 and drops to 5)
-__global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 && BPW == 1) ? 6 : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
+__global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 && BPW == 1) ? 6 : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
 {
     constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U_HERMITE : ZL_K2_U;
-    __shared__ ZlBlockPlan  s_plan_[BPW][ZL_K2_CHUNK];
-    __shared__ ZlVoiceConst s_vc[ZL_K2_CHUNK];
-    __shared__ int s_cls_[BPW][ZL_K2_CHUNK];          // per voice: 1 = plays this block, 2 = per-frame control
-    __shared__ int s_chunk_[BPW][ZL_K2_CHUNK / U];    // class of each chunk of U voices
-    __shared__ ZlUnit s_unit_[BPW][ZL_K2_CHUNK];
+    constexpr int CH = ST ? ZL_ST_CHUNK : ZL_K2_CHUNK;    // voice records staged per pass (the staged variant trades them for ring space)
+    __shared__ ZlWin s_win_[ST ? CH * 4 : 1];             // [voice][wave of the workgroup]
+    __shared__ unsigned long long s_stmask_[ST ? BPW * (CH / 64) : 1];   // per block: which voices of the pass are staged
+    __shared__ ZlBlockPlan  s_plan_[BPW][CH];
+    __shared__ ZlVoiceConst s_vc[CH];
+    __shared__ int s_cls_[BPW][CH];                   // per voice: 1 = plays this block, 2 = per-frame control
+    __shared__ int s_chunk_[BPW][CH / U];             // class of each chunk of U voices
+    __shared__ ZlUnit s_unit_[BPW][CH];
     __shared__ int   s_pk[2][ZL_K2_MAXNB][4];         // fused level scan: per-wave partial results of each of the workgroup's buses
     __shared__ float s_sq[2][ZL_K2_MAXNB][4];
 
@@ -650,14 +784,14 @@ __global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_D
         }
     };
 
-    for (int vb = v0; vb < v1; vb += ZL_K2_CHUNK) {
-        const int nv = (v1 - vb < ZL_K2_CHUNK) ? v1 - vb : ZL_K2_CHUNK;
+    for (int vb = v0; vb < v1; vb += CH) {
+        const int nv = (v1 - vb < CH) ? v1 - vb : CH;
         // ---- stage the per-voice records of this pass in LDS: one lane per (block, voice) issues every load it may
         //      need at once (voice constants, run list; plan header + first segment when no run covers the block), so
         //      the prologue is one memory round trip (two for blocks with a second segment) and one barrier
         __syncthreads();
-        for (int idx = threadIdx.x; idx < BPW * ZL_K2_CHUNK; idx += blockDim.x) {   // whole waves: blockDim.x is a multiple of 64
-            const int b = idx / ZL_K2_CHUNK, i = idx - b * ZL_K2_CHUNK;
+        for (int idx = threadIdx.x; idx < BPW * CH; idx += blockDim.x) {   // whole waves: blockDim.x is a multiple of 64
+            const int b = idx / CH, i = idx - b * CH;
             const int kk = yb * BPW + b;
             ZlVoiceConst vc;
             ZlBlockPlan pl;
@@ -683,6 +817,27 @@ __global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_D
                 cls |= 4 | (pl.nseg == 2 ? 8 : 0) | (vc.channels == 1 ? 16 : 0) | ((pl.nseg == 1 && pl.step == 1.0 && pl.P0 < 1073741824.0) ? 32 : 0)
                      | (interior ? 64 : 0);
             }
+            if (ST) {
+                // windows of the block's waves (BPW == 1: the workgroup's four frame tiles; else the N / 64 waves of block b).
+                // Staged: an interior stereo voice on one line whose window fits a slot for every wave.
+                constexpr int WPB = 4 / BPW;
+                constexpr int TB = (MODE & ZL_MODE_HERMITE) ? 1 : 0, TA = (MODE & ZL_MODE_HERMITE) ? 2 : 1;
+                const bool cand = (cls & (4 | 8 | 16 | 64)) == (4 | 64) && (uint32_t)vc.sample_duration < 0x0ffffff0u;
+                int a[WPB], n16[WPB];
+                bool fits = cand;
+#pragma unroll
+                for (int w = 0; w < WPB; ++w) {
+                    const int f0 = (BPW > 1) ? 64 * w : (int)blockIdx.x * 256 + 64 * w;
+                    const int first = (int)fma((double)f0, pl.step, pl.P0) - TB, last = (int)fma((double)(f0 + 63), pl.step, pl.P0) + TA;
+                    a[w] = first & ~1;                             // even frame = 16-byte aligned in the arena
+                    n16[w] = (last - a[w] + 2) >> 1;               // 16-byte pieces covering frames [a, last]
+                    fits = fits && n16[w] >= 1 && n16[w] <= ZL_ST_SLOT / 16;
+                }
+#pragma unroll
+                for (int w = 0; w < WPB; ++w) { ZlWin wn; wn.a = fits ? a[w] : 0; wn.n16 = fits ? n16[w] : 0; s_win_[i * 4 + b * WPB + w] = wn; }
+                const unsigned long long fm = __ballot(fits);      // the wave's 64 voices are one block's voices [64 m, 64 m + 64)
+                if ((i & 63) == 0) s_stmask_[b * (CH / 64) + (i >> 6)] = fm;
+            }
             { ZlUnit un; un.ipos = (int)pl.P0; un.alpha = (float)(pl.P0 - (double)un.ipos); s_unit_[b][i] = un; }
             if (b == 0) s_vc[i] = vc;
             s_plan_[b][i] = pl;                   // idle slots: a harmless record with no active frame
@@ -707,6 +862,102 @@ __global__ void __launch_bounds__(256, ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_D
         zl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
         const size_t pbase = (size_t)k * V + vb;
+        if (ST) {
+            // ---- LDS-staged pass: the wave's ring runs ZL_ST_D voices ahead of its compute.  Voice j of the pass owns slot j mod
+            //      ZL_ST_D.  Before the step over voices [c0, c0 + US) everything up to voice c0 + US - 1 must have landed: at most
+            //      the D - US youngest DMAs (voices c0 + US .. c0 + D - 1) may be outstanding.  Voices that are not staged (loop
+            //      ends, events, mono, ...) take a one-lane dummy DMA so that the count stays uniform, and are rendered by the
+            //      general single-voice path -- in voice order, as always.  A step's wave-uniform inputs (the next voices'
+            //      parameters, the next DMAs' addresses) are read one step ahead, into registers.
+            constexpr int D = ZL_ST_D, US = ZL_ST_U;
+            static_assert(D % US == 0 && D > US && D <= 60 && 8 % US == 0, "ring shape");
+            const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const char *ring = zl_dyn_lds + wave * (D * ZL_ST_SLOT);
+            const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)zl_lds_addr(ring));
+            const ZlWin *s_win = s_win_ + wave;                    // entry of voice i: s_win[i * 4]
+            const uint32_t lane16 = (threadIdx.x & 63u) << 4;
+            unsigned long long stm[CH / 64];
+#pragma unroll
+            for (int m = 0; m < CH / 64; ++m) {
+                const unsigned long long x = s_stmask_[blk * (CH / 64) + m];
+                stm[m] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x);
+            }
+            const int nvR = (nv + US - 1) / US * US;
+            for (int j = 0; j < D && j < nv; ++j) {
+                const ZlStDma d = zl_st_dma(A, s_vc, s_win, j, lane16);
+                zl_glds_piece(d.g, lane16, d.nbytes, ring_lds + (uint32_t)j * ZL_ST_SLOT);
+            }
+            // parameters in two register sets that swap roles every step (no copies); the per-voice DMA descriptors likewise
+            ZlStParams pa[US], pb[US];
+#pragma unroll
+            for (int u = 0; u < US; ++u) pa[u] = zl_st_params(s_plan, s_vc, s_win, u);           // (records of idle slots are harmless)
+            int slot0 = 0;
+            // one step over voices [c0, c0 + US): `cur` was read one step ago, `nxt` is read now for the following step
+            auto step = [&](int c0, const ZlStParams (&cur)[US], ZlStParams (&nxt)[US]) {
+                if (c0 + D < nv) zl_wait_vm<D - US>(); else zl_wait_vm<0>();     // (past that point nothing more is issued)
+                const unsigned long long mw = (CH > 64 && c0 >= 64) ? stm[(CH / 64) - 1] : stm[0];
+                const unsigned sm = (unsigned)(mw >> (c0 & 63)) & ((1u << US) - 1u);
+                int slot[US];
+#pragma unroll
+                for (int u = 0; u < US; ++u) { slot[u] = slot0 + u; slot[u] -= slot[u] >= D ? D : 0; }
+                ZlStDma dma[US];
+                if (sm == (1u << US) - 1u) {
+                    ZlStTaps t[US];
+#pragma unroll
+                    for (int u = 0; u < US; ++u) t[u] = zl_st_taps<MODE>(cur[u], ring, slot[u], fd);
+                    // one step ahead, while the taps travel: the next voices' parameters and the next DMAs' addresses
+#pragma unroll
+                    for (int u = 0; u < US; ++u) {
+                        nxt[u] = zl_st_params(s_plan, s_vc, s_win, c0 + US + u < CH ? c0 + US + u : CH - 1);
+                        dma[u] = zl_st_dma(A, s_vc, s_win, c0 + D + u < CH ? c0 + D + u : CH - 1, lane16);
+                    }
+                    zl_f2 acc = {accL, accR};
+#ifdef ZL_ST_DIAG_NOMIX     // timing-only diagnostic build: taps are read, nothing is computed
+#pragma unroll
+                    for (int u = 0; u < US; ++u) acc += t[u].xm + t[u].x2;
+#else
+#pragma unroll
+                    for (int u = 0; u < US; ++u) zl_st_mix<MODE>(A, cur[u], t[u], vb + c0 + u, wantPeak, acc);
+#endif
+                    accL = acc.x; accR = acc.y;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < US; ++u) {
+                        const int i = c0 + u;
+                        if (i < nv) {
+                            const int cl = __builtin_amdgcn_readfirstlane(s_cls[i]);
+                            if ((sm >> u) & 1u) {
+                                const ZlStTaps t = zl_st_taps<MODE>(cur[u], ring, slot[u], fd);
+                                zl_f2 ac = {accL, accR};
+                                zl_st_mix<MODE>(A, cur[u], t, vb + i, wantPeak, ac);
+                                accL = ac.x; accR = ac.y;
+                            } else if (cl == 0) { }                                                       // idle (SamplerSynth.cpp:137)
+                            else if (cl & 2) zl_k2_chunk<MODE, true, 1>(A, s_plan, s_vc, s_cls, i, pbase, vb, f, wantPeak, accL, accR);
+                            else zl_k2_chunk<MODE, false, 1>(A, s_plan, s_vc, s_cls, i, pbase, vb, f, wantPeak, accL, accR);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < US; ++u) {
+                        nxt[u] = zl_st_params(s_plan, s_vc, s_win, c0 + US + u < CH ? c0 + US + u : CH - 1);
+                        dma[u] = zl_st_dma(A, s_vc, s_win, c0 + D + u < CH ? c0 + D + u : CH - 1, lane16);
+                    }
+                }
+                if (NB > 1 && vb + c0 + US == busEnd) {
+                    // that step held the last voice of a bus (bus widths are multiples of 8 and US divides 8): write it, start the next
+                    store_bus(curBus);
+                    accL = 0.0f; accR = 0.0f;
+                    ++curBus; busEnd += A.VPB;
+                }
+#pragma unroll
+                for (int u = 0; u < US; ++u)
+                    if (c0 + D + u < nv) zl_glds_piece(dma[u].g, lane16, dma[u].nbytes, ring_lds + (uint32_t)slot[u] * ZL_ST_SLOT);
+                slot0 += US; slot0 -= slot0 >= D ? D : 0;
+            };
+            for (int c0 = 0; c0 < nvR; c0 += 2 * US) {
+                step(c0, pa, pb);
+                if (c0 + US < nvR) step(c0 + US, pb, pa);
+            }
+        } else
         for (int c0 = 0; c0 < nv; c0 += U) {
             const int cc = __builtin_amdgcn_readfirstlane(s_chunk[c0 / U]);
 #ifdef ZL_STAMPS
@@ -970,11 +1221,17 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEv
     const int pad = (A.mode & ZL_MODE_HERMITE) ? (pad_env_h >= 0 ? pad_env_h : 0) : (pad_env >= 0 ? pad_env : 10240);
     // ev_start / ev_stop (profiling): the kernel's own begin / end timestamps, taken by the dispatch packet itself -- no
     // event packets around the launch for the command processor to handle
+    // LDS-staged source windows (A.staged): batches only, whole 256-thread workgroups; the ring is dynamic LDS
+    const bool st = A.staged && A.K > 1 && tpb == 256;
+    const int ring = 4 * ZL_ST_D * ZL_ST_SLOT;
     switch (A.mode & 7u) {
 #define ZL_CASE(M) case M: \
-        if (bpw == 4)      hipExtLaunchKernelGGL((zl_k2_render<M, 4>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
-        else if (bpw == 2) hipExtLaunchKernelGGL((zl_k2_render<M, 2>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
-        else               hipExtLaunchKernelGGL((zl_k2_render<M, 1>), grid, block, pad, s, ev_start, ev_stop, 0, A); \
+        if (st && bpw == 4)      hipExtLaunchKernelGGL((zl_k2_render<M, 4, true>), grid, block, ring, s, ev_start, ev_stop, 0, A); \
+        else if (st && bpw == 2) hipExtLaunchKernelGGL((zl_k2_render<M, 2, true>), grid, block, ring, s, ev_start, ev_stop, 0, A); \
+        else if (st)             hipExtLaunchKernelGGL((zl_k2_render<M, 1, true>), grid, block, ring, s, ev_start, ev_stop, 0, A); \
+        else if (bpw == 4)       hipExtLaunchKernelGGL((zl_k2_render<M, 4, false>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
+        else if (bpw == 2)       hipExtLaunchKernelGGL((zl_k2_render<M, 2, false>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
+        else                     hipExtLaunchKernelGGL((zl_k2_render<M, 1, false>), grid, block, pad, s, ev_start, ev_stop, 0, A); \
         break;
         ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
 #undef ZL_CASE

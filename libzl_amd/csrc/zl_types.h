@@ -189,6 +189,7 @@ struct ZlBatch {
                                   //    the block in which a beat-locked loop restarts can be found by bisection
     int32_t inline_clock;         // 1: the (single) block's clock travels in clock0 with the kernel arguments
     int32_t fuse_assemble;        // 1: K1 assembles the plan records itself (single real-time block: one launch less)
+    int32_t staged;               // 1: K2 stages source windows in LDS (LDS-DMA ring) instead of gathering into registers
     ZlClock clock0;
     const ZlClock      *clocks;   // [K]
     const ZlSound      *sounds;

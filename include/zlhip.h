@@ -160,7 +160,8 @@ const char *zlhip_strerror(int status);
  * in *out_id.  The id doubles as the clip id (one SamplerSynthSound per ClipAudioSource). */
 int zlhip_sound_upload(zlhip_engine *e, const float *left, const float *right, int32_t length,
                        double sample_rate, int32_t *out_id);
-/* Same, but left/right are DEVICE pointers on the engine's device (no PCIe transfer). */
+/* Same, but left/right are DEVICE pointers on the engine's device (no PCIe transfer).  The call waits for the device
+ * (hipDeviceSynchronize) before it reads them: whatever stream produced the planes, they are complete. */
 int zlhip_sound_upload_device(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length,
                               double sample_rate, int32_t *out_id);
 int zlhip_sound_release(zlhip_engine *e, int32_t id);          /* SamplerSynth::unregisterClip */
@@ -220,6 +221,27 @@ int zlhip_block_peaks(zlhip_engine *e, int32_t *out, size_t out_ints);
 /* levels of an arbitrary DEVICE bus buffer [num_buses][2][nblocks*nframes] (e.g. the result of a
  * multi-GPU reduce): recomputes the per-block peaks the next zlhip_levels_tick will use */
 int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblocks, int32_t nframes, void *stream);
+
+/* ---- multi-GPU exchange (a bus that spans GPUs) ----------------------------------------------------
+ * The only coupling between voices is the per-bus sum of SamplerChannel::process (SamplerSynth.cpp:134-140).  When the
+ * voices of a bus live on several GPUs, every rank renders a partial bus [num_buses][2][nblocks*nframes] and the ranks
+ * exchange it piecewise (all-to-all over the xGMI mesh: rank r receives piece r of every rank's partial bus; the transport is
+ * the host's, e.g. RCCL).  A piece is a run of whole UNITS, unit u = (bus * 2 + channel) * nblocks + block = nframes
+ * consecutive floats of the bus buffer.
+ *
+ * zlhip_bus_reduce_sum_scan: one kernel, run by every rank on the pieces it received.  Sums them in piece (= rank) order,
+ * ((0 + p0) + p1) + ... per sample -- deterministic, the same bits for any number of ranks, and equal to the single-GPU
+ * result with voices_per_task = voices per rank -- writes the reduced piece and, in the same pass, the AudioLevels scan of
+ * every unit (integer peak, AudioLevels.cpp:361-383; sum of squares of the RMS extension).
+ *   pieces_dev      DEVICE [npieces] pieces of units * nframes floats, piece_stride_floats apart (the all-to-all receive buffer)
+ *   sum_out_dev     DEVICE [units * nframes]
+ *   levels_out_dev  DEVICE [units]
+ * zlhip_levels_import_units: on the rank that meters (the root, after gathering the unit levels of all pieces in unit order
+ * [num_buses * 2 * nblocks]): makes them the block levels the next zlhip_levels_tick / zlhip_block_peaks read. */
+typedef struct zlhip_unit_levels { int32_t peak; float sumsq; } zlhip_unit_levels;
+int zlhip_bus_reduce_sum_scan(zlhip_engine *e, const float *pieces_dev, int32_t npieces, int64_t piece_stride_floats, int64_t units,
+                              int32_t nframes, float *sum_out_dev, zlhip_unit_levels *levels_out_dev, void *stream);
+int zlhip_levels_import_units(zlhip_engine *e, const zlhip_unit_levels *units_dev, int32_t nblocks, int32_t nframes, void *stream);
 
 /* ---- JackPassthrough fan-out ---------------------------------------------------------------- */
 void zlhip_passthrough_params_default(zlhip_passthrough_params *p);

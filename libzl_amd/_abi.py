@@ -127,6 +127,8 @@ SIGNATURES = {
     "zlhip_levels_tick": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(Levels)]),
     "zlhip_block_peaks": (C.c_int, [_E, C.c_void_p, C.c_size_t]),
     "zlhip_levels_scan_device": (C.c_int, [_E, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "zlhip_bus_reduce_sum_scan": (C.c_int, [_E, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zlhip_levels_import_units": (C.c_int, [_E, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "zlhip_passthrough_params_default": (None, [C.POINTER(PassthroughParams)]),
     "zlhip_passthrough_process": (C.c_int, [_E, C.POINTER(PassthroughParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "zlhip_set_profiling": (C.c_int, [_E, C.c_int]),
@@ -159,6 +161,10 @@ def load():
                 "(hipcc --offload-arch=gfx950).  libzl_amd has no CPU fallback.")
         _lib = bind(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
     return _lib
+
+
+class UnitLevels(C.Structure):
+    _fields_ = [("peak", C.c_int32), ("sumsq", C.c_float)]
 
 
 class ZlHipError(RuntimeError):

@@ -995,6 +995,35 @@ int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblo
     return ZLHIP_OK;
 }
 
+// ---- multi-GPU exchange ---------------------------------------------------------------------------
+int zlhip_bus_reduce_sum_scan(zlhip_engine *e, const float *pieces_dev, int32_t npieces, int64_t piece_stride_floats, int64_t units,
+                              int32_t nframes, float *sum_out_dev, zlhip_unit_levels *levels_out_dev, void *stream)
+{
+    static_assert(sizeof(zlhip_unit_levels) == sizeof(ZlUnitLevels), "ABI mirror");
+    if (!e || !pieces_dev || !sum_out_dev || !levels_out_dev || npieces < 1 || units < 1 || nframes < 64 || (nframes % 64) != 0
+        || piece_stride_floats < units * (int64_t)nframes) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    const int off = (e->cfg.mode & ZLHIP_MODE_FIX_DELAY) ? 0 : 1;  // tile offset of the RMS order (zl_scan_rows)
+    ZL_KERNEL(e, zl_launch_reduce_scan(pieces_dev, npieces, (long long)piece_stride_floats, (long long)units, nframes, off, sum_out_dev,
+                                       reinterpret_cast<ZlUnitLevels *>(levels_out_dev), s));
+    if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->evJoin, s)); e->joins[1] = e->evJoin; }
+    e->outstanding = true;
+    return ZLHIP_OK;
+}
+
+int zlhip_levels_import_units(zlhip_engine *e, const zlhip_unit_levels *units_dev, int32_t nblocks, int32_t nframes, void *stream)
+{
+    if (!e || !units_dev || nblocks < 1 || nblocks > e->cfg.max_batch_blocks || nframes < 64 || nframes > e->cfg.max_frames) return ZLHIP_ERR_INVALID;
+    ZL_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    ZL_KERNEL(e, zl_launch_levels_import(reinterpret_cast<const ZlUnitLevels *>(units_dev), e->dLevels, e->cfg.num_buses, nblocks, s));
+    if (s != e->stream) { ZL_HIP(e, hipEventRecord(e->evJoin, s)); e->joins[1] = e->evJoin; }
+    e->lastK = nblocks; e->lastN = nframes;
+    e->outstanding = true;
+    return ZLHIP_OK;
+}
+
 // ---- JackPassthrough ------------------------------------------------------------------------------
 void zlhip_passthrough_params_default(zlhip_passthrough_params *p)
 {

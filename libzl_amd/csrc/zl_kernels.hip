@@ -1093,6 +1093,64 @@ __global__ void __launch_bounds__(256) zl_k3_scan(const ZlBatch A, const float *
     if (lane == 0) A.levels[(size_t)k * A.B + b] = out;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU exchange step: when a bus spans GPUs every rank receives, for its share of the bus, one piece
+// per rank (all-to-all over the xGMI mesh).  This kernel sums the pieces IN RANK ORDER -- ((0 + p0) + p1) + ... per sample,
+// the order of K3's mix-group sum and of the oracle's grouped mix, so the result is the same bits for any number of ranks --
+// writes the reduced piece, and scans it for AudioLevels in the same pass: integer peak and sum of squares (defined order,
+// zl_scan_rows) per unit.  A piece is a run of whole units; unit = the N frames of one (bus, channel, block).  One wave per
+// unit; the loads of up to 8 pieces are in flight before the ordered adds.
+__global__ void __launch_bounds__(256) zl_k_reduce_scan(const float *pieces, int npieces, long long stride, long long units, int N, int off,
+                                                        float *out, ZlUnitLevels *lv)
+{
+    const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= units) return;                                        // whole waves leave
+    const int lane = threadIdx.x & 63;
+    const float *p0 = pieces + u * N;
+    float *o = out + u * N;
+    auto sum_at = [&](int idx) {
+        float v = 0.0f;
+        const float *p = p0 + idx;
+        int r = 0;
+        for (; r + 8 <= npieces; r += 8) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = p[(long long)(r + j) * stride];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += x[j];
+        }
+        for (; r < npieces; ++r) v += p[(long long)r * stride];
+        return v;
+    };
+    int pk = 0; float sq = 0.0f;
+    if (off) {                                                     // the frame in front of the first tile (every lane: one address)
+        const float v = sum_at(0);
+        if (lane == 0) o[0] = v;
+        pk = zl_sample_to_peak_int(v); sq = v * v;
+    }
+    for (int t0 = off; t0 < N; t0 += 64) {
+        const int idx = t0 + lane;
+        float v = 0.0f;
+        if (idx < N) { v = sum_at(idx); o[idx] = v; }
+        const int a = zl_sample_to_peak_int(v);
+        pk = a > pk ? a : pk;
+        sq += zl_wave_sum(v * v);                                  // wave-uniform running sum, tile order
+    }
+    pk = zl_wave_max_nonneg(pk);
+    if (lane == 0) { ZlUnitLevels r; r.peak = pk; r.sumsq = sq; lv[u] = r; }
+}
+
+// unit levels of a whole bus ([bus][channel][block], as the exchange gathers them) -> the engine's per-block levels
+__global__ void zl_k_levels_import(const ZlUnitLevels *units, ZlBlockLevels *levels, int B, int K)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;           // (block, bus), bus fastest
+    if (i >= B * K) return;
+    const int k = i / B, b = i - k * B;
+    const ZlUnitLevels l = units[((size_t)b * 2) * K + k], r = units[((size_t)b * 2 + 1) * K + k];
+    ZlBlockLevels o; o.peak_l = l.peak; o.peak_r = r.peak; o.sumsq_l = l.sumsq; o.sumsq_r = r.sumsq;
+    levels[i] = o;
+}
+
 // AudioLevels::timerCallback state update for every bus (AudioLevels.cpp:359-360, 367-383 via the
 // block scan of K3, 385, 395-396).  dBFS conversion (log10f) stays on the host, as in the reference.
 __global__ void zl_k_levels_tick(ZlLevelsState *state, const ZlBlockLevels *levels, int B, int N, int with_hold_bus)
@@ -1266,6 +1324,20 @@ int zl_launch_reports(const ZlReport *reports, int V, float *gain_out, ZlReport 
 int zl_launch_levels_tick(ZlLevelsState *state, const ZlBlockLevels *levels, int B, int N, int with_hold_bus, hipStream_t s)
 {
     hipLaunchKernelGGL(zl_k_levels_tick, dim3((B + 63) / 64), dim3(64), 0, s, state, levels, B, N, with_hold_bus);
+    ZL_LAUNCH_CHECK();
+    return 0;
+}
+
+int zl_launch_reduce_scan(const float *pieces, int npieces, long long stride, long long units, int N, int off, float *out, ZlUnitLevels *lv, hipStream_t s)
+{
+    hipLaunchKernelGGL(zl_k_reduce_scan, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, pieces, npieces, stride, units, N, off, out, lv);
+    ZL_LAUNCH_CHECK();
+    return 0;
+}
+
+int zl_launch_levels_import(const ZlUnitLevels *units, ZlBlockLevels *levels, int B, int K, hipStream_t s)
+{
+    hipLaunchKernelGGL(zl_k_levels_import, dim3((unsigned)((B * K + 255) / 256)), dim3(256), 0, s, units, levels, B, K);
     ZL_LAUNCH_CHECK();
     return 0;
 }

@@ -148,6 +148,11 @@ struct ZlBlockLevels {            // per (block, bus)
     float   sumsq_l, sumsq_r;     // sum of squares (RMS extension)
 };
 
+struct ZlUnitLevels {             // levels of one (bus, channel, block) unit of a bus piece (multi-GPU exchange, zl_k_reduce_scan)
+    int32_t peak;                 // max over the unit of (int)|131072*x|
+    float   sumsq;                // sum of squares in the defined order (RMS extension)
+};
+
 struct ZlLevelsState {            // AudioLevelsChannel meter state per bus
     int32_t peak_a, peak_b;
     float   hold_a, hold_b;

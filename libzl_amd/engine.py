@@ -230,6 +230,18 @@ class SamplerSynth:
         self._ck(self._lib.zlhip_levels_scan_device(self._e, bus_dev_ptr, nblocks, nframes, stream), "levels_scan_device")
         self._last = (nblocks, nframes)
 
+    # -- multi-GPU exchange (a bus that spans GPUs) -------------------------------------------
+    def bus_reduce_sum_scan(self, pieces_dev_ptr: int, npieces: int, piece_stride_floats: int, units: int, nframes: int,
+                            sum_out_dev_ptr: int, levels_out_dev_ptr: int, stream: Optional[int] = None):
+        """Sum `npieces` received bus pieces in piece (= rank) order and scan the result for AudioLevels, one kernel."""
+        self._ck(self._lib.zlhip_bus_reduce_sum_scan(self._e, pieces_dev_ptr, npieces, piece_stride_floats, units, nframes,
+                                                     sum_out_dev_ptr, levels_out_dev_ptr, stream), "bus_reduce_sum_scan")
+
+    def levels_import_units(self, units_dev_ptr: int, nblocks: int, nframes: int, stream: Optional[int] = None):
+        """Unit levels of the whole bus ([bus][channel][block]) -> the block levels levels_tick / block_peaks read."""
+        self._ck(self._lib.zlhip_levels_import_units(self._e, units_dev_ptr, nblocks, nframes, stream), "levels_import_units")
+        self._last = (nblocks, nframes)
+
     # -- passthrough ------------------------------------------------------------------------
     def passthrough(self, params: Sequence[PassthroughParams], in_dev_ptr: int, out_dev_ptr: int, frames: int, stream: Optional[int] = None):
         arr = (PassthroughParams * self.num_buses)(*params)

@@ -1,11 +1,15 @@
-"""Multi-GPU sharding of the sampler hot path: one process per GPU, voices partitioned across ranks,
-one RCCL sum-reduce of the stereo buses onto rank 0.
+"""Multi-GPU sharding of the sampler hot path: one process per GPU.
 
 Voices are independent given the shared clock and clip parameters (SamplerSynthVoice::process has no
 cross-voice state); the only coupling is the per-bus sum of SamplerChannel::process
-(reference lib/SamplerSynth.cpp:134-140).  Every rank therefore renders the voices it owns into a
-partial bus [num_buses, 2, frames]; the partial buses are summed with ONE collective per batch and
-AudioLevels (which must see the final mix, not the partials) runs on the root afterwards.
+(reference lib/SamplerSynth.cpp:134-140).  Two partitions follow from that:
+
+* **bus-aligned** (`BusPartition`, used whenever the job has at least as many buses as GPUs): every GPU owns whole buses --
+  their voices, their sources, their mix and their meters.  No bus spans GPUs, so NO data-path collective runs at all.
+* **a bus spans GPUs** (`exchange_bus_mesh` / `OverlappedBusReduce`): every rank renders the voices it owns into a partial bus
+  [num_buses, 2, frames]; the partial buses are exchanged piecewise over the point-to-point xGMI mesh (all-to-all), every rank
+  sums the pieces it received in rank order AND scans them for AudioLevels with one HIP kernel behind the C-ABI
+  (`zlhip_bus_reduce_sum_scan`), and the reduced pieces and their levels are gathered on the root.
 
 `torch.distributed` with backend "nccl" is RCCL over xGMI on ROCm; the same code runs on "gloo" for
 the CPU tests.  The reduce's operand order is the backend's (ring / tree), so for more than two ranks
@@ -25,6 +29,38 @@ def voice_range(num_voices: int, world_size: int, rank: int) -> Tuple[int, int]:
 def bus_owner(bus: int, num_buses: int, world_size: int) -> int:
     """Bus-aligned partition for the case num_buses >= world_size: whole buses per GPU, no collective."""
     return (bus * world_size) // num_buses
+
+
+class BusPartition:
+    """Bus-aligned partition: global bus g lives on rank bus_owner(g); a rank's engine holds its buses as local buses
+    0..n-1 in global order.  The per-bus sum -- the only coupling of the path -- never crosses a GPU: rendering, mixing and
+    metering of a rank's buses need no collective.  (Global midi channel of local bus b: first + b - 2, SamplerSynth.cpp:270.)"""
+
+    def __init__(self, num_buses_global: int, world_size: int, rank: int):
+        if num_buses_global < world_size:
+            raise ValueError("bus-aligned partition needs at least one bus per rank; let the bus span ranks instead (exchange_bus_mesh)")
+        self.num_buses_global, self.world_size, self.rank = num_buses_global, world_size, rank
+        self.buses = [g for g in range(num_buses_global) if bus_owner(g, num_buses_global, world_size) == rank]
+        self.first = self.buses[0]
+
+    @property
+    def num_local_buses(self) -> int:
+        return len(self.buses)
+
+    def local_bus(self, global_bus: int) -> int:
+        """Local index of a global bus on this rank, or -1 if another rank owns it."""
+        return global_bus - self.first if self.first <= global_bus < self.first + len(self.buses) else -1
+
+    def local_command(self, cmd):
+        """A ClipCommand addressed by GLOBAL midi channel (bus g has channel g - 2) -> the same command for this rank's engine,
+        or None when the channel's bus lives on another rank (the command is simply not this rank's)."""
+        b = self.local_bus(cmd.midi_channel + 2)
+        if b < 0:
+            return None
+        import copy
+        c = copy.copy(cmd)
+        c.midi_channel = b - 2
+        return c
 
 
 def slots_for_rank(voices_per_bus_global: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -91,6 +127,57 @@ def reduce_bus_mesh(bus, dst: int = 0, group=None, scratch=None):
     return bus
 
 
+def exchange_bus_mesh(synth, bus, nblocks: int, nframes: int, dst: int = 0, group=None, scratch=None, stream=None):
+    """A bus that spans ranks, over the point-to-point mesh, with the sum and the meters in ONE kernel behind the C-ABI.
+    `bus` [num_buses, 2, nblocks*nframes] is this rank's partial bus.  The flat bus is world equal pieces of whole units (unit =
+    the nframes of one (bus, channel, block)):
+      1. all-to-all: rank r receives piece r of every rank's partial bus (world - 1 links in parallel, 1/world of the bytes each);
+      2. synth.bus_reduce_sum_scan: ((0 + p0) + p1) + ... per sample in rank order + the AudioLevels scan of every unit;
+      3. gather of the reduced pieces (into `bus` on dst) and of their unit levels; dst imports the levels into its engine.
+    Falls back to reduce_bus_mesh + a scan on the root when the units do not divide evenly among the ranks.
+    scratch: optional dict the caller keeps between batches (receive / result buffers).  stream: the stream the kernels run on
+    (an int handle) when it is not torch's current stream."""
+    import os
+    import torch
+    import torch.distributed as dist
+    single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    if single and not os.environ.get("ZL_FORCE_COLLECTIVES"):
+        synth.levels_scan_device(bus.data_ptr(), nblocks, nframes, stream=stream)
+        return bus
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = bus.shape[0]
+    units_total = B * 2 * nblocks
+    if units_total % world != 0:
+        reduce_bus_mesh(bus, dst=dst, group=group)
+        if rank == dst:
+            synth.levels_scan_device(bus.data_ptr(), nblocks, nframes, stream=stream)
+        return bus
+    units = units_total // world
+    chunk = units * nframes
+    flat = bus.view(-1)
+    sc = scratch if scratch is not None else {}
+    key = (flat.numel(), flat.device, world)
+    if sc.get("key") != key:
+        sc.clear()
+        sc["key"] = key
+        sc["recv"] = torch.empty_like(flat)
+        sc["acc"] = torch.empty(chunk, dtype=torch.float32, device=flat.device)
+        sc["lv"] = torch.empty((units, 2), dtype=torch.int32, device=flat.device)          # zlhip_unit_levels {int32 peak; float sumsq}
+        sc["lv_all"] = torch.empty((world, units, 2), dtype=torch.int32, device=flat.device) if rank == dst else None
+    recv, acc, lv = sc["recv"], sc["acc"], sc["lv"]
+    dist.all_to_all_single(recv, flat, group=group)               # recv[r] = piece `rank` of rank r's partial bus
+    if flat.is_cuda and stream is None:
+        stream = torch.cuda.current_stream(flat.device).cuda_stream   # the kernel follows the collective on its stream
+    synth.bus_reduce_sum_scan(recv.data_ptr(), world, chunk, units, nframes, acc.data_ptr(), lv.data_ptr(), stream=stream)
+    pieces = [flat[r * chunk:(r + 1) * chunk] for r in range(world)] if rank == dst else None
+    dist.gather(acc, gather_list=pieces, dst=dst, group=group)    # piece r of the final bus comes from rank r
+    lvs = [sc["lv_all"][r] for r in range(world)] if rank == dst else None
+    dist.gather(lv, gather_list=lvs, dst=dst, group=group)
+    if rank == dst:
+        synth.levels_import_units(sc["lv_all"].data_ptr(), nblocks, nframes, stream=stream)
+    return bus
+
+
 def render_sharded(synth, nblocks: int, nframes: int, clocks, bus, dst: int = 0, stream=None, group=None):
     """One batch on this rank's voices into `bus` (device pointer of a torch tensor), then the bus reduce;
     on the root the reduced bus is scanned for AudioLevels.  `synth` is a libzl_amd.SamplerSynth."""
@@ -126,7 +213,7 @@ class OverlappedBusReduce:
         self.i = 0
         if algorithm != "reduce":
             import torch
-            self.scratch = [torch.empty_like(self.bus[0]), torch.empty_like(self.bus[0])] if algorithm == "mesh" else [None, None]
+            self.scratch = [{}, {}] if algorithm == "mesh" else [None, None]
             if self.cuda:
                 self.comm = torch.cuda.Stream(device=self.bus[0].device)
                 self.done = [torch.cuda.Event(), torch.cuda.Event()]
@@ -145,9 +232,10 @@ class OverlappedBusReduce:
             else:
                 self.work[j].wait()                   # the current stream waits for the collective
             self.work[j] = None
-            if dist.get_rank(self.group) == self.dst and self.shape[j] is not None:
+            if self.algorithm != "mesh" and dist.get_rank(self.group) == self.dst and self.shape[j] is not None:
                 nb, nf = self.shape[j]
                 self.synth.levels_scan_device(self.bus[j].data_ptr(), nb, nf, stream=stream)   # levels see the final mix
+            # ("mesh": every rank scanned its reduced piece inside zlhip_bus_reduce_sum_scan; the root imported the levels)
 
     def step(self, nblocks: int, nframes: int, clocks, stream=None):
         import torch
@@ -163,7 +251,7 @@ class OverlappedBusReduce:
             else:
                 self.work[j] = dist.reduce(self.bus[j], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            fn = (lambda: reduce_bus_mesh(self.bus[j], dst=self.dst, group=self.group, scratch=self.scratch[j])) \
+            fn = (lambda: exchange_bus_mesh(self.synth, self.bus[j], nblocks, nframes, dst=self.dst, group=self.group, scratch=self.scratch[j])) \
                 if self.algorithm == "mesh" else (lambda: reduce_bus_in_rank_order(self.bus[j], dst=self.dst, group=self.group))
             if self.cuda:
                 # the exchange, the ordered sum and the gather run on the communication stream, behind the render

@@ -47,7 +47,7 @@ class SimSynth:
     def __init__(self, num_buses=12, voices_per_bus=8, *, mode=0, playback_sample_rate=48000.0,
                  max_sounds=1024, voices_per_task=0, **_):
         self.l = lib()
-        self.num_buses, self.voices_per_bus = num_buses, voices_per_bus
+        self.num_buses, self.voices_per_bus, self.mode = num_buses, voices_per_bus, mode
         self.num_voices = num_buses * voices_per_bus
         self.s = C.c_void_p(self.l.zlsim_create(num_buses, voices_per_bus, max_sounds, playback_sample_rate, mode, voices_per_task))
         self._last = (0, 0)
@@ -90,6 +90,30 @@ class SimSynth:
         buf = np.ctypeslib.as_array(C.cast(bus_ptr, C.POINTER(C.c_float)), (n,)).reshape(self.num_buses, 2, nblocks, nframes)
         v = np.abs(np.float32(131072.0) * buf)
         self.scanned_peaks = v.astype(np.int64).max(axis=3).transpose(2, 0, 1)      # [block][bus][channel]
+
+    # host stand-ins of the two exchange kernels (zlhip_bus_reduce_sum_scan / zlhip_levels_import_units): the same defined
+    # arithmetic -- ((0 + p0) + p1) + ... in fp32, integer peak, sums of squares through the oracle's order -- on host pointers
+    def bus_reduce_sum_scan(self, pieces_ptr, npieces, piece_stride_floats, units, nframes, sum_out_ptr, levels_out_ptr, stream=None):
+        from oracle import zl_oracle as zo
+        lib = zo.load()
+        src = np.ctypeslib.as_array(C.cast(pieces_ptr, C.POINTER(C.c_float)), (npieces * piece_stride_floats,)).reshape(npieces, piece_stride_floats)
+        out = np.ctypeslib.as_array(C.cast(sum_out_ptr, C.POINTER(C.c_float)), (units * nframes,))
+        lv = np.ctypeslib.as_array(C.cast(levels_out_ptr, C.POINTER(C.c_int32)), (units * 2,)).reshape(units, 2)
+        acc = np.zeros(units * nframes, dtype=np.float32)
+        for r in range(npieces):
+            acc = acc + src[r, :units * nframes]
+        out[:] = acc
+        off = 0 if (self.mode & 2) else 1
+        rows = np.ascontiguousarray(acc.reshape(units, nframes))
+        lv[:, 0] = np.abs(np.float32(131072.0) * rows).astype(np.int64).max(axis=1)
+        sq = np.array([lib.zlo_block_sumsq(rows[u].ctypes.data, nframes, off) for u in range(units)], dtype=np.float32)
+        lv[:, 1] = sq.view(np.int32)
+
+    def levels_import_units(self, units_ptr, nblocks, nframes, stream=None):
+        u = np.ctypeslib.as_array(C.cast(units_ptr, C.POINTER(C.c_int32)), (self.num_buses * 2 * nblocks * 2,)).reshape(self.num_buses, 2, nblocks, 2)
+        self.scanned_peaks = u[:, :, :, 0].transpose(2, 0, 1).astype(np.int64)                  # [block][bus][channel]
+        self.scanned_sumsq = np.ascontiguousarray(u[:, :, :, 1]).view(np.float32).transpose(2, 0, 1)
+        self._last = (nblocks, nframes)
 
     def read_bus(self):
         return self._bus

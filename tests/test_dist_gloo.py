@@ -42,10 +42,14 @@ def _worker(rank, world, port, q):
     sc.voices_per_bus = hi - lo
     bus, rep, syn, _ = run_backend(sc, SimSynth, batch=5)
     t = torch.from_numpy(np.ascontiguousarray(bus))
-    t_det, t_mesh = t.clone(), t.clone()
+    t_det, t_mesh, t_fused = t.clone(), t.clone(), t.clone()       # (t shares the harness's buffer: clone before the in-place reduce)
     sharding.reduce_bus(t, dst=0)
     sharding.reduce_bus_in_rank_order(t_det, dst=0)
     sharding.reduce_bus_mesh(t_mesh, dst=0)
+    # the exchange behind the C-ABI: all-to-all, zlhip_bus_reduce_sum_scan on every rank's pieces, gather of pieces + unit levels
+    sharding.exchange_bus_mesh(syn, t_fused, sc.nblocks, sc.nframes, dst=0)
+    fused_peaks, fused_sumsq = (getattr(syn, "scanned_peaks", None), getattr(syn, "scanned_sumsq", None)) if rank == 0 else (None, None)
+    syn.scanned_peaks = None
     # the double-buffered, overlapped variant bench.py uses at N > 1: three more batches of the same voices
     from libzl_amd.engine import synthetic_clocks
     ov = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((sc.num_buses, 2, 4 * sc.nframes), dtype=torch.float32), dst=0,
@@ -57,7 +61,8 @@ def _worker(rank, world, port, q):
     ov.flush()
     tail = torch.cat([outs[0], outs[1], outs[2]], dim=2) if rank == 0 else None      # buffers 0 and 1 alternate: outs[2] is outs[0]
     if rank == 0:
-        q.put((t.numpy().copy(), outs[1].numpy().copy(), outs[2].numpy().copy(), getattr(syn, "scanned_peaks", None), t_det.numpy().copy(), t_mesh.numpy().copy()))
+        q.put((t.numpy().copy(), outs[1].numpy().copy(), outs[2].numpy().copy(), getattr(syn, "scanned_peaks", None), t_det.numpy().copy(), t_mesh.numpy().copy(),
+               t_fused.numpy().copy(), fused_peaks, fused_sumsq))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,7 +77,7 @@ def test_sharded_voices_reduce_to_the_full_mix(built, world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, tail1, tail2, peaks, got_det, got_mesh = q.get(timeout=180)
+    got, tail1, tail2, peaks, got_det, got_mesh, got_fused, fused_peaks, fused_sumsq = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -84,6 +89,18 @@ def test_sharded_voices_reduce_to_the_full_mix(built, world):
     # gather + sum in rank order: the oracle's grouped order bit for bit, for any number of ranks
     assert np.array_equal(grouped.view(np.int32), got_det.view(np.int32))
     assert np.array_equal(grouped.view(np.int32), got_mesh.view(np.int32))     # all-to-all + rank-order sum + gather
+    # the fused exchange: the same bits, and the levels of every (block, bus, channel) as the oracle defines them
+    assert np.array_equal(grouped.view(np.int32), got_fused.view(np.int32))
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    N0 = sc.nframes
+    rows = grouped.reshape(sc.num_buses, 2, sc.nblocks, N0)
+    assert np.array_equal(fused_peaks, np.abs(np.float32(131072.0) * rows).astype(np.int64).max(axis=3).transpose(2, 0, 1))
+    for k in range(sc.nblocks):
+        for b in range(sc.num_buses):
+            for c in range(2):
+                row = np.ascontiguousarray(rows[b, c, k])
+                assert fused_sumsq[k, b, c] == lib.zlo_block_sumsq(row.ctypes.data, N0, 1), (k, b, c)
     if world == 2:
         assert np.array_equal(grouped.view(np.int32), got.view(np.int32))      # a + b has one order
     else:
@@ -103,3 +120,70 @@ def test_partition_helpers():
     assert [sharding.voice_range(1024, 8, r) for r in (0, 7)] == [(0, 128), (896, 1024)]
     assert sum(b - a for a, b in (sharding.voice_range(1000, 3, r) for r in range(3))) == 1000
     assert [sharding.bus_owner(b, 12, 4) for b in range(12)] == [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3]
+
+
+def _aligned_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every collective entry point is counted: the bus-aligned path must not call any
+    calls = []
+    for name in ("all_reduce", "reduce", "gather", "all_gather", "all_to_all_single", "all_to_all", "broadcast", "reduce_scatter", "scatter", "send", "recv"):
+        if hasattr(dist, name):
+            orig = getattr(dist, name)
+            setattr(dist, name, (lambda *a, _n=name, _o=orig, **k: (calls.append(_n), _o(*a, **k))[1]))
+    from cpu_harness.sim import SimSynth
+    from libzl_amd import sharding
+    from scenario import engine_cmd, run_backend
+    sc = _aligned_scene()
+    part = sharding.BusPartition(sc.num_buses, world, rank)
+    # this rank's engine holds only its buses; commands addressed by global midi channel are routed by the partition
+    mine = []
+    for ev in sc.events[0]:
+        local = part.local_command(engine_cmd(**ev[1]))
+        if local is not None:
+            f = dict(ev[1]); f["midiChannel"] = local.midi_channel
+            mine.append(("cmd", f, ev[2]))
+    sc.events[0] = mine
+    sc.num_buses = part.num_local_buses
+    bus, rep, syn, _ = run_backend(sc, SimSynth, batch=8)         # one batch: block_peaks() covers every block
+    peaks = syn.block_peaks()
+    q.put((rank, part.buses, bus.copy(), peaks.copy(), list(calls)))
+    # (the test's own barrier, outside the data path)
+    calls.clear()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _aligned_scene():
+    from scenario import random_scene
+    return random_scene(777, num_buses=6, voices_per_bus=4, nclips=14, nframes=128, nblocks=8, events=False)
+
+
+def test_bus_aligned_partition_needs_no_collective(built):
+    """num_buses >= world_size: whole buses per rank.  Two ranks render their buses of one 6-bus scene; together they
+    are the oracle's full mix bit for bit, levels included, and the data path made ZERO collective calls."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenario import run_oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_aligned_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc = _aligned_scene()
+    full, _, _ = run_oracle(sc)
+    seen = []
+    for rank, buses, bus, peaks, calls in res:
+        assert calls == [], f"rank {rank} called collectives on the data path: {calls}"
+        seen += buses
+        assert np.array_equal(bus.view(np.int32), full[buses].view(np.int32))
+        exp = np.abs(np.float32(131072.0) * full[buses].reshape(len(buses), 2, sc.nblocks, sc.nframes)).astype(np.int64).max(axis=3).transpose(2, 0, 1)
+        assert np.array_equal(peaks, exp)
+    assert sorted(seen) == list(range(6))

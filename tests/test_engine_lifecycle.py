@@ -142,3 +142,96 @@ def test_device_upload_is_ordered_behind_its_producer(Engine):
     ref, _ = osyn.render_batch(2, 128, clk)
     assert np.array_equal(syn.read_bus().view(np.int32), ref.view(np.int32))
     syn.close()
+
+
+@pytest.mark.parametrize("npieces,nframes,mode", [(2, 128, 0), (8, 256, 0), (3, 64, 2), (11, 512, 0)])
+def test_bus_reduce_sum_scan_kernel(Engine, npieces, nframes, mode):
+    """zlhip_bus_reduce_sum_scan: the rank-order sum of received pieces and the level scan of every unit in one kernel, and
+    zlhip_levels_import_units on the root -- against the defined arithmetic: ((0 + p0) + p1) + ... in fp32, integer peaks,
+    the oracle's sum-of-squares order (tile offset 1 / 0 by mode)."""
+    import torch
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    B, K = 3, 5
+    units = B * 2 * K                                                # one rank holding the whole (reduced) bus: every unit
+    g = torch.Generator(device="cuda"); g.manual_seed(100 + npieces)
+    stride = units * nframes + 192                                   # pieces need not be packed
+    pieces = (torch.rand((npieces, stride), generator=g, device="cuda") * 2 - 1) * 3.0
+    pieces[1, 5 * nframes:6 * nframes] = -0.0                       # a unit of negative zeros in one piece: 0 + (-0) = +0
+    out = torch.full((units * nframes,), 7.0, device="cuda")
+    lv = torch.zeros((units, 2), dtype=torch.int32, device="cuda")
+    syn = Engine(B, 2, max_frames=max(64, nframes), max_batch_blocks=K, max_sounds=2, mode=mode)
+    syn.bus_reduce_sum_scan(pieces.data_ptr(), npieces, stride, units, nframes, out.data_ptr(), lv.data_ptr())
+    syn.levels_import_units(lv.data_ptr(), K, nframes)
+    peaks = syn.block_peaks()                                        # waits for the engine
+    ph = pieces.cpu().numpy()
+    acc = np.zeros(units * nframes, dtype=np.float32)
+    for r in range(npieces):
+        acc = acc + ph[r, :units * nframes]
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.int32), acc.view(np.int32))
+    rows = np.ascontiguousarray(acc.reshape(B, 2, K, nframes))
+    assert np.array_equal(peaks, np.abs(np.float32(131072.0) * rows).astype(np.int64).max(axis=3).transpose(2, 0, 1))
+    lvh = lv.cpu().numpy()
+    off = 0 if (mode & 2) else 1
+    for u in range(units):
+        row = np.ascontiguousarray(acc[u * nframes:(u + 1) * nframes])
+        assert lvh[u, 1:].view(np.float32)[0] == lib.zlo_block_sumsq(row.ctypes.data, nframes, off), u
+    t = syn.levels_tick(block_index=2)
+    for b in range(B):
+        assert t[b].rms_a == lib.zlo_block_rms(np.ascontiguousarray(rows[b, 0, 2]).ctypes.data, nframes, off)
+        assert t[b].rms_b == lib.zlo_block_rms(np.ascontiguousarray(rows[b, 1, 2]).ctypes.data, nframes, off)
+    syn.close()
+
+
+def test_setters_race_free_next_to_the_process_thread(built, tmp_path):
+    """the ClipAudioSource_set* entry points run on the host's UI thread while the JACK thread calls
+    libzl_hotpath_process (reference: setters on the message thread, Helper.h:8-26).  Every entry point that reaches the
+    engine or the clip list takes the bridge's mutex: two threads hammering both sides for 300 cycles must neither crash nor
+    produce a non-finite sample, and the final parameter values must be the last ones written."""
+    import threading
+    from libzl_amd import libzl
+    from libzl_amd.engine import synthetic_clocks
+    zl = libzl.load()
+    zl.initJuce()
+    assert zl.libzl_hotpath_status() == 0
+    rng = np.random.default_rng(9)
+    clips = []
+    for i in range(4):
+        L = rng.uniform(-1, 1, 6000).astype(np.float32); R = rng.uniform(-1, 1, 6000).astype(np.float32)
+        c = zl.ClipAudioSource_newFromBuffer(L.ctypes.data, R.ctypes.data, 6000, 48000.0, f"r{i}".encode())
+        zl.ClipAudioSource_setLength(c, 0.2, 120)
+        zl.ClipAudioSource_playOnChannel(c, True, i)
+        clips.append(c)
+    stop = threading.Event()
+    errors = []
+
+    def ui():
+        k = 0
+        while not stop.is_set():
+            c = clips[k % 4]
+            zl.ClipAudioSource_setPan(c, ((k % 21) - 10) / 10.0)
+            zl.ClipAudioSource_setVolumeAbsolute(c, 0.1 + (k % 9) / 10.0)
+            zl.ClipAudioSource_setStartPosition(c, (k % 5) * 0.001)
+            zl.ClipAudioSource_setADSRRelease(c, 0.01 + (k % 3) * 0.01)
+            zl.ClipAudioSource_setSlices(c, 4 + k % 13)
+            zl.ClipAudioSource_peakGain(c); zl.ClipAudioSource_firstProgress(c); zl.ClipAudioSource_byID(zl.ClipAudioSource_id(c))
+            k += 1
+
+    th = threading.Thread(target=ui)
+    th.start()
+    N = 128
+    outL = np.zeros((12, N), dtype=np.float32); outR = np.zeros((12, N), dtype=np.float32)
+    try:
+        for k in range(300):
+            if zl.libzl_hotpath_process(N, synthetic_clocks(1, N, 48000.0, start_block=k), outL.ctypes.data, outR.ctypes.data) != 0:
+                errors.append(k)
+            if not (np.isfinite(outL).all() and np.isfinite(outR).all()):
+                errors.append(("nan", k))
+    finally:
+        stop.set(); th.join()
+    assert not errors
+    zl.ClipAudioSource_setPan(clips[0], 0.25)
+    for c in clips:
+        zl.ClipAudioSource_destroy(c)
+    zl.shutdownJuce()

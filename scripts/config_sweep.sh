@@ -5,7 +5,7 @@ tag=${1:-r01}
 out=gpurun_out/config_sweep_$tag.jsonl
 mkdir -p gpurun_out
 : > $out
-run() { echo "### $*" >> $out; timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/config_sweep_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/config_sweep_err.log >> $out; return 1; }; }
+run() { echo "### $*" >> $out; timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/config_sweep_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/config_sweep_err.log >> $out; return 1; }; }
 run --voices 64 --buses 8 --frames 256 &&
 run --voices 64 --buses 8 --frames 256 --source-rate 44100 --notes 48,72 &&
 run --voices 96 --buses 12 --frames 256 &&
@@ -13,7 +13,12 @@ run --voices 1024 --buses 8 --frames 128 &&
 run --voices 1024 --buses 8 --notes 48,72 &&
 run --voices 1024 --buses 8 --notes 48,72 --hermite &&
 run --voices 1024 --buses 8 --hermite &&
-run --voices 4096 --buses 32 --fs 96000 --loop-seconds 1 --blocks-per-step 3750
+run --voices 4096 --buses 32 --fs 96000 --loop-seconds 2 --blocks-per-step 3750 &&
+# the HBM-only counterparts (10 s sources: nothing is re-read inside a plan window)
+run --voices 1024 --buses 8 --loop-seconds 10 &&
+run --voices 1024 --buses 8 --notes 48,72 --loop-seconds 10 &&
+run --voices 1024 --buses 8 --notes 48,72 --hermite --loop-seconds 10 &&
+run --voices 1024 --buses 8 --frames 128 --loop-seconds 10
 python3 - <<PY
 import json
 for l in open("$out"):

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-2 evidence run on one MI355X box (gpurun).  Usage: scripts/profile_r2.sh <tag>
+# Produces under gpurun_out/<tag>/: the default bench line (with cpu_baseline), rocprofv3 kernel-trace + stats and PMC passes
+# for the timed (2 s sources) workload and for the no-reuse (10 s sources: HBM only) workload, the config sweep.
+set -o pipefail
+tag=${1:-r2p}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/$tag; rm -rf $O; mkdir -p $O
+B="--no-cpu-baseline --no-reuse-check --no-spot-check --steps 4 --warmup 1"
+python3 bench.py > $O/bench_line.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
+for wl in "reuse:" "noreuse:--loop-seconds 10"; do
+  name=${wl%%:*}; args=${wl#*:}
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${name}_trace -- python3 bench.py $B $args > $O/${name}_trace.log 2>&1 || echo "trace $name failed"
+  rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/${name}_pmc1 -- python3 bench.py $B $args > $O/${name}_pmc1.log 2>&1 || echo "pmc1 $name failed"
+  rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/${name}_pmc2 -- python3 bench.py $B $args > $O/${name}_pmc2.log 2>&1 || echo "pmc2 $name failed"
+  rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O/${name}_pmc3 -- python3 bench.py $B $args > $O/${name}_pmc3.log 2>&1 || echo "pmc3 $name failed"
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/${name}_pmc4 -- python3 bench.py $B $args > $O/${name}_pmc4.log 2>&1 || echo "pmc4 $name failed"
+  rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr --output-format csv -d $O/${name}_pmc5 -- python3 bench.py $B $args > $O/${name}_pmc5.log 2>&1 || echo "pmc5 $name failed"
+  python3 scripts/summarize_prof.py $O/${name}_trace $O/${name}_trace_summary.txt
+  for i in 1 2 3 4 5; do python3 scripts/summarize_prof.py $O/${name}_pmc$i $O/${name}_pmc${i}_summary.txt; done
+  cat $O/${name}_trace_summary.txt $O/${name}_pmc?_summary.txt > $O/${name}_summary.txt
+  rm -rf $O/${name}_trace $O/${name}_pmc?            # raw CSVs are large; the condensed summaries stay
+done
+# pitched Hermite (the kernel furthest below its roofline): counters of the gather path
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $O/herm_pmc -- python3 bench.py $B --hermite --notes 48,72 > $O/herm_pmc.log 2>&1 || echo "herm pmc failed"
+python3 scripts/summarize_prof.py $O/herm_pmc $O/herm_pmc_summary.txt; rm -rf $O/herm_pmc
+scripts/config_sweep.sh ${tag} > $O/config_sweep.txt 2>&1
+echo "cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)  nproc: $(nproc)" > $O/host.txt
+ls -la $O | head -40

@@ -469,6 +469,7 @@ def main():
                     "value": float(V) * KB * N * n2 / (t2.total_ms * 1e-3) if t2.total_ms > 0 else None}
         syn2.close()
 
+    eng_total, eng_arena = syn.memory_bytes()
     total_vs = float(V) * world * KB * N * args.steps
     value = total_vs / dt
     # algorithmic bytes of the K2 launches of one step: every source frame once per block
@@ -532,6 +533,7 @@ def main():
                 "other_ms_per_step": {"planning_not_hidden (K0+K1+K1c of the first window; overlaps the previous step)": float(np.mean(plan_ms)),
                                       "K3 finalize + reports + launch gaps": float(np.mean(fin_ms))},
                 "state_and_levels_bytes_per_step": state_bytes, "slow_blocks": int(slow),
+                "engine_device_bytes": {"total": eng_total, "source_arena": eng_arena, "beyond_sources": eng_total - eng_arena},
                 "note": "achieved / frac are algorithmic bytes over the K2 launch time of the timed (BASELINE) workload, whose 2 s sources are re-read "
                         "every 375 blocks: inside a 2048-block plan window about 80 % of the source reads are re-reads served by the 256 MiB Infinity "
                         "Cache (bus-major launch order keeps one bus's 98 MB of sources hot), so that figure exceeds what HBM alone delivers on this "

@@ -27,7 +27,13 @@
 
 namespace {
 
-template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)); }
+size_t g_alloc_bytes = 0;          // device bytes allocated by the engine being created (zlhip_engine_create is not re-entrant)
+template <typename T> hipError_t dalloc(T **p, size_t n)
+{
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    g_alloc_bytes += bytes;
+    return hipMalloc((void **)p, bytes);
+}
 
 // host memory mapped into the device, grown by doubling (the buffer must be idle)
 template <typename T> hipError_t grow_mapped(T **host, T **dev, size_t *cap, size_t need)
@@ -64,7 +70,10 @@ struct zlhip_engine {
     struct PlanSet {
         ZlVoiceConst *vconst = nullptr; ZlRunList *runs = nullptr; ZlTSeg *tsegs = nullptr;
         ZlPlanHdr *hdr = nullptr; ZlPlanSeg0 *seg0 = nullptr; ZlPlanSeg1 *seg1 = nullptr;
-        double *ctlP = nullptr; float *ctlEnv = nullptr;
+        double *ctlP = nullptr; float *ctlEnv = nullptr;  // the window's pool of per-frame control slots (zl_plan.h, zl_ctl_alloc)
+        unsigned long long *ctlNext = nullptr;            // its bump counter, never reset: a window's slots count from ctlBase
+        unsigned long long ctlBase = 0;                   // host side: past every value the counter can have reached
+        ZlSimConst *simConst = nullptr;
         float *partials = nullptr;
         hipEvent_t planned = nullptr, rendered = nullptr, k1done = nullptr;
         hipEvent_t renderedEv = nullptr; // the event that marks the end of the last rendering from this set (rendered, or a profiling event)
@@ -73,6 +82,8 @@ struct zlhip_engine {
     int windowBlocks = 0;                // plan_window_blocks when given (a fixed number of blocks per plan window)
     size_t windowFrames = 0;             // else a window is this many frames: 2048 blocks of 256 frames, more blocks when they are shorter
     int windowCap = 0;                   // blocks the K1 -> K2 record arrays hold
+    size_t ctlPoolFrames = 0;            // frames of per-frame control a record set's pool holds (slots = this / nframes)
+    int ctlSlotsOverride = -1;           // ZL_CTL_POOL_SLOTS (tests of the exhausted pool)
     hipStream_t planStream = nullptr;    // K0 + K1 (sequential per voice)
     hipStream_t lastPlanStream = nullptr; hipEvent_t evPlanTail = nullptr;   // where the previous call planned (voice-state order)
     hipEvent_t lastPlanEvent = nullptr;  // marks the end of that planning: evPlanTail, or the call's `done` event when it planned on its render stream
@@ -118,6 +129,7 @@ struct zlhip_engine {
     int lastK = 0, lastN = 0, lastWindows = 0; float *lastBus = nullptr; bool outstanding = false; bool reportsFresh = false;
     bool trace = false; int traceK = 0, traceN = 0;
     int forceSlow = 0;
+    size_t deviceBytes = 0;              // HBM the engine allocated at creation (arena included)
     int staged = 0;                      // K2 variant with LDS-staged source windows (zl_kernels.hip), chosen per mode at creation
 
     // profiling
@@ -211,7 +223,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dTrace, e->dPass, e->dPassCache };
     for (void *p : dev) if (p) (void)hipFree(p);
     for (auto &q : e->ps) {
-        void *pd[] = { q.vconst, q.runs, q.tsegs, q.hdr, q.seg0, q.seg1, q.ctlP, q.ctlEnv, q.partials };
+        void *pd[] = { q.vconst, q.runs, q.tsegs, q.hdr, q.seg0, q.seg1, q.ctlP, q.ctlEnv, q.partials, q.ctlNext, q.simConst };
         for (void *p : pd) if (p) (void)hipFree(p);
         if (q.planned) (void)hipEventDestroy(q.planned);
         if (q.rendered) (void)hipEventDestroy(q.rendered);
@@ -250,6 +262,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     if (hipSetDevice(cfg->device) != hipSuccess) return ZLHIP_ERR_NO_DEVICE;
 
     zlhip_engine *e = new zlhip_engine();
+    g_alloc_bytes = 0;
     e->cfg = *cfg;
     e->device = cfg->device;
     e->V = cfg->num_buses * cfg->voices_per_bus;
@@ -309,8 +322,22 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             chk(dalloc(&q.hdr, W * V), "plan headers");
             chk(dalloc(&q.seg0, W * V), "plan segment 0");
             chk(dalloc(&q.seg1, W * V), "plan segment 1");
-            chk(dalloc(&q.ctlP, ctlFrames * V), "ctlP");
-            chk(dalloc(&q.ctlEnv, ctlFrames * V), "ctlEnv");
+            // per-frame control of the window's slow (block, voice)s: a pool of block-sized slots.  One slot for every (block, voice)
+            // of a window would be 12 bytes per voice-frame (6.4 GB per set for 1024 voices); slow blocks are sparse (release tails of
+            // one-shots, the block behind a loop restart), so the pool is capped -- ZL_CTL_POOL_MB per set, default 256 -- and a
+            // window that exhausts it has K2 recompute the control of the blocks that got no slot (zl_slow_control)
+            {
+                const char *mb = std::getenv("ZL_CTL_POOL_MB");
+                const size_t capFrames = (size_t)(mb ? std::max(1, std::atoi(mb)) : 256) * ((size_t)1 << 20) / 12;
+                e->ctlPoolFrames = std::max<size_t>(N, std::min(ctlFrames * V, capFrames));
+                const char *so = std::getenv("ZL_CTL_POOL_SLOTS");
+                if (so) e->ctlSlotsOverride = std::max(0, std::atoi(so));
+            }
+            chk(dalloc(&q.ctlP, e->ctlPoolFrames), "ctlP");
+            chk(dalloc(&q.ctlEnv, e->ctlPoolFrames), "ctlEnv");
+            chk(dalloc(&q.ctlNext, 1), "ctlNext");
+            chk(dalloc(&q.simConst, V), "simConst");
+            if (rc == ZLHIP_OK) chk(hipMemsetAsync(q.ctlNext, 0, sizeof(unsigned long long), e->stream), "memset ctlNext");
             {
                 // mix-group partials of a window; or, for the per-voice split of single real-time blocks, of one block
                 size_t pf = e->maxGroups > 1 ? ctlFrames * B * (size_t)e->maxGroups * 2 : 1;
@@ -381,6 +408,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
     e->arenaFree.assign(1, { (size_t)0, e->arenaFloats & ~(size_t)3 });
     for (auto &c : e->slots) { std::memset(c.hReports, 0, V * sizeof(ZlReport)); std::memset(c.hStats, 0, sizeof(ZlBatchStats)); }
     e->latest = &e->slots[0];
+    e->deviceBytes = g_alloc_bytes;
     *out = e;
     return ZLHIP_OK;
 }
@@ -781,6 +809,11 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         Aw.pos_trace = traceBase ? traceBase + (size_t)Aw.k0 * e->V * nframes : nullptr;
         Aw.vconst = q.vconst; Aw.runs = q.runs; Aw.tsegs = q.tsegs; Aw.plan_hdr = q.hdr; Aw.plan_seg0 = q.seg0; Aw.plan_seg1 = q.seg1;
         Aw.ctl_P = q.ctlP; Aw.ctl_env = q.ctlEnv; Aw.partials = q.partials;
+        Aw.ctl_next = q.ctlNext; Aw.sim_const = q.simConst;
+        Aw.ctl_slots = e->ctlSlotsOverride >= 0 ? std::min<int>(e->ctlSlotsOverride, (int)(e->ctlPoolFrames / (size_t)nframes)) : (int)std::min<size_t>(e->ctlPoolFrames / (size_t)nframes, 0x7fffffff);
+        // every (block, voice) of a window asks for at most one slot: the next window of this set counts from past that
+        Aw.ctl_base = q.ctlBase;
+        q.ctlBase += (unsigned long long)Aw.K * (unsigned long long)e->V + 1ull;
         if (w > 0) { Aw.n_op_ranges = 0; Aw.ops = nullptr; Aw.op_ranges = nullptr; }     // commands apply before the first block only
         // planning may not overwrite a record set while an earlier window (of this or the previous call) still renders from it
         if (ps != s && q.used) ZL_HIP(e, hipStreamWaitEvent(ps, q.renderedEv, 0));
@@ -1085,5 +1118,13 @@ int zlhip_profile_totals(zlhip_engine *e, zlhip_timings *totals, int32_t *calls,
 }
 
 float *zlhip_bus_device_ptr(zlhip_engine *e) { return e ? e->dBus : nullptr; }
+
+int zlhip_memory_bytes(zlhip_engine *e, uint64_t *total_device_bytes, uint64_t *arena_bytes)
+{
+    if (!e) return ZLHIP_ERR_INVALID;
+    if (total_device_bytes) *total_device_bytes = (uint64_t)e->deviceBytes;
+    if (arena_bytes) *arena_bytes = (uint64_t)e->arenaFloats * sizeof(float);
+    return ZLHIP_OK;
+}
 
 }  // extern "C"

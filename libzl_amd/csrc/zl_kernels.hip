@@ -44,9 +44,14 @@ static __device__ __forceinline__ void zl_k1c_block(const ZlBatch &A, ZlAssemble
         const int l = __builtin_ctzll(m);
         m &= m - 1;
         const int vv = __shfl(v, l, 64), ii = __shfl(idx0, l, 64), bb = __shfl(base0, l, 64), na = __shfl(n_active, l, 64);
+        // a slot of the window's control pool for this (block, voice); none left: the block is marked and K2 recomputes it
+        int slot = 0;
+        if (lane == 0) slot = zl_expand_slot(A, (size_t)k * A.V + vv, ii, bb);
+        slot = __shfl(slot, 0, 64);
+        if (slot < 0) continue;
         ZlSegStream ss;
         ss.init(A, vv, A.runs[vv]);
-        const size_t base = ((size_t)k * A.V + vv) * (size_t)A.N;
+        const size_t base = (size_t)slot * (size_t)A.N;
         for (int f = lane; f < A.N; f += 64) {
             float env;
             A.ctl_P[base + f] = zl_expand_frame(ss, A.N, k, ii, bb, f < na ? f : 0, env);
@@ -210,29 +215,29 @@ struct ZlK2Tap { ZlTaps t; float alpha, env; int flags; };   // flags: 1 act, 2 
 typedef float zl_f2 __attribute__((ext_vector_type(2)));
 
 // unit-step blocks (playback at the source rate inside an exact run): integer part of P0 and the constant fraction
-struct ZlUnit { int ipos; float alpha; };
+// + the gain products (gain * envelope) * volume of the Hermite mode's whole-sample gain (zl_render.h), one number per voice-block in sustain
+struct ZlUnit { int ipos; float alpha; float gpl, gpr; };
 
-// zl_hermite4 (zl_render.h) on both channels at once: v_pk_fma_f32, one rounding per fused operation
+// zl_hermite_weights / zl_hermite4 (zl_render.h) with both channels in one register pair: the weights are scalar work shared by
+// the channels, the four multiply-adds are v_pk_fma_f32 (one rounding per fused operation, as fmaf)
 static __device__ __forceinline__ zl_f2 zl_fma2(zl_f2 a, zl_f2 b, zl_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 static __device__ __forceinline__ zl_f2 zl_hermite4_pk(zl_f2 y0, zl_f2 y1, zl_f2 y2, zl_f2 y3, float a)
 {
-    const zl_f2 aa = {a, a};
-    const zl_f2 c1 = 0.5f * (y2 - y0);
-    const zl_f2 c2 = zl_fma2((zl_f2){-0.5f, -0.5f}, y3, zl_fma2((zl_f2){2.0f, 2.0f}, y2, zl_fma2((zl_f2){-2.5f, -2.5f}, y1, y0)));
-    const zl_f2 c3 = zl_fma2((zl_f2){1.5f, 1.5f}, y1 - y2, 0.5f * (y3 - y0));
-    return zl_fma2(aa, zl_fma2(aa, zl_fma2(aa, c3, c2), c1), y1);
+    const ZlHermiteW w = zl_hermite_weights(a);
+    return zl_fma2((zl_f2){w.w3, w.w3}, y3, zl_fma2((zl_f2){w.w2, w.w2}, y2, zl_fma2((zl_f2){w.w1, w.w1}, y1, (zl_f2){w.w0, w.w0} * y0)));
 }
 
+// gprod (Hermite mode only): (gain * envelope) * volume of both channels, formed by the caller (per voice-block in sustain)
 template <uint32_t MODE>
 static __device__ __forceinline__ zl_f2 zl_mix_frame_pk(zl_f2 xm, zl_f2 x0, zl_f2 x1, zl_f2 x2, float alpha, bool inb, bool wide,
-                                                         zl_f2 gain, float env, float vol, zl_f2 pan)
+                                                         zl_f2 gain, float env, float vol, zl_f2 pan, zl_f2 gprod = (zl_f2){0.0f, 0.0f})
 {
     const float invAlpha = 1.0f - alpha;                         // :200
     zl_f2 lr;
     if (MODE & ZL_MODE_HERMITE) {
         const zl_f2 h = zl_hermite4_pk(xm, x0, x1, x2, alpha);
         const zl_f2 lin = x0 * invAlpha + x1 * alpha;
-        lr = (wide ? h : lin) * gain * env * vol;
+        lr = (wide ? h : lin) * gprod;                              // whole-sample gain, the product formed first (zl_render.h)
     } else if (MODE & ZL_MODE_FIX_GAIN) {
         lr = (x0 * invAlpha + x1 * alpha) * gain * env * vol;
     } else {
@@ -317,7 +322,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
             const zl_f2 o = zl_mix_frame_pk<MODE>((zl_f2){d[u].x, d[u].y}, (zl_f2){d[u].z, d[u].w}, (zl_f2){e[HERM ? u : 0].x, e[HERM ? u : 0].y},
                                                   (zl_f2){e[HERM ? u : 0].z, e[HERM ? u : 0].w}, alpha[u], true, true,
                                                   (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
-                                                  (zl_f2){s_vc[i].lpan, s_vc[i].rpan});
+                                                  (zl_f2){s_vc[i].lpan, s_vc[i].rpan}, (zl_f2){s_unit[i].gpl, s_unit[i].gpr});
             acc += o;
             if (wantPeak) {
                 const float ng = o.x + o.y;
@@ -347,7 +352,7 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
             }
             const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, alpha[u], true, wide,
                                                   (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
-                                                  (zl_f2){s_vc[i].lpan, s_vc[i].rpan});
+                                                  (zl_f2){s_vc[i].lpan, s_vc[i].rpan}, (zl_f2){s_unit[i].gpl, s_unit[i].gpr});
             acc += o;                                             // :218-221 (index shift applied at the store)
             l = o.x; r = o.y;
         } else {
@@ -501,7 +506,7 @@ struct ZlStParams {
     double P0, step;
     int    a;                 // first source frame of this wave's window
     float  env, vol;
-    zl_f2  gain, pan;         // (l, r) pairs
+    zl_f2  gain, pan, gprod;  // (l, r) pairs
 };
 static __device__ __forceinline__ ZlStParams zl_st_params(const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlWin *s_win, int i)
 {
@@ -509,6 +514,7 @@ static __device__ __forceinline__ ZlStParams zl_st_params(const ZlBlockPlan *s_p
     q.P0 = s_plan[i].P0; q.step = s_plan[i].step; q.env = s_plan[i].env;
     q.a = s_win[i * 4].a;
     q.gain = (zl_f2){s_vc[i].lgain, s_vc[i].rgain}; q.vol = s_vc[i].clip_volume; q.pan = (zl_f2){s_vc[i].lpan, s_vc[i].rpan};
+    q.gprod = (q.gain * q.env) * q.vol;                           // Hermite mode's whole-sample gain (zl_render.h)
     return q;
 }
 // The DMA of voice j of the pass, as per-lane values (no scalar round trip): lane address and bytes of the window.  Voices
@@ -552,7 +558,7 @@ static __device__ __forceinline__ void zl_st_mix(const ZlBatch &A, const ZlStPar
 {
     float l, r;
     if (MODE & ZL_MODE_HERMITE) {
-        const zl_f2 o = zl_mix_frame_pk<MODE>(t.xm, t.x0, t.x1, t.x2, t.alpha, true, true, q.gain, q.env, q.vol, q.pan);
+        const zl_f2 o = zl_mix_frame_pk<MODE>(t.xm, t.x0, t.x1, t.x2, t.alpha, true, true, q.gain, q.env, q.vol, q.pan, q.gprod);
         acc += o;
         l = o.x; r = o.y;
     } else {
@@ -585,9 +591,14 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
             const int i = c0 + u;
             const bool ctl = s_cls[i] & 2;
             const bool act = (s_cls[i] & 1) && f < s_plan[i].n_active;
-            const size_t off = ctl ? (pbase + i) * (size_t)N + (act ? f : 0) : 0;    // regular voices: word 0 (always valid)
-            Pc[u] = A.ctl_P[off];
-            Ec[u] = A.ctl_env[off];
+            if (__builtin_expect(ctl && (s_plan[i].flags & (ZL_PLAN_NOSLOT_SIM | ZL_PLAN_NOSLOT_EXPAND)), 0)) {
+                // the window's control pool was exhausted when this block was planned: recompute its control (zl_plan.h)
+                zl_slow_control(A, s_plan[i], vfirst + i, (int)(pbase / (size_t)A.V), act ? f : 0, Pc[u], Ec[u]);
+            } else {
+                const size_t off = ctl ? (size_t)(int)s_plan[i].step * (size_t)N + (act ? f : 0) : 0;   // the block's slot; regular voices: word 0 (always valid)
+                Pc[u] = A.ctl_P[off];
+                Ec[u] = A.ctl_env[off];
+            }
         }
     }
 #pragma unroll
@@ -838,7 +849,8 @@ __global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_M
                 const unsigned long long fm = __ballot(fits);      // the wave's 64 voices are one block's voices [64 m, 64 m + 64)
                 if ((i & 63) == 0) s_stmask_[b * (CH / 64) + (i >> 6)] = fm;
             }
-            { ZlUnit un; un.ipos = (int)pl.P0; un.alpha = (float)(pl.P0 - (double)un.ipos); s_unit_[b][i] = un; }
+            { ZlUnit un; un.ipos = (int)pl.P0; un.alpha = (float)(pl.P0 - (double)un.ipos);
+              un.gpl = (vc.lgain * pl.env) * vc.clip_volume; un.gpr = (vc.rgain * pl.env) * vc.clip_volume; s_unit_[b][i] = un; }
             if (b == 0) s_vc[i] = vc;
             s_plan_[b][i] = pl;                   // idle slots: a harmless record with no active frame
             s_cls_[b][i] = cls;

@@ -286,38 +286,90 @@ ZL_HD inline void zl_loop_restart(ZlVoiceState &st, const ZlVoiceBatchConst &c, 
     st.P = (double)c.start_int;                                  // :241 / :246
 }
 
-// Per-frame simulation of one block (the reference loop minus the audio arithmetic).  Records
-// (P, env) of every rendered frame; returns the number of frames rendered.
+// One frame of the reference loop minus the audio arithmetic (:223-261): advances the position and the loop / stop logic
+// after frame `frame` was rendered.  Returns false when the voice stopped with that frame.
+ZL_HD inline bool zl_sim_step(ZlVoiceState &st, const ZlVoiceBatchConst &c, const ZlClock &ck, double upf, int frame)
+{
+    st.P += st.pitch_ratio;                                      // :223
+    if (st.looping) {
+        if (c.beat_locked) {
+            if (ck.current_usecs + zl_f64_to_u64_sat((double)(uint32_t)frame * upf) >= st.next_loop_usecs)   // :232
+                zl_loop_restart(st, c, ck, true);
+        } else if (st.P >= (double)c.stop_pos) {                 // :243
+            zl_loop_restart(st, c, ck, false);
+        }
+    } else {
+        if (st.P >= (double)c.stop_pos) {                        // :249-252
+            zl_voice_hard_stop(st);
+            return false;
+        } else if (st.P >= c.tail_T) {                           // :253-256 (Q7: every frame)
+            zl_adsr_note_off(st);
+        }
+    }
+    if (st.adsr_state == ZL_ADSR_IDLE) {                         // :258-261
+        zl_voice_hard_stop(st);
+        return false;
+    }
+    return true;
+}
+
+// Per-frame simulation of one block.  Records (P, env) of every rendered frame (ctlP == nullptr: only advances the voice);
+// returns the number of frames rendered.
 ZL_HD inline int zl_sim_block(ZlVoiceState &st, const ZlVoiceBatchConst &c, const ZlClock &ck, int N,
                               double *ctlP, float *ctlEnv)
 {
     const double upf = (double)ck.usecs_per_frame;               // :183
-    int frame = 0;
-    for (; frame < N; ++frame) {
-        ctlP[frame] = st.P;
-        ctlEnv[frame] = zl_adsr_next(st);                        // :201
-        st.P += st.pitch_ratio;                                  // :223
-        if (st.looping) {
-            if (c.beat_locked) {
-                if (ck.current_usecs + zl_f64_to_u64_sat((double)(uint32_t)frame * upf) >= st.next_loop_usecs)   // :232
-                    zl_loop_restart(st, c, ck, true);
-            } else if (st.P >= (double)c.stop_pos) {             // :243
-                zl_loop_restart(st, c, ck, false);
-            }
-        } else {
-            if (st.P >= (double)c.stop_pos) {                    // :249-252
-                zl_voice_hard_stop(st);
-                return frame + 1;
-            } else if (st.P >= c.tail_T) {                       // :253-256 (Q7: every frame)
-                zl_adsr_note_off(st);
-            }
-        }
-        if (st.adsr_state == ZL_ADSR_IDLE) {                     // :258-261
-            zl_voice_hard_stop(st);
-            return frame + 1;
-        }
+    for (int frame = 0; frame < N; ++frame) {
+        const double P = st.P;
+        const float env = zl_adsr_next(st);                      // :201
+        if (ctlP) { ctlP[frame] = P; ctlEnv[frame] = env; }
+        if (!zl_sim_step(st, c, ck, upf, frame)) return frame + 1;
     }
     return N;
+}
+
+// ---- the window's pool of per-frame control slots ------------------------------------------------------------------------
+// One slot = the (P, env) of the N frames of one slow (block, voice).  K1 (simulated blocks) and K1c (multi-segment blocks)
+// take slots with a bump counter that is never reset: a window's slots count from A.ctl_base, which the host raises past every
+// value the counter can have reached (zl_engine.cpp).  -1: the pool is exhausted -- the block then carries a snapshot and K2
+// recomputes its control (zl_slow_control).
+ZL_HD inline int zl_ctl_alloc(const ZlBatch &A)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(A.ctl_next, A.ctl_base);
+    const unsigned long long old = atomicAdd(A.ctl_next, 1ull);
+#else
+    if (*A.ctl_next < A.ctl_base) *A.ctl_next = A.ctl_base;
+    const unsigned long long old = (*A.ctl_next)++;
+#endif
+    const unsigned long long sl = old - A.ctl_base;
+    return sl < (unsigned long long)(A.ctl_slots > 0 ? A.ctl_slots : 0) ? (int)sl : -1;
+}
+
+// The voice state at the start of a simulated block, packed into the block's plan record (seg0 + seg1 = 48 bytes): everything
+// of ZlVoiceState that moves inside a window.
+ZL_HD inline void zl_snapshot_store(ZlBlockPlan &pl, const ZlVoiceState &st)
+{
+    pl.P0 = st.P;
+    pl.step = zl_from_bits(st.next_loop_tick);
+    pl.P1 = zl_from_bits(st.next_loop_usecs);
+    pl.step1 = zl_from_bits((uint64_t)__builtin_bit_cast(uint32_t, st.env) | ((uint64_t)__builtin_bit_cast(uint32_t, st.release_rate) << 32));
+    pl.n1 = st.adsr_state;
+}
+ZL_HD inline void zl_snapshot_load(const ZlBlockPlan &pl, const ZlSimConst &sc, ZlVoiceState &st, ZlVoiceBatchConst &c)
+{
+    st.P = pl.P0;
+    st.next_loop_tick = zl_bits(pl.step);
+    st.next_loop_usecs = zl_bits(pl.P1);
+    const uint64_t er = zl_bits(pl.step1);
+    st.env = __builtin_bit_cast(float, (uint32_t)er);
+    st.release_rate = __builtin_bit_cast(float, (uint32_t)(er >> 32));
+    st.adsr_state = pl.n1;
+    st.pitch_ratio = sc.pitch_ratio; st.adsr_sr = sc.adsr_sr; st.src_len = 0.0;
+    st.attack_rate = sc.attack_rate; st.decay_rate = sc.decay_rate; st.sustain = sc.sustain; st.release = sc.release;
+    st.lgain = 0.0f; st.rgain = 0.0f; st.clip = 0; st.slice = 0; st.looping = sc.looping; st.playing = 1; st.loop_phase1 = 0;
+    c.start_int = sc.start_int; c.stop_pos = sc.stop_pos; c.tail_T = sc.tail_T; c.length_ticks = sc.length_ticks;
+    c.beat_locked = sc.beat_locked; c.clock_ok = 1;
 }
 
 struct ZlPlanStats { unsigned long long source_bytes, slow_blocks, active_frames; };
@@ -334,7 +386,7 @@ ZL_HD inline void zl_plan_store(const ZlBatch &A, size_t pidx, const ZlBlockPlan
     A.plan_hdr[pidx] = h;
     ZlPlanSeg0 s0; s0.P0 = pl.P0; s0.step = pl.step;
     A.plan_seg0[pidx] = s0;
-    if (pl.nseg >= 2 || (pl.flags & ZL_PLAN_ENV)) {
+    if (pl.nseg >= 2 || (pl.flags & (ZL_PLAN_ENV | ZL_PLAN_NOSLOT_SIM))) {
         ZlPlanSeg1 s1; s1.P1 = pl.P1; s1.step1 = pl.step1; s1.n1 = pl.n1; s1.estep0 = pl.estep0; s1.E1 = pl.E1; s1.estep1 = pl.estep1;
         A.plan_seg1[pidx] = s1;
     }
@@ -349,7 +401,7 @@ ZL_HD inline ZlBlockPlan zl_plan_load(const ZlBatch &A, size_t pidx)
     const ZlPlanSeg0 s0 = A.plan_seg0[pidx];
     pl.flags = h.flags; pl.n_active = h.n_active; pl.nseg = h.nseg; pl.env = h.env;
     pl.P0 = s0.P0; pl.step = s0.step;
-    if ((h.nseg >= 2 || (h.flags & ZL_PLAN_ENV)) && !(h.flags & ZL_PLAN_SLOW)) {
+    if (((h.nseg >= 2 || (h.flags & ZL_PLAN_ENV)) && !(h.flags & ZL_PLAN_SLOW)) || (h.flags & (ZL_PLAN_NOSLOT_SIM | ZL_PLAN_NOSLOT_EXPAND))) {
         const ZlPlanSeg1 s1 = A.plan_seg1[pidx];
         pl.P1 = s1.P1; pl.step1 = s1.step1; pl.n1 = s1.n1; pl.estep0 = s1.estep0; pl.E1 = s1.E1; pl.estep1 = s1.estep1;
     }
@@ -437,6 +489,13 @@ struct ZlPlanner {
         c.beat_locked = truncf(cl.length_beats) == cl.length_beats;
         c.clock_ok = 1;
 
+        if (A.sim_const) {
+            ZlSimConst sc;
+            sc.pitch_ratio = st.pitch_ratio; sc.adsr_sr = st.adsr_sr; sc.tail_T = c.tail_T; sc.length_ticks = c.length_ticks;
+            sc.attack_rate = st.attack_rate; sc.decay_rate = st.decay_rate; sc.sustain = st.sustain; sc.release = st.release;
+            sc.start_int = c.start_int; sc.stop_pos = c.stop_pos; sc.beat_locked = c.beat_locked; sc.looping = st.looping;
+            A.sim_const[v] = sc;
+        }
         ZlVoiceConst vc;
         vc.src_offset = sd.offset;
         vc.sample_duration = sd.length - 1;                       // :191
@@ -545,7 +604,15 @@ struct ZlPlanner {
                 ZlBlockPlan pl;
                 zl_plan_clear(pl);
                 pl.flags = ZL_PLAN_ACTIVE | ZL_PLAN_SLOW; pl.env = st.sustain; pl.P0 = st.P;
-                pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N);
+                const int slot = zl_ctl_alloc(A);
+                if (slot >= 0) {
+                    pl.step = (double)slot;                         // where K2 finds the block's control
+                    pl.n_active = zl_sim_block(st, c, ck, N, A.ctl_P + (size_t)slot * (size_t)N, A.ctl_env + (size_t)slot * (size_t)N);
+                } else {
+                    pl.flags |= ZL_PLAN_NOSLOT_SIM;                 // pool exhausted: K2 re-simulates from this state
+                    zl_snapshot_store(pl, st);
+                    pl.n_active = zl_sim_block(st, c, ck, N, nullptr, nullptr);
+                }
                 haveRun = false; haveERun = false; endAfter = false;
                 zl_plan_store(A, pidx, pl);
                 stats.slow_blocks += 1;
@@ -941,6 +1008,45 @@ ZL_HD inline double zl_expand_frame(const ZlSegStream &ss, int N, int k, int idx
     const ZlTSeg a = ss.ts[idx];
     env = (float)fma((double)(T - (a.t + base)), (double)a.estep, (double)a.E);                    // exact
     return fma((double)(T - (a.t + base)), a.step, a.P);          // exact
+}
+
+// Position and envelope of frame f (< n_active) of a SLOW block of voice v, block k of the window: from the block's slot of the
+// control pool or, when the pool was exhausted, recomputed -- a multi-segment block straight from the segment stream, a
+// simulated block by running the reference's per-frame recurrence again from the state at the block's start (O(f) steps per
+// lane: the price of an exhausted pool, never of a normal run).
+ZL_HD inline void zl_slow_control(const ZlBatch &A, const ZlBlockPlan &pl, int v, int k, int f, double &P, float &env)
+{
+    if (!(pl.flags & (ZL_PLAN_NOSLOT_SIM | ZL_PLAN_NOSLOT_EXPAND))) {
+        const size_t o = (size_t)(int)pl.step * (size_t)A.N + (size_t)f;
+        P = A.ctl_P[o]; env = A.ctl_env[o];
+        return;
+    }
+    if (pl.flags & ZL_PLAN_NOSLOT_EXPAND) {
+        ZlSegStream ss;
+        ss.init(A, v, A.runs[v]);
+        P = zl_expand_frame(ss, A.N, k, pl.n1, (int)(uint32_t)zl_bits(pl.P1), f, env);
+        return;
+    }
+    ZlVoiceState st; ZlVoiceBatchConst c;
+    zl_snapshot_load(pl, A.sim_const[v], st, c);
+    const ZlClock ck = A.inline_clock ? A.clock0 : A.clocks[k];
+    const double upf = (double)ck.usecs_per_frame;
+    for (int frame = 0;; ++frame) {
+        P = st.P; env = zl_adsr_next(st);
+        if (frame >= f || !zl_sim_step(st, c, ck, upf, frame)) return;
+    }
+}
+
+// A multi-segment block (K1c): takes a slot for its per-frame control or, when the pool is exhausted, marks the block for
+// recomputation in K2.  Returns the slot (>= 0) the caller fills with zl_expand_frame, or -1.
+ZL_HD inline int zl_expand_slot(const ZlBatch &A, size_t pidx, int idx0, int base0)
+{
+    const int slot = zl_ctl_alloc(A);
+    if (slot >= 0) { A.plan_seg0[pidx].step = (double)slot; return slot; }
+    A.plan_hdr[pidx].flags |= ZL_PLAN_NOSLOT_EXPAND;
+    ZlPlanSeg1 s1; s1.P1 = zl_from_bits((uint64_t)(uint32_t)base0); s1.step1 = 0.0; s1.n1 = idx0; s1.estep0 = 0.0f; s1.E1 = 0.0f; s1.estep1 = 0.0f;
+    A.plan_seg1[pidx] = s1;
+    return -1;
 }
 
 // Whole window of one voice with the clocks read from A.clocks (host harness; the kernel stages them in LDS).

@@ -9,31 +9,36 @@
 #include "zl_types.h"
 #include <math.h>
 
-// Position and envelope of frame f of a planned block (after K1c: at most two inline segments, or
-// per-frame control).
-ZL_HD inline void zl_eval_control(const ZlBlockPlan &pl, const double *ctlP, const float *ctlEnv, int f, double &P, float &env)
+// Position and envelope of frame f of a planned FAST block (at most two inline segments; blocks with per-frame control: zl_plan.h,
+// zl_slow_control).
+ZL_HD inline void zl_eval_control(const ZlBlockPlan &pl, int f, double &P, float &env)
 {
-    if (pl.flags & ZL_PLAN_SLOW) {
-        P = ctlP[f];
-        env = ctlEnv[f];
-        return;
-    }
     const bool seg1 = f >= pl.n1;
     const int n0 = seg1 ? pl.n1 : 0;
     P = fma((double)(f - n0), seg1 ? pl.step1 : pl.step, seg1 ? pl.P1 : pl.P0);                     // exact (see zl_plan.h)
     env = (float)fma((double)(f - n0), (double)(seg1 ? pl.estep1 : pl.estep0), (double)(seg1 ? pl.E1 : pl.env));   // exact fp32 ramp
 }
 
-// 4-point Catmull-Rom (build-defined extension, absent in the reference): the cubic
-//   y1 + a (c1 + a (c2 + a c3)),  c1 = (y2 - y0) / 2,  c2 = y0 - 5/2 y1 + 2 y2 - y3 / 2,  c3 = (y3 - y0) / 2 + 3/2 (y1 - y2)
-// evaluated with fused multiply-adds in exactly this order (12 operations per channel; every fmaf below is ONE
-// rounding -- the oracle and the numpy restatement do the same).
-ZL_HD inline float zl_hermite4(float y0, float y1, float y2, float y3, float a)
+// 4-point Catmull-Rom (build-defined extension, absent in the reference) in TAP-WEIGHT form: the four cubic
+// weights of the fractional position a,
+//   w0 = ((-a/2 + 1) a - 1/2) a    w1 = (3/2 a - 5/2) a^2 + 1    w2 = ((-3/2 a + 2) a + 1/2) a    w3 = (a/2 - 1/2) a^2,
+// are computed once per frame and shared by both channels; y = w0 y0 + w1 y1 + w2 y2 + w3 y3.  Fused multiply-adds in
+// exactly this order (11 operations for the weights + 4 per channel; every fmaf is ONE rounding -- the oracle and the numpy
+// restatement do the same).  The Horner form of round 1 cost 12 per channel: the kernel is bound by VALU issue in this mode.
+struct ZlHermiteW { float w0, w1, w2, w3; };
+ZL_HD inline ZlHermiteW zl_hermite_weights(float a)
 {
-    const float c1 = 0.5f * (y2 - y0);
-    const float c2 = fmaf(-0.5f, y3, fmaf(2.0f, y2, fmaf(-2.5f, y1, y0)));
-    const float c3 = fmaf(1.5f, y1 - y2, 0.5f * (y3 - y0));
-    return fmaf(a, fmaf(a, fmaf(a, c3, c2), c1), y1);
+    ZlHermiteW w;
+    const float t = a * a;
+    w.w0 = fmaf(fmaf(-0.5f, a, 1.0f), a, -0.5f) * a;
+    w.w1 = fmaf(fmaf(1.5f, a, -2.5f), t, 1.0f);
+    w.w2 = fmaf(fmaf(-1.5f, a, 2.0f), a, 0.5f) * a;
+    w.w3 = fmaf(0.5f, a, -0.5f) * t;
+    return w;
+}
+ZL_HD inline float zl_hermite4(float y0, float y1, float y2, float y3, const ZlHermiteW &w)
+{
+    return fmaf(w.w3, y3, fmaf(w.w2, y2, fmaf(w.w1, y1, w.w0 * y0)));
 }
 
 // The gathered samples of one frame: taps pos, pos+1 (and pos-1, pos+2 for Hermite) of both channels.
@@ -59,11 +64,13 @@ ZL_HD inline void zl_mix_frame(const ZlTaps &t, float alpha, bool inb, bool wide
     const float invAlpha = 1.0f - alpha;                         // :200
     float l, r;
     if (MODE & ZL_MODE_HERMITE) {
-        // build-defined extension: Catmull-Rom with whole-sample gain, linear at the source edges
-        const float sl = wide ? zl_hermite4(t.xml, t.x0l, t.x1l, t.x2l, alpha) : (t.x0l * invAlpha + t.x1l * alpha);
-        const float sr = wide ? zl_hermite4(t.xmr, t.x0r, t.x1r, t.x2r, alpha) : (t.x0r * invAlpha + t.x1r * alpha);
-        l = sl * lgain * env * vol;
-        r = sr * rgain * env * vol;
+        // build-defined extension: Catmull-Rom, linear at the source edges; whole-sample gain with the gain product formed first,
+        // sample * ((gain * envelope) * volume) -- for a voice in sustain the product is one number per block
+        const ZlHermiteW w = zl_hermite_weights(alpha);
+        const float sl = wide ? zl_hermite4(t.xml, t.x0l, t.x1l, t.x2l, w) : (t.x0l * invAlpha + t.x1l * alpha);
+        const float sr = wide ? zl_hermite4(t.xmr, t.x0r, t.x1r, t.x2r, w) : (t.x0r * invAlpha + t.x1r * alpha);
+        l = sl * ((lgain * env) * vol);
+        r = sr * ((rgain * env) * vol);
     } else if (MODE & ZL_MODE_FIX_GAIN) {
         l = (t.x0l * invAlpha + t.x1l * alpha) * lgain * env * vol;
         r = (t.x0r * invAlpha + t.x1r * alpha) * rgain * env * vol;

@@ -88,7 +88,11 @@ struct ZlVoiceConst {             // per voice, constant over a batch; 48 bytes 
     int32_t  pad[2];
 };
 
-enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2, ZL_PLAN_ENV = 4 };   // ENV: the envelope ramps inside the block (ZlPlanSeg1 holds the slopes)
+enum { ZL_PLAN_ACTIVE = 1, ZL_PLAN_SLOW = 2, ZL_PLAN_ENV = 4,      // ENV: the envelope ramps inside the block (ZlPlanSeg1 holds the slopes)
+       // SLOW blocks keep their per-frame control in a slot of the window's control pool (slot index in ZlPlanSeg0::step).  When the
+       // pool is exhausted the block carries what K2 needs to recompute its control instead:
+       ZL_PLAN_NOSLOT_SIM = 8,      // a block K1 simulated: the voice state at the block's start (ZlPlanSeg0/1, zl_plan.h zl_snapshot_*)
+       ZL_PLAN_NOSLOT_EXPAND = 16 };// a multi-segment block: its position in the segment stream (ZlPlanSeg1::n1 = idx0, P1 = base0)
 // K1's output per voice and plan window is a stream of linear segments in window time: frames [t, next segment's t)
 // are rendered at position P + (frame - t) * step with envelope E + (frame - t) * estep, both exactly (zl_plan.h).  A
 // segment ends at a binade crossing of the position or of the envelope, an ADSR state change, a loop restart or the
@@ -135,6 +139,15 @@ struct ZlBlockPlan {              // per (block, voice); 64 bytes, the first two
     double  step1;
     float   E1, estep1;           // envelope of frame n1 and the slope of the second segment
 };
+// What re-simulating a block needs of a voice besides the snapshot in its plan record: constant over a plan window (commands
+// apply between calls only).  Written by K1 for every playing voice.
+struct ZlSimConst {
+    double   pitch_ratio, adsr_sr, tail_T;
+    uint64_t length_ticks;
+    float    attack_rate, decay_rate, sustain, release;
+    int32_t  start_int, stop_pos, beat_locked, looping;
+};
+
 struct ZlReport {                 // device side of zlhip_voice_report
     int32_t playing, valid;
     uint32_t peak_bits;           // max over the last block of (l'+r'), as float bits (>= 0)
@@ -209,8 +222,12 @@ struct ZlBatch {
     ZlPlanHdr          *plan_hdr; // [K][V] explicit plans (blocks not covered by a run)
     ZlPlanSeg0         *plan_seg0;// [K][V]
     ZlPlanSeg1         *plan_seg1;// [K][V] valid where nseg >= 2
-    double             *ctl_P;    // [K][V][N]   per-frame control of slow blocks
-    float              *ctl_env;  // [K][V][N]
+    double             *ctl_P;    // [ctl_slots][N]  per-frame control of slow blocks: a pool of block-sized slots per window
+    float              *ctl_env;  // [ctl_slots][N]
+    unsigned long long *ctl_next; // the pool's bump counter (monotone across windows; a window's slots count from ctl_base)
+    unsigned long long  ctl_base;
+    int32_t             ctl_slots;
+    ZlSimConst         *sim_const;// [V]
     ZlReport           *reports;  // [V]
     float              *partials; // [K][B][groups][2][N]  (only when groups > 1)
     float              *bus;      // [B][2][Ktot*N]

@@ -263,5 +263,11 @@ class SamplerSynth:
         self._ck(self._lib.zlhip_profile_totals(self._e, C.byref(t), C.byref(n), 1 if reset else 0), "profile_totals")
         return t, n.value
 
+    def memory_bytes(self):
+        """(HBM bytes the engine allocated at creation, the source arena's share of them)."""
+        t, a = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._lib.zlhip_memory_bytes(self._e, C.byref(t), C.byref(a)), "memory_bytes")
+        return t.value, a.value
+
     def bus_device_ptr(self) -> int:
         return self._lib.zlhip_bus_device_ptr(self._e)

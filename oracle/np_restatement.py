@@ -295,17 +295,21 @@ class Voice:
             inb = dur > pos
             if hermite and inb:
                 wide = pos - 1 >= 0 and pos + 2 <= dur
+                # Catmull-Rom in tap-weight form: four cubic weights of alpha, shared by both channels; every fma32 is one rounding
+                t = f32(alpha * alpha)
+                w0 = f32(fma32(fma32(f32(-0.5), alpha, f32(1.0)), alpha, f32(-0.5)) * alpha)
+                w1 = fma32(fma32(f32(1.5), alpha, f32(-2.5)), t, f32(1.0))
+                w2 = f32(fma32(fma32(f32(-1.5), alpha, f32(2.0)), alpha, f32(0.5)) * alpha)
+                w3 = f32(fma32(f32(0.5), alpha, f32(-0.5)) * t)
 
                 def interp(x):
                     if wide:
                         y0, y1, y2, y3 = x[pos - 1], x[pos], x[pos + 1], x[pos + 2]
-                        c1 = f32(f32(0.5) * f32(y2 - y0))
-                        c2 = fma32(f32(-0.5), y3, fma32(f32(2.0), y2, fma32(f32(-2.5), y1, y0)))
-                        c3 = fma32(f32(1.5), f32(y1 - y2), f32(f32(0.5) * f32(y3 - y0)))
-                        return fma32(alpha, fma32(alpha, fma32(alpha, c3, c2), c1), y1)
+                        return fma32(w3, y3, fma32(w2, y2, fma32(w1, y1, f32(w0 * y0))))
                     return f32(f32(x[pos] * inv) + f32(x[pos + 1] * alpha))
-                l = f32(f32(f32(interp(inL) * self.lgain) * env) * vol)
-                r = f32(f32(f32(interp(inR) * self.rgain) * env) * vol) if inR is not None else l
+                # whole-sample gain, the gain product formed first: sample * ((gain * envelope) * volume)
+                l = f32(interp(inL) * f32(f32(self.lgain * env) * vol))
+                r = f32(interp(inR) * f32(f32(self.rgain * env) * vol)) if inR is not None else l
             elif fix_gain:
                 l = f32(f32(f32(f32(f32(inL[pos] * inv) + f32(inL[pos + 1] * alpha)) * self.lgain) * env) * vol) if inb else f32(0)
                 r = (f32(f32(f32(f32(f32(inR[pos] * inv) + f32(inR[pos + 1] * alpha)) * self.rgain) * env) * vol)

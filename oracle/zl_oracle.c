@@ -474,15 +474,27 @@ void zlo_voice_stop_note(zlo_voice *v, int allowTailOff, zlo_clip *clips, int64_
     }
 }
 
-/* build-defined Hermite extension (absent in the reference): 4-point Catmull-Rom
- *   y1 + a (c1 + a (c2 + a c3)),  c1 = (y2 - y0)/2,  c2 = y0 - 5/2 y1 + 2 y2 - y3/2,  c3 = (y3 - y0)/2 + 3/2 (y1 - y2)
- * with the operation order and the fused multiply-adds fixed here (fmaf = one rounding, C99 7.12.13.1) */
-static float hermite4(float y0, float y1, float y2, float y3, float a)
+/* build-defined Hermite extension (absent in the reference): 4-point Catmull-Rom through x[pos-1 .. pos+2], evaluated in
+ * TAP-WEIGHT form: the four cubic weights of the fractional position a are computed once per frame and shared by both
+ * channels,
+ *   w0 = ((-a/2 + 1) a - 1/2) a     w1 = (3/2 a - 5/2) a^2 + 1     w2 = ((-3/2 a + 2) a + 1/2) a     w3 = (a/2 - 1/2) a^2
+ *   y  = w0 y0 + w1 y1 + w2 y2 + w3 y3
+ * with the operation order and the fused multiply-adds fixed here (fmaf = one rounding, C99 7.12.13.1).  The same cubic as the
+ * Horner form of JUCE's CatmullRomInterpolator, other roundings; 19 instead of 24 operations per stereo frame. */
+typedef struct { float w0, w1, w2, w3; } hermite_w;
+static hermite_w hermite_weights(float a)
 {
-    const float c1 = 0.5f * (y2 - y0);
-    const float c2 = fmaf(-0.5f, y3, fmaf(2.0f, y2, fmaf(-2.5f, y1, y0)));
-    const float c3 = fmaf(1.5f, y1 - y2, 0.5f * (y3 - y0));
-    return fmaf(a, fmaf(a, fmaf(a, c3, c2), c1), y1);
+    hermite_w w;
+    const float t = a * a;
+    w.w0 = fmaf(fmaf(-0.5f, a, 1.0f), a, -0.5f) * a;
+    w.w1 = fmaf(fmaf(1.5f, a, -2.5f), t, 1.0f);
+    w.w2 = fmaf(fmaf(-1.5f, a, 2.0f), a, 0.5f) * a;
+    w.w3 = fmaf(0.5f, a, -0.5f) * t;
+    return w;
+}
+static float hermite4(float y0, float y1, float y2, float y3, hermite_w w)
+{
+    return fmaf(w.w3, y3, fmaf(w.w2, y2, fmaf(w.w1, y1, w.w0 * y0)));
 }
 
 void zlo_voice_process(zlo_voice *v, float *leftBuffer, float *rightBuffer, uint32_t nframes, const zlo_clock *clk,
@@ -525,15 +537,17 @@ void zlo_voice_process(zlo_voice *v, float *leftBuffer, float *rightBuffer, uint
 
         float l, r;
         if (hermite && sampleDuration > pos) {
-            /* extension: whole-sample gain; falls back to 2-tap linear at the buffer edges */
+            /* extension: whole-sample gain, the gain product formed first -- sample * ((gain * envelope) * volume) --; falls back
+             * to 2-tap linear at the buffer edges */
             const int wide = (pos - 1 >= 0) && (pos + 2 <= sampleDuration);
-            const float sl = wide ? hermite4(inL[pos - 1], inL[pos], inL[pos + 1], inL[pos + 2], alpha)
+            const hermite_w w = hermite_weights(alpha);
+            const float sl = wide ? hermite4(inL[pos - 1], inL[pos], inL[pos + 1], inL[pos + 2], w)
                                   : (inL[pos] * invAlpha + inL[pos + 1] * alpha);
-            l = sl * v->lgain * envelopeValue * clipVolume;
+            l = sl * ((v->lgain * envelopeValue) * clipVolume);
             if (inR != NULL) {
-                const float sr_ = wide ? hermite4(inR[pos - 1], inR[pos], inR[pos + 1], inR[pos + 2], alpha)
+                const float sr_ = wide ? hermite4(inR[pos - 1], inR[pos], inR[pos + 1], inR[pos + 2], w)
                                        : (inR[pos] * invAlpha + inR[pos + 1] * alpha);
-                r = sr_ * v->rgain * envelopeValue * clipVolume;
+                r = sr_ * ((v->rgain * envelopeValue) * clipVolume);
             } else {
                 r = l;
             }

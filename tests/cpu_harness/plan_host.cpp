@@ -25,7 +25,8 @@ struct ZlSim {
     std::vector<ZlPassCache> passCache;
     std::vector<ZlVoiceConst> vconst; std::vector<ZlRunList> runs; std::vector<ZlTSeg> tsegs;
     std::vector<ZlPlanHdr> planHdr; std::vector<ZlPlanSeg0> planSeg0; std::vector<ZlPlanSeg1> planSeg1;
-    std::vector<double> ctlP; std::vector<float> ctlEnv;
+    std::vector<double> ctlP; std::vector<float> ctlEnv; std::vector<ZlSimConst> simConst;
+    unsigned long long ctlNext = 0, ctlBase = 0; int ctlSlots = -1;      // -1: a slot for every (block, voice); >= 0: the pool's size (tests of the exhausted pool)
     std::vector<ZlReport> reports;
     std::vector<int32_t> trace;
     std::vector<ZlBlockLevels> levels;
@@ -58,7 +59,8 @@ static void render_all(ZlSim &S, const ZlBatch &A, float *bus)
                         const ZlVoiceConst &vc = A.vconst[v];
                         const bool act = f < pl.n_active;
                         double P; float env;
-                        zl_eval_control(pl, A.ctl_P + pidx * (size_t)N, A.ctl_env + pidx * (size_t)N, act ? f : 0, P, env);
+                        if (pl.flags & ZL_PLAN_SLOW) zl_slow_control(A, pl, v, k, act ? f : 0, P, env);
+                        else zl_eval_control(pl, act ? f : 0, P, env);
                         float l, r; int pos;
                         zl_render_frame<MODE>(vc, A.arena + vc.src_offset, P, env, l, r, pos);
                         if (act) { accL += l; accR += r; }
@@ -106,6 +108,7 @@ ZlSim *zlsim_create(int B, int VPB, int max_sounds, double fs, uint32_t mode, in
 }
 
 void zlsim_destroy(ZlSim *S) { delete S; }
+void zlsim_set_ctl_slots(ZlSim *S, int slots) { S->ctlSlots = slots; }
 
 int zlsim_clip_set(ZlSim *S, int id, const zlhip_clip_params *p)
 {
@@ -158,7 +161,9 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
             || (k > 0 && ck[(size_t)k].current_usecs < ck[(size_t)k - 1].current_usecs)) regular = false;
     }
     S->planHdr.assign((size_t)K * V, ZlPlanHdr{}); S->planSeg0.assign((size_t)K * V, ZlPlanSeg0{}); S->planSeg1.assign((size_t)K * V, ZlPlanSeg1{});
-    S->ctlP.assign((size_t)K * V * N, 0.0); S->ctlEnv.assign((size_t)K * V * N, 0.0f);
+    const size_t slots = S->ctlSlots >= 0 ? (size_t)S->ctlSlots : (size_t)K * V;
+    S->ctlP.assign(slots * N + 1, 0.0); S->ctlEnv.assign(slots * N + 1, 0.0f); S->simConst.assign(V, ZlSimConst{});
+    S->ctlBase = S->ctlNext + (unsigned long long)K * V + 1;            // past every value the counter can have reached (as the engine does)
     S->trace.assign((size_t)K * V * N, -1);
     S->levels.assign((size_t)K * S->B, ZlBlockLevels{});
     std::vector<ZlVoiceOp> ops; std::vector<ZlOpRange> ranges;
@@ -170,6 +175,7 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
     A.clocks = ck.data(); A.sounds = S->sounds.data(); A.clips = S->clips.data(); A.arena = S->arena.data();
     A.voices = S->voices.data(); A.pass_cache = S->passCache.data(); A.vconst = S->vconst.data(); A.runs = S->runs.data(); A.tsegs = S->tsegs.data(); A.plan_hdr = S->planHdr.data(); A.plan_seg0 = S->planSeg0.data(); A.plan_seg1 = S->planSeg1.data();
     A.ctl_P = S->ctlP.data(); A.ctl_env = S->ctlEnv.data(); A.reports = S->reports.data();
+    A.ctl_next = &S->ctlNext; A.ctl_base = S->ctlBase; A.ctl_slots = (int)slots; A.sim_const = S->simConst.data();
 
     for (const ZlOpRange &rg : ranges) {                          // K0
         ZlVoiceState st = S->voices[(size_t)rg.voice];
@@ -190,11 +196,12 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
             int idx0 = 0, base0 = 0, n_active = 0;
             if (as.block(A, k, idx0, base0, n_active) <= 2) continue;
             ++S->expanded;
-            const size_t pidx = (size_t)k * V + (size_t)v;
+            const int slot = zl_expand_slot(A, (size_t)k * V + (size_t)v, idx0, base0);
+            if (slot < 0) continue;                               // pool exhausted: the block was marked, rendering recomputes it
             for (int f = 0; f < N; ++f) {
                 float env;
-                S->ctlP[pidx * (size_t)N + f] = zl_expand_frame(as.ss, N, k, idx0, base0, f < n_active ? f : 0, env);
-                S->ctlEnv[pidx * (size_t)N + f] = env;
+                S->ctlP[(size_t)slot * (size_t)N + f] = zl_expand_frame(as.ss, N, k, idx0, base0, f < n_active ? f : 0, env);
+                S->ctlEnv[(size_t)slot * (size_t)N + f] = env;
             }
         }
     }

@@ -20,6 +20,7 @@ def lib():
         l.zlsim_create.restype = C.c_void_p
         l.zlsim_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint32, C.c_int]
         l.zlsim_destroy.argtypes = [C.c_void_p]
+        l.zlsim_set_ctl_slots.argtypes = [C.c_void_p, C.c_int]
         l.zlsim_clip_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(ClipParams)]
         l.zlsim_sound_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]
         l.zlsim_handle_command.argtypes = [C.c_void_p, C.POINTER(ClipCommand), C.c_uint64]
@@ -45,11 +46,13 @@ class SimSynth:
     """Same surface as libzl_amd.SamplerSynth, executed by the CPU harness."""
 
     def __init__(self, num_buses=12, voices_per_bus=8, *, mode=0, playback_sample_rate=48000.0,
-                 max_sounds=1024, voices_per_task=0, **_):
+                 max_sounds=1024, voices_per_task=0, ctl_pool_slots=-1, **_):
         self.l = lib()
         self.num_buses, self.voices_per_bus, self.mode = num_buses, voices_per_bus, mode
         self.num_voices = num_buses * voices_per_bus
         self.s = C.c_void_p(self.l.zlsim_create(num_buses, voices_per_bus, max_sounds, playback_sample_rate, mode, voices_per_task))
+        if ctl_pool_slots >= 0:                              # the window's control pool (-1: a slot for every (block, voice))
+            self.l.zlsim_set_ctl_slots(self.s, ctl_pool_slots)
         self._last = (0, 0)
         self.force_slow = False
         self.no_periodic = False

@@ -669,10 +669,10 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
 // paid once per 256 frames whatever the block size is.  A wavefront never straddles two blocks (N is a multiple of 64).
 // ST = the variant with LDS-staged source windows (zl_st_* above): its occupancy is set by the ring in LDS (2-3
 // workgroups per CU), so it may take the registers of 3 waves per SIMD.
+// (the body is a device function so that the persistent real-time kernel below can run it too: bx / by / bz / gdx / gdy stand for
+// blockIdx.x / .y / .z and gridDim.x / .y of the batch launch)
 template <uint32_t MODE, int BPW, bool ST>
-// (faithful linear mode, one block per workgroup -- the headline shape: ask for the 6 waves per SIMD its 78 registers
-// allow; left to itself the allocator takes 82 and drops to 5)
-__global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 && BPW == 1) ? 6 : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
+static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsigned bx, const unsigned by, const unsigned bz, const unsigned gdx, const unsigned gdy)
 {
     constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U_HERMITE : ZL_K2_U;
     constexpr int CH = ST ? ZL_ST_CHUNK : ZL_K2_CHUNK;    // voice records staged per pass (the staged variant trades them for ring space)
@@ -688,12 +688,12 @@ __global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_M
 
     const int N = A.N, V = A.V;
     const int blk = (BPW > 1) ? (int)threadIdx.x / N : 0;          // which of the workgroup's blocks this lane renders
-    const int f = (BPW > 1) ? (int)threadIdx.x - blk * N : (int)(blockIdx.x * blockDim.x + threadIdx.x);   // frame inside the block
+    const int f = (BPW > 1) ? (int)threadIdx.x - blk * N : (int)(bx * blockDim.x + threadIdx.x);   // frame inside the block
     // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin in launch order, so launch slot y runs on XCD
     // y % 8; giving XCD x the contiguous blocks [x * KY / 8, (x + 1) * KY / 8) lets neighbouring blocks (which share the
     // cache line at their common edge of every source) meet in the same L2
-    const int ky = (int)gridDim.y, xq = ky >> 3, xr = ky & 7, xx = (int)(blockIdx.y & 7u);
-    const int yb = xx * xq + (xx < xr ? xx : xr) + (int)(blockIdx.y >> 3);      // a bijection of [0, ky) for every ky
+    const int ky = (int)gdy, xq = ky >> 3, xr = ky & 7, xx = (int)(by & 7u);
+    const int yb = xx * xq + (xx < xr ? xx : xr) + (int)(by >> 3);      // a bijection of [0, ky) for every ky
     const int k = yb * BPW + blk;
     const bool live = k < A.K;                                     // the last workgroup may hold fewer than BPW blocks
     const ZlBlockPlan *s_plan = s_plan_[blk];
@@ -704,8 +704,8 @@ __global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_M
     // from ONE staging pass over their NB * VPB <= 128 voices -- the gathers of consecutive buses keep flowing and the
     // fixed costs per workgroup are shared.  NB == 1: one (bus, mix group) per workgroup.
     const int NB = A.NB;
-    const int bus0 = (NB > 1) ? (int)blockIdx.z * NB : (int)blockIdx.z / A.groups;
-    const int g    = (NB > 1) ? 0 : (int)blockIdx.z - bus0 * A.groups;
+    const int bus0 = (NB > 1) ? (int)bz * NB : (int)bz / A.groups;
+    const int g    = (NB > 1) ? 0 : (int)bz - bus0 * A.groups;
     const int v0 = bus0 * A.VPB + g * A.G;
     const int vlim = (NB > 1) ? ((bus0 + NB) * A.VPB < V ? (bus0 + NB) * A.VPB : V) : (bus0 + 1) * A.VPB;
     const int v1 = (NB > 1) ? vlim : ((v0 + A.G < vlim) ? v0 + A.G : vlim);
@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_M
         }
         // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of its
         //      whole block(s) (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
-        if (A.groups == 1 && gridDim.x == 1 && A.levels) {
+        if (A.groups == 1 && gdx == 1 && A.levels) {
             int pkL = written ? zl_sample_to_peak_int(accL) : 0, pkR = written ? zl_sample_to_peak_int(accR) : 0;
             float sqL = written ? accL * accL : 0.0f, sqR = written ? accR * accR : 0.0f;
             pkL = zl_wave_max_nonneg(pkL); pkR = zl_wave_max_nonneg(pkR);
@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_M
     };
     // the block levels of the workgroup's buses from the per-wave partial results: one lane per (bus, block)
     auto combine_levels = [&](int nbus) {
-        if (!(A.groups == 1 && gridDim.x == 1 && A.levels)) return;
+        if (!(A.groups == 1 && gdx == 1 && A.levels)) return;
         __syncthreads();
         for (int idx = threadIdx.x; idx < nbus * BPW; idx += blockDim.x) {
             const int bi = idx / BPW, b = idx - bi * BPW;
@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_M
                 bool fits = cand;
 #pragma unroll
                 for (int w = 0; w < WPB; ++w) {
-                    const int f0 = (BPW > 1) ? 64 * w : (int)blockIdx.x * 256 + 64 * w;
+                    const int f0 = (BPW > 1) ? 64 * w : (int)bx * 256 + 64 * w;
                     const int first = (int)fma((double)f0, pl.step, pl.P0) - TB, last = (int)fma((double)(f0 + 63), pl.step, pl.P0) + TA;
                     a[w] = first & ~1;                             // even frame = 16-byte aligned in the arena
                     n16[w] = (last - a[w] + 2) >> 1;               // 16-byte pieces covering frames [a, last]
@@ -1004,13 +1004,162 @@ __global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_M
 
 #ifdef ZL_STAMPS
     if (threadIdx.x == 0 && A.pos_trace) {
-        unsigned long long *st = reinterpret_cast<unsigned long long *>(A.pos_trace) + 4 * ((size_t)blockIdx.z * gridDim.y + blockIdx.y);
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(A.pos_trace) + 4 * ((size_t)bz * gdy + by);
         st[0] = zl_t0; st[1] = zl_t1; st[2] = __builtin_amdgcn_s_memrealtime();
         st[3] = zl_paths;
     }
 #endif
     if (NB == 1) { store_bus(bus0); combine_levels(1); }
     else combine_levels(curBus - bus0);
+}
+
+// the kernel: one workgroup = one (bus or group of narrow buses, mix group, block or BPW short blocks, frame tile)
+// (faithful linear mode, one block per workgroup -- the headline shape: ask for the 6 waves per SIMD its 78 registers
+// allow; left to itself the allocator takes 82 and drops to 5)
+template <uint32_t MODE, int BPW, bool ST>
+__global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 && BPW == 1) ? 6 : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
+{
+    zl_k2_body<MODE, BPW, ST>(A, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident real-time kernel: one workgroup PER BUS that stays on the GPU and renders a JACK cycle whenever the host
+// posts one in the mailbox -- no kernel launch, no completion event, no command-processor packet per block.  A workgroup owns
+// its bus: it applies the voice operations of the bus's voices (K0), plans them (K1 + K1c, one block), renders the bus (the K2
+// body: the workgroup's lanes = the block's frames), and writes mix + reports straight into host memory.  Nothing is handed
+// from one workgroup to another except the command: workgroup 0 watches the mailbox (host memory) and republishes each block in
+// HBM with agent-scope atomics; the last workgroup to finish (an arrival counter) tells the host.  Only workgroup 0 decides to
+// leave -- on a stop request or after idle_ticks (100 MHz) without a block -- and publishes that too, so every block is either
+// rendered by all workgroups or by none, and every wave reaches the exit.
+template <uint32_t MODE>
+__global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared *sh, ZlRtDev *dev, unsigned long long first_seq, unsigned long long idle_ticks,
+                                                    float *gain_out, ZlReport *host_reports, float *host_gain)
+{
+    __shared__ unsigned long long s_cmd[ZL_RT_CMD_WORDS + 1];     // [0] = the block's sequence number (0 with s_go = 0: leave)
+    __shared__ int s_go;
+    __shared__ ZlClock s_clk0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int z = blockIdx.x, W = gridDim.x;                       // one workgroup per bus
+    const int vbeg = z * A0.VPB, vend = vbeg + A0.VPB;
+    unsigned long long last = first_seq;
+    if (z == 0 && tid == 0) __hip_atomic_store(&sh->state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (;;) {
+        if (tid == 0) {
+            int go = 0;
+            if (z == 0) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    const unsigned long long q = __hip_atomic_load(&sh->cmd_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (q != last) {
+                        // the block's inputs: out of host memory once, into HBM for everybody (words first, then the sequence number)
+                        unsigned long long w[ZL_RT_CMD_WORDS];
+                        w[0] = (unsigned long long)(uint32_t)sh->nframes | ((unsigned long long)(uint32_t)sh->n_op_ranges << 32);
+                        w[1] = (unsigned long long)(uintptr_t)sh->ops; w[2] = (unsigned long long)(uintptr_t)sh->op_ranges; w[3] = sh->ctl_base;
+                        w[4] = sh->clock.current_usecs; w[5] = sh->clock.next_usecs; w[6] = sh->clock.playhead; w[7] = sh->clock.playhead_usecs;
+                        w[8] = sh->clock.subbeat_usecs; w[9] = sh->clock.usecs_per_frame; w[10] = 0; w[11] = 0;
+#pragma unroll
+                        for (int i = 0; i < ZL_RT_CMD_WORDS; ++i) { s_cmd[1 + i] = w[i]; __hip_atomic_store(&dev->cmd[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&dev->pub_seq, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_cmd[0] = q; go = 1;
+                        break;
+                    }
+                    if (__hip_atomic_load(&sh->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || __builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) {
+                        __hip_atomic_store(&dev->pub_seq, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody leaves
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            } else {
+                for (;;) {
+                    const unsigned long long q = __hip_atomic_load(&dev->pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q == ~0ull) break;
+                    if (q != last) {
+#pragma unroll
+                        for (int i = 0; i < ZL_RT_CMD_WORDS; ++i) s_cmd[1 + i] = __hip_atomic_load(&dev->cmd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_cmd[0] = q; go = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            s_go = go;
+        }
+        __syncthreads();
+        if (!s_go) break;
+        last = s_cmd[0];
+        if (z == 0 && tid == 0) sh->stamps[0] = __builtin_amdgcn_s_memrealtime();
+        ZlBatch A = A0;
+        A.N = (int)(uint32_t)s_cmd[1]; A.n_op_ranges = (int)(uint32_t)(s_cmd[1] >> 32);
+        A.ops = reinterpret_cast<const ZlVoiceOp *>((uintptr_t)s_cmd[2]); A.op_ranges = reinterpret_cast<const ZlOpRange *>((uintptr_t)s_cmd[3]);
+        A.ctl_base = s_cmd[4];
+        A.clock0.current_usecs = s_cmd[5]; A.clock0.next_usecs = s_cmd[6]; A.clock0.playhead = s_cmd[7]; A.clock0.playhead_usecs = s_cmd[8];
+        A.clock0.subbeat_usecs = s_cmd[9]; A.clock0.usecs_per_frame = s_cmd[10];
+        A.inline_clock = 1; A.fuse_assemble = 1;
+        // ---- K0: the operations of this bus's voices (the ranges are sorted by voice; host memory, read in place -- behind a
+        //      system-scope acquire: the host reuses the same buffers every block and plain loads may hit stale cached lines)
+        if (A.n_op_ranges > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        for (int i = tid; i < A.n_op_ranges; i += (int)blockDim.x) {
+            const ZlOpRange rg = A.op_ranges[i];
+            if (rg.voice < vbeg || rg.voice >= vend) continue;
+            ZlVoiceState st = A.voices[rg.voice];
+            for (int j = 0; j < rg.count; ++j) zl_apply_op(st, A.ops[rg.first + j]);
+            A.voices[rg.voice] = st;
+        }
+        if (tid == 0) s_clk0 = A.clock0;
+        __threadfence_block();
+        __syncthreads();
+        if (z == 0 && tid == 0) sh->stamps[1] = __builtin_amdgcn_s_memrealtime();
+        // ---- K1: one lane per voice of the bus, the single block of this cycle
+        for (int v = vbeg + tid; v < vend; v += (int)blockDim.x) {
+            ZlPlanner pl;
+            pl.begin(A, v, 0);
+            while (pl.t < A.N) pl.iterate(A, 1, &s_clk0, 0, 0);
+            pl.end(A);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (z == 0 && tid == 0) sh->stamps[2] = __builtin_amdgcn_s_memrealtime();
+        // ---- K1c: plan records of the block, multi-segment blocks expanded by whole waves
+        for (int v0 = vbeg; v0 < vend; v0 += (int)blockDim.x) {
+            const int v = v0 + tid;
+            const bool mine = v < vend;
+            ZlAssembler as;
+            as.begin(A, mine ? v : vbeg, 0, mine ? 1 : 0);
+            zl_k1c_block(A, as, v, lane, 0);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (z == 0 && tid == 0) sh->stamps[3] = __builtin_amdgcn_s_memrealtime();
+        // ---- K2: this bus
+        zl_k2_body<MODE, 1, false>(A, 0u, 0u, (unsigned)z, 1u, 1u);
+        __threadfence_block();
+        __syncthreads();
+        if (z == 0 && tid == 0) sh->stamps[4] = __builtin_amdgcn_s_memrealtime();
+        // ---- reports (gain = peakGain * 0.5f, SamplerSynthVoice.cpp:266) straight into host memory
+        for (int v = vbeg + tid; v < vend; v += (int)blockDim.x) {
+            const ZlReport r = A.reports[v];
+            const float g = __uint_as_float(r.peak_bits) * 0.5f;
+            gain_out[v] = g; host_reports[v] = r; host_gain[v] = g;
+        }
+        __syncthreads();                                           // every wave's stores are issued and waited for (workgroup release)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this bus's mix and reports (host memory), its levels (HBM)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (z == 0) sh->stamps[5] = __builtin_amdgcn_s_memrealtime();
+            const unsigned int old = __hip_atomic_fetch_add(&dev->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned int)W - 1u) {                     // the last bus: the block is complete
+                __hip_atomic_store(&dev->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&sh->done_seq, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    if (z == 0 && tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&sh->state, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // The AudioLevels scan of one (block, bus) row pair by ONE wave: integer peaks (AudioLevels.cpp:361-383) and the sums of
@@ -1303,6 +1452,20 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEv
         else if (bpw == 2)       hipExtLaunchKernelGGL((zl_k2_render<M, 2, false>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
         else                     hipExtLaunchKernelGGL((zl_k2_render<M, 1, false>), grid, block, pad, s, ev_start, ev_stop, 0, A); \
         break;
+        ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
+#undef ZL_CASE
+    }
+    ZL_LAUNCH_CHECK();
+    return 0;
+}
+
+int zl_launch_rt_loop(const ZlBatch &A, void *mailbox_dev, void *dev_state, unsigned long long first_seq, unsigned long long idle_ticks, float *gain_out,
+                      ZlReport *host_reports, float *host_gain, int threads, hipStream_t s)
+{
+    ZlRtShared *sh = reinterpret_cast<ZlRtShared *>(mailbox_dev);
+    ZlRtDev *dv = reinterpret_cast<ZlRtDev *>(dev_state);
+    switch (A.mode & 7u) {
+#define ZL_CASE(M) case M: hipLaunchKernelGGL((zl_k_rt_loop<M>), dim3(A.B), dim3(threads), 0, s, A, sh, dv, first_seq, idle_ticks, gain_out, host_reports, host_gain); break;
         ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
 #undef ZL_CASE
     }

@@ -193,6 +193,30 @@ struct ZlBatchStats {
     unsigned long long active_frames;
 };
 
+// Mailbox between zlhip_render and the resident real-time kernel (zl_k_rt_loop), in host memory mapped into the device.
+// The host fills in a block's inputs, then writes cmd_seq; the kernel renders the block, writes the mix and the reports into
+// host memory, then writes done_seq.  state: 0 not started, 1 resident, 2 left (stop request or idle timeout).
+struct ZlRtShared {
+    unsigned long long cmd_seq, done_seq;
+    uint32_t state, stop;
+    int32_t  nframes, n_op_ranges;
+    const ZlVoiceOp   *ops;       // device views of the block's voice operations (mapped host memory)
+    const ZlOpRange   *op_ranges;
+    unsigned long long ctl_base;  // base of this cycle's control-slot pool (zl_plan.h zl_ctl_alloc)
+    ZlClock  clock;
+    unsigned long long stamps[8]; // s_memrealtime (100 MHz) at the kernel's stages of the last block (diagnostic)
+};
+
+// Device side of the resident kernel: workgroup 0 watches the mailbox and republishes every block in HBM for the other
+// workgroups (agent-scope atomics: eight-byte words, visible across XCDs without cache fences); `arrive` counts the workgroups
+// that have finished the block.
+#define ZL_RT_CMD_WORDS 12
+struct ZlRtDev {
+    unsigned long long pub_seq;                  // the block being rendered (~0ull: leave)
+    unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words)
+    unsigned int arrive, pad;
+};
+
 // Launch-wide arguments (passed by value to the kernels).
 struct ZlBatch {
     int32_t V, B, VPB, K, N;      // voices, buses, voices per bus, blocks in this plan window, frames per block

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-block real-time latency of zlhip_render (host buffers in and out, synchronous), SURVEY.md H3."""
+"""Per-block real-time latency of zlhip_render (host buffers in and out, synchronous), SURVEY.md H3: the launched path (three
+kernels + one completion event per block) against the resident kernel (ZL_RT_PERSISTENT=1), p50 / p99 / max over 10^4 blocks."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,7 +8,8 @@ import numpy as np, torch
 from libzl_amd import SamplerSynth, clip_command
 from libzl_amd.engine import synthetic_clocks
 
-def run(V, B, N, vpt=0):
+def run(V, B, N, vpt=0, resident=False, blocks=10000, paced=False):
+    os.environ["ZL_RT_PERSISTENT"] = "1" if resident else "0"
     fs = 48000.0
     lf = 96000
     syn = SamplerSynth(B, V // B, max_frames=N, max_batch_blocks=4, max_sounds=V, playback_sample_rate=fs,
@@ -19,18 +21,27 @@ def run(V, B, N, vpt=0):
         syn.set_clip_params(v, p)
         syn.start_voice(v // (V // B), v % (V // B), clip_command(clip=v, midi_note=60, midi_channel=v // (V // B) - 2, start_playback=1, looping=1, change_volume=1, volume=0.5), 0)
     ts = []
-    for k in range(300):
+    period = N / fs
+    t_next = time.perf_counter()
+    for k in range(blocks + 50):
         clk = synthetic_clocks(1, N, fs, start_block=k)[0]
+        if paced:                                   # one block per JACK period, as in production (the GPU idles in between)
+            while time.perf_counter() < t_next: pass
+            t_next += period
         t0 = time.perf_counter(); syn.process(N, clk); ts.append(time.perf_counter() - t0)
     ts = np.array(ts[50:]) * 1e6
-    print(f"V={V:5d} B={B:3d} N={N:4d} voices_per_task={vpt:3d}: zlhip_render median {np.median(ts):7.1f} us  p99 {np.percentile(ts, 99):7.1f} us  "
-          f"(block period {1e6 * N / fs:.0f} us) -> {V * N / np.median(ts) * 1e6:.3e} voice-samples/s PCIe-inclusive")
+    print(f"V={V:5d} B={B:3d} N={N:4d} vpt={vpt:3d} {'resident' if resident else 'launched'} {'paced   ' if paced else 'back2back'}: zlhip_render p50 {np.median(ts):7.1f} us  p99 {np.percentile(ts, 99):7.1f} us  "
+          f"max {ts.max():7.1f} us  (block period {1e6 * period:.0f} us, {blocks} blocks)", flush=True)
     syn.close()
 
-run(96, 12, 256)          # the reference's own shape: 12 channels x 8 voices
-run(64, 8, 256)           # BASELINE config 1
-run(1024, 8, 128)         # config 2 shape
-run(1024, 8, 256)
-run(1024, 8, 256, vpt=16)
-run(1024, 8, 256, vpt=1)  # one voice per task: every voice rendered by its own workgroup, K3 sums them in voice order (= the reference's order)
-run(1024, 8, 256, vpt=4)
+if __name__ == "__main__":
+    quick = "--quick" in sys.argv
+    n = 2000 if quick else 10000
+    for res in (False, True):
+        run(96, 12, 256, resident=res, blocks=n)          # the reference's own shape: 12 channels x 8 voices
+        run(64, 8, 256, resident=res, blocks=n)           # BASELINE configs[1]
+        run(96, 12, 128, resident=res, blocks=n)
+    for res in (False, True):
+        run(96, 12, 256, resident=res, blocks=1500, paced=True)
+    if not quick:
+        run(1024, 8, 128); run(1024, 8, 256); run(1024, 8, 256, vpt=16)   # wide buses: the launched path (per-voice split + K3)

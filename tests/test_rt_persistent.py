@@ -1,0 +1,146 @@
+"""GPU tier: zlhip_render through the resident real-time kernel (the default for narrow buses; ZL_RT_PERSISTENT=0 disables it) -- the same bits as the launched
+path, block by block, across commands, idle spells (the kernel leaves and is started again), block-size changes, parameter edits
+and batch calls in between (which stop the kernel)."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+from golden_util import golden_names, load_golden
+from scenario import engine_cmd, random_scene, run_oracle, snapshot_clip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def rt_env():
+    old = os.environ.get("ZL_RT_PERSISTENT")
+    os.environ["ZL_RT_PERSISTENT"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("ZL_RT_PERSISTENT", None)
+    else:
+        os.environ["ZL_RT_PERSISTENT"] = old
+
+
+def _play_blockwise(sc, *, pause_at=(), batch_at=(), edit_at=()):
+    """The scene cycle by cycle through SamplerSynth.process (zlhip_render): returns (bus [B][2][K*N], last reports, synth)."""
+    from libzl_amd import SamplerSynth
+    from oracle import zl_oracle as zo
+    ref = zo.OracleSynth(1, 1, sc.fs, sc.mode, max_sounds=max(8, len(sc.sounds)))
+    syn = SamplerSynth(num_buses=sc.num_buses, voices_per_bus=sc.voices_per_bus, mode=sc.mode, playback_sample_rate=sc.fs,
+                       max_frames=max(64, sc.nframes), max_batch_blocks=4, max_sounds=max(8, len(sc.sounds)),
+                       sound_arena_bytes=max(1 << 20, sum((s[0].shape[0] + 16) * 8 for s in sc.sounds) + (1 << 16)))
+    for i, (L, R, sr) in enumerate(sc.sounds):
+        assert ref.register_clip(L, R, sr) == i and syn.register_clip(L, R, sr) == i
+        if i in sc.clip_setup:
+            sc.clip_setup[i](ref.lib, ref.clips[i])
+        syn.set_clip_params(i, snapshot_clip(ref.clips[i]))
+    N = sc.nframes
+    out = np.zeros((sc.num_buses, 2, sc.nblocks * N), dtype=np.float32)
+    for k in range(sc.nblocks):
+        for ev in sc.events.get(k, []):
+            if ev[0] == "cmd":
+                syn.handle_clip_command(engine_cmd(**ev[1]), ev[2])
+            elif ev[0] == "start":
+                syn.start_voice(ev[1], ev[2], engine_cmd(**ev[3]), ev[4])
+            elif ev[0] == "clip":
+                ev[2](ref.lib, ref.clips[ev[1]])
+                syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))      # stops the resident kernel; the next cycle restarts it
+        if k in pause_at:
+            time.sleep(0.35)                                                    # longer than the kernel's idle timeout (200 ms)
+        if k in edit_at:
+            syn.set_clip_params(0, snapshot_clip(ref.clips[0]))                 # same parameters again: only the stop / restart matters
+        L, R = syn.process(N, sc.make_clocks(k, 1)[0])
+        out[:, 0, k * N:(k + 1) * N] = L
+        out[:, 1, k * N:(k + 1) * N] = R
+    return out, syn.voice_reports(), syn
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_resident_kernel_renders_the_golden_vectors(built, rt_env, name):
+    sc, ex = load_golden(name)
+    bus, rep, syn = _play_blockwise(sc, pause_at=(3,), edit_at=(6,))
+    assert np.array_equal(bus.view(np.int32), ex["bus"].view(np.int32)), f"max diff {np.abs(bus - ex['bus']).max()}"
+    for v in range(sc.num_buses * sc.voices_per_bus):
+        assert bool(rep[v].playing) == bool(ex["state"][v, 0])
+        if rep[v].playing:
+            assert rep[v].source_sample_position == ex["state"][v, 1]
+        assert rep[v].valid == int(ex["reports"][v, 0])
+        if rep[v].valid:
+            assert np.float32(rep[v].gain) == np.float32(ex["reports"][v, 1]) and np.float32(rep[v].progress) == np.float32(ex["reports"][v, 2])
+    syn.close()
+
+
+@pytest.mark.parametrize("seed,mode,nframes", [(300, 0, 256), (301, 4, 128), (302, 3, 64), (303, 0, 128)])
+def test_resident_kernel_matches_oracle_on_mixed_scenes(built, rt_env, seed, mode, nframes):
+    """The reference's own shape -- 12 channels x 8 voices -- with commands and clip edits between cycles, and the levels."""
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    sc = random_scene(seed, num_buses=12, voices_per_bus=8, nclips=20, mode=mode, nframes=nframes, nblocks=40)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn = _play_blockwise(sc, pause_at=(17,))
+    assert np.array_equal(bus.view(np.int32), ref_bus.view(np.int32)), f"max diff {np.abs(bus - ref_bus).max()}"
+    for v in range(96):
+        assert bool(ref_syn.voices[v].isPlaying) == bool(rep[v].playing)
+        assert ref_rep[v].valid == rep[v].valid
+        if ref_rep[v].valid:
+            assert ref_rep[v].gain == rep[v].gain and ref_rep[v].progress == rep[v].progress
+    lv = syn.levels_tick(block_index=-1, with_hold_bus=1)                       # the meters read the resident kernel's last block
+    N = nframes
+    for b in range(12):
+        ch = zo.LevelsChannel()
+        L = np.ascontiguousarray(bus[b, 0, -N:]); R = np.ascontiguousarray(bus[b, 1, -N:])
+        lib.zlo_levels_tick(C.byref(ch), L.ctypes.data, R.ctypes.data, N, 1 if b == 1 else 0)
+        assert (lv[b].peak_a, lv[b].peak_b) == (ch.peakA, ch.peakB)
+        assert lv[b].rms_a == lib.zlo_block_rms(L.ctypes.data, N, 0 if (mode & 2) else 1)
+    syn.close()
+
+
+@pytest.mark.parametrize("name", ["g5_adsr_commands", "g8_resampled_256"])
+def test_launched_path_still_renders_the_golden_vectors(built, name):
+    """ZL_RT_PERSISTENT=0: three launches and a completion event per block (the path wide buses always take)."""
+    old = os.environ.get("ZL_RT_PERSISTENT")
+    os.environ["ZL_RT_PERSISTENT"] = "0"
+    try:
+        sc, ex = load_golden(name)
+        bus, rep, syn = _play_blockwise(sc)
+        assert np.array_equal(bus.view(np.int32), ex["bus"].view(np.int32))
+        syn.close()
+    finally:
+        if old is None:
+            os.environ.pop("ZL_RT_PERSISTENT", None)
+        else:
+            os.environ["ZL_RT_PERSISTENT"] = old
+
+
+def test_resident_kernel_and_batches_interleave(built, rt_env):
+    """Real-time cycles, then a batch on the same engine (the kernel is stopped), then cycles again: one continuous, exact stream."""
+    from libzl_amd import SamplerSynth
+    from oracle import zl_oracle as zo
+    sc = random_scene(310, num_buses=4, voices_per_bus=8, nclips=10, nframes=128, nblocks=30, events=False)
+    ref_bus, _, _ = run_oracle(sc)
+    ref = zo.OracleSynth(1, 1, sc.fs, sc.mode, max_sounds=16)
+    syn = SamplerSynth(num_buses=4, voices_per_bus=8, max_frames=128, max_batch_blocks=8, max_sounds=16, sound_arena_bytes=1 << 21)
+    for i, (L, R, sr) in enumerate(sc.sounds):
+        ref.register_clip(L, R, sr); syn.register_clip(L, R, sr)
+        sc.clip_setup[i](ref.lib, ref.clips[i])
+        syn.set_clip_params(i, snapshot_clip(ref.clips[i]))
+    for ev in sc.events[0]:
+        syn.handle_clip_command(engine_cmd(**ev[1]), ev[2])
+    N = 128
+    out = np.zeros((4, 2, 30 * N), dtype=np.float32)
+    k = 0
+    while k < 30:
+        if k in (10, 21):                                                       # a batch of 8 blocks in the middle of the stream
+            syn.render_batch(8, N, sc.make_clocks(k, 8))
+            out[:, :, k * N:(k + 8) * N] = syn.read_bus()
+            k += 8
+            continue
+        L, R = syn.process(N, sc.make_clocks(k, 1)[0])
+        out[:, 0, k * N:(k + 1) * N] = L; out[:, 1, k * N:(k + 1) * N] = R
+        k += 1
+    assert np.array_equal(out.view(np.int32), ref_bus.view(np.int32))
+    syn.close()

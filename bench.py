@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reuse-check", action="store_true", help="skip the 10 s-loop (no source re-read inside a window: HBM only) measurement")
     ap.add_argument("--no-reuse-calls", type=int, default=12)
+    ap.add_argument("--no-repeats", action="store_true", help="skip the two extra timed regions that give value_per_gpu_repeats")
     ap.add_argument("--no-spot-check", action="store_true", help="skip the output check against the oracle after the timed region")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the measured path) or gloo (rehearsal: exchange through host memory)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
@@ -416,6 +417,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # ---- spread: the same K steps timed twice more (each region bracketed by a synchronisation like the first; `value` stays the
+    #      first region's).  Not for --span-buses (the exchange pipeline would have to be flushed per region).
+    repeats = []
+    if not exchange and not args.no_repeats:
+        for rep in range(2):
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            for i in range(args.steps):
+                step(args.warmup + i, True)
+            torch.cuda.synchronize()
+            repeats.append(float(V) * KB * N * args.steps / (time.perf_counter() - tr0))
+
     # ---- output check (every rank, its own voices): one more step, untimed, rendered like the timed ones; 3 random
     #      (bus, block) rows of it against the CPU oracle, bit for bit.  A mismatch fails the run.
     check = None
@@ -504,7 +517,7 @@ def main():
         out = {
             "metric": "voice-samples/sec at 1024 voices x 256-frame blocks; % HBM roofline",
             "value": value, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "value_per_gpu_repeats": repeats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{V} looping {'mono' if args.mono else 'stereo'} voices per GPU on {B} buses x {vpb}, {N}-frame blocks, {KB} blocks per step ({launches} K2 launches), "

@@ -5,7 +5,7 @@ set -o pipefail
 tag=${1:-ab}
 out=gpurun_out/ab_staged_$tag.jsonl
 : > $out
-run() { echo "### ZL_K2_STAGED=$ST $*" >> $out; ZL_K2_STAGED=$ST timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/ab_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/ab_err.log >> $out; return 1; }; }
+run() { echo "### ZL_K2_STAGED=$ST $*" >> $out; ZL_K2_STAGED=$ST timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --no-repeats --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/ab_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/ab_err.log >> $out; return 1; }; }
 for ls in 2 10; do for ST in 0 2; do
 run --loop-seconds $ls --notes 48,72 --hermite &&
 run --loop-seconds $ls --hermite &&

@@ -6,7 +6,7 @@ set -o pipefail
 tag=${1:-r2p}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$tag; rm -rf $O; mkdir -p $O
-B="--no-cpu-baseline --no-reuse-check --no-spot-check --steps 4 --warmup 1"
+B="--no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1"
 python3 bench.py > $O/bench_line.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
 for wl in "reuse:" "noreuse:--loop-seconds 10"; do
   name=${wl%%:*}; args=${wl#*:}

@@ -61,7 +61,7 @@ for wl, loops in (("reuse", 2.0), ("noreuse", 10.0)):
 # workload: bench.py defaults (1024 stereo voices, 8 buses x 128, 256-frame blocks, 8192 blocks per call, ratio 1, linear, faithful) with
 #   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits' if wl == 'reuse' else ' -- NO source byte is re-read inside a plan window (2048 blocks = 10.9 s): every source read comes from HBM'}
 # commands (one pass each; raw CSVs condensed by scripts/summarize_prof.py; long torch kernel names cut):
-#   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --steps 4 --warmup 1{' --loop-seconds 10' if wl == 'noreuse' else ''}
+#   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1{' --loop-seconds 10' if wl == 'noreuse' else ''}
 #   rocprofv3 --pmc <counters> --output-format csv -- same command (5 passes: FETCH_SIZE | WRITE_SIZE TCC_HIT/MISS | TCC_EA0_RDREQ/WRREQ | SQ_* | LDS / TA / TCP)
 # {calls} zlhip_render_batch calls = {fetch[0]} K2 dispatches; the full plan windows are the {big['grid']}-thread launches (2048 blocks).
 #
@@ -89,7 +89,7 @@ json.dump({"kernel": "zl_k2_render<0,1,false>", "kernel_source_digest": digest,
            "reuse": out["reuse"], "noreuse": out["noreuse"],
            "source": f"profiles/{name}_reuse_rocprofv3_summary.txt, profiles/{name}_noreuse_rocprofv3_summary.txt"},
           open(os.path.join(P, f"{name}_pmc.json"), "w"), indent=1)
-for f in ("config_sweep.txt", "herm_pmc_summary.txt", "host.txt"):
+for f in ("config_sweep.txt", "herm_pmc_summary.txt", "host.txt", "realtime.txt"):
     src = os.path.join(G, f)
     if os.path.exists(src):
         open(os.path.join(P, f"{name}_{f}"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l))

@@ -7,7 +7,7 @@ tag=${1:-r2}; shift
 out=gpurun_out/sweep_$tag.jsonl
 mkdir -p gpurun_out
 : > $out
-run() { echo "### $*" >> $out; timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/sweep_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/sweep_err.log >> $out; return 1; }; }
+run() { echo "### $*" >> $out; timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --no-repeats --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/sweep_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/sweep_err.log >> $out; return 1; }; }
 for ls in 2 10; do
 run --loop-seconds $ls "$@" &&
 run --loop-seconds $ls --notes 48,72 "$@" &&

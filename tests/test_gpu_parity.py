@@ -238,7 +238,7 @@ def test_full_voice_count_bit_exact_against_oracle(Engine):
     syn.close()
 
 
-def test_config1_shape_64_voices_resampled(Engine):
+def test_baseline_configs_1_64_voices_resampled(Engine):
     """BASELINE configs[1]: 64 stereo voices, linear-interp resample (44.1 kHz and 48 kHz sources, notes +-12),
     48 kHz playback, 256-frame blocks; attack/decay envelopes as SURVEY.md section 8d cfg 2."""
     rng = np.random.default_rng(0x5A17 + 1)
@@ -265,7 +265,7 @@ def test_config1_shape_64_voices_resampled(Engine):
     syn.close()
 
 
-def test_config2_shape_1024_loops_128_frames_levels(Engine):
+def test_baseline_configs_2_1024_loops_128_frames_levels(Engine):
     """BASELINE configs[2]: 1024 stereo clip loops, per-clip gain/pan, AudioLevels peaks every block, 128-frame blocks."""
     sc = _big_scene(V=1024, B=16, nframes=128, nblocks=30, seed=0x5A17 + 2)
     ref_bus, ref_rep, ref_syn = run_oracle(sc, threads=8)
@@ -285,7 +285,7 @@ def test_config2_shape_1024_loops_128_frames_levels(Engine):
     syn.close()
 
 
-def test_config5_shape_96k_batched_bounce(Engine):
+def test_baseline_configs_4_96k_batched_bounce(Engine):
     """BASELINE configs[4] in miniature: 96 kHz sources and playback, many voices, long batched render that spans
     several plan windows; throughput-only in the benchmark, parity here."""
     rng = np.random.default_rng(0x5A17 + 5)
@@ -308,8 +308,8 @@ def test_config5_shape_96k_batched_bounce(Engine):
     syn.close()
 
 
-def test_config4_shape_pitched_hermite(Engine):
-    """BASELINE config 4 per-GPU shape: 1024 voices on one bus, pitch 0.5-2x, 4-tap Hermite (build-defined extension)."""
+def test_baseline_configs_3_pitched_hermite_shard(Engine):
+    """BASELINE.json configs[3], per-GPU shape: 1024 voices on one bus, pitch 0.5-2x, 4-tap Hermite (build-defined extension)."""
     sc = _big_scene(V=1024, B=1, nblocks=8, hermite=True, ratios=True, seed=0x5A1B)
     sc.mix_group = 64
     ref_bus, ref_rep, ref_syn = run_oracle(sc)

@@ -390,6 +390,8 @@ def main():
             overlapped = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32), dst=0, algorithm="reduce")
             step(i, False)
     torch.cuda.synchronize()
+    import gc
+    gc.collect(); gc.disable()                                       # as timeit does: no collector pause of this harness inside a timed region
     syn.profile_totals(reset=True)                                   # HIP-event sums start with the timed region
     if distributed:
         dist.barrier()
@@ -397,8 +399,11 @@ def main():
     t0 = time.perf_counter()
     # the steps are queued back to back: consecutive zlhip_render_batch calls pipeline (the planning of step i+1
     # overlaps the rendering of step i); the per-kernel HIP events of every step are read once, after the region
+    host_ms = []                                                     # host time inside each step's calls (they return before the GPU is done)
     for i in range(args.steps):
+        th = time.perf_counter()
         step(args.warmup + i, True)
+        host_ms.append((time.perf_counter() - th) * 1e3)
     if overlapped is not None:
         overlapped.flush(stream=sptr)                                # the last exchanges + level scans are inside the timed region
     torch.cuda.synchronize()
@@ -545,6 +550,7 @@ def main():
                 "bytes_per_voice_sample": k2_bytes_step / (V * KB * N),
                 "other_ms_per_step": {"planning_not_hidden (K0+K1+K1c of the first window; overlaps the previous step)": float(np.mean(plan_ms)),
                                       "K3 finalize + reports + launch gaps": float(np.mean(fin_ms))},
+                "host_dispatch_ms_per_step": {"mean": float(np.mean(host_ms)), "max": float(np.max(host_ms)), "argmax": int(np.argmax(host_ms))},
                 "state_and_levels_bytes_per_step": state_bytes, "slow_blocks": int(slow),
                 "engine_device_bytes": {"total": eng_total, "source_arena": eng_arena, "beyond_sources": eng_total - eng_arena},
                 "note": "achieved / frac are algorithmic bytes over the K2 launch time of the timed (BASELINE) workload, whose 2 s sources are re-read "

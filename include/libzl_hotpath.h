@@ -115,6 +115,8 @@ int    ClipAudioSource_engineClip(ClipAudioSource *c);                          
 int  libzl_wav_read(const char *path, float **left, float **right, int *length, double *sampleRate);  /* malloc'd planes; free with libzl_wav_free */
 void libzl_wav_free(float *plane);
 int  libzl_wav_write(const char *path, const float *left, const float *right, int length, double sampleRate, int bitsPerSample /* 16 or 32(float) */);
+/* the same file from already interleaved frames: 16 bit = int16_t pairs as zlhip_bounce(ZLHIP_BOUNCE_PCM16_STEREO) delivers them per bus, 32 = float */
+int  libzl_wav_write_interleaved(const char *path, const void *frames, int length, int channels, double sampleRate, int bitsPerSample);
 
 #ifdef __cplusplus
 }

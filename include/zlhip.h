@@ -260,6 +260,25 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
                               float *bus_out_dev, const zlhip_passthrough_params *fan_params, float *fan_out_dev,
                               void *stream);
 
+/* ---- offline bounce (BASELINE configs[4]; the recorder side of the bus, AudioLevels.cpp:35-119) ----------------------------
+ * Renders nblocks consecutive blocks exactly like consecutive zlhip_render_batch calls (voice state, levels and reports carry on;
+ * afterwards zlhip_levels_tick / zlhip_block_peaks / zlhip_voice_reports see the last sub-batch) and delivers every bus to HOST
+ * memory: the bounce is cut into sub-batches of sub_blocks blocks (0 = a sixth of the bounce, at least 256 blocks; at most max_batch_blocks) that
+ * render into three device buffers in turn while the previous ones cross PCIe on a copy stream.  Synchronous.
+ *   clocks    host [nblocks]
+ *   host_out  ZLHIP_BOUNCE_F32_PLANAR:  float   [num_buses][2][nblocks*nframes]     (the layout of zlhip_render_batch)
+ *             ZLHIP_BOUNCE_PCM16_STEREO: int16_t [num_buses][nblocks*nframes][2]     (the data chunk of one 16-bit stereo WAV per
+ *             bus, converted on the GPU as the reference's recorder converts -- juce::WavAudioFormat 16 bit, AudioLevels.cpp:53-58;
+ *             restated, JUCE version unpinned: clamp, x 0x7fffffff in double, round to nearest even, upper 16 bits; half the PCIe bytes)
+ *             Page-locked memory (zlhip_host_alloc, or the caller's hipHostMalloc / hipHostRegister) gives the full PCIe rate;
+ *             pageable memory works through the runtime's staging copies.
+ * zlhip_host_alloc / zlhip_host_free: page-locked host memory for callers that do not link HIP. */
+enum { ZLHIP_BOUNCE_F32_PLANAR = 0, ZLHIP_BOUNCE_PCM16_STEREO = 1 };
+int  zlhip_bounce(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_clock *clocks, void *host_out, int32_t format,
+                  int32_t sub_blocks);
+int  zlhip_host_alloc(size_t bytes, void **out);
+void zlhip_host_free(void *p);
+
 /* ---- introspection / measurement ------------------------------------------------------------ */
 int zlhip_set_profiling(zlhip_engine *e, int enable);
 int zlhip_last_timings(zlhip_engine *e, zlhip_timings *out);

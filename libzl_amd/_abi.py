@@ -128,6 +128,9 @@ SIGNATURES = {
     "zlhip_block_peaks": (C.c_int, [_E, C.c_void_p, C.c_size_t]),
     "zlhip_levels_scan_device": (C.c_int, [_E, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "zlhip_memory_bytes": (C.c_int, [_E, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "zlhip_bounce": (C.c_int, [_E, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "zlhip_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "zlhip_host_free": (None, [C.c_void_p]),
     "zlhip_bus_reduce_sum_scan": (C.c_int, [_E, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zlhip_levels_import_units": (C.c_int, [_E, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "zlhip_passthrough_params_default": (None, [C.POINTER(PassthroughParams)]),

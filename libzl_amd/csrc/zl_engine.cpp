@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -144,6 +145,16 @@ struct zlhip_engine {
         bool stampsOn = false; double stampSum[6] = {0, 0, 0, 0, 0, 0}; unsigned long long stampN = 0;   // ZL_RT_STAMPS=1: stage times (us)
     } rt;
 
+    // offline bounce (zlhip_bounce): two device bus buffers rendered into in turn, their 16-bit versions, the copy stream
+    struct Bounce {
+        static constexpr int NBUF = 3;       // one renders, one is delivered, one is spare: the "delivered" wait of a render is always long over
+        float *bus[NBUF] = {nullptr, nullptr, nullptr}; int16_t *pcm[NBUF] = {nullptr, nullptr, nullptr};
+        size_t busFloats = 0, pcmFrames = 0;
+        hipStream_t copyStream = nullptr;
+        hipEvent_t rendered[NBUF] = {nullptr, nullptr, nullptr}, copied[NBUF] = {nullptr, nullptr, nullptr};
+        bool active = false;                 // inside zlhip_bounce: every sub-batch plans on the planning stream
+    } bnc;
+
     // profiling
     bool profiling = false; hipEvent_t evJoin = nullptr;
     hipEvent_t joins[2] = {nullptr, nullptr};   // events on caller streams the host still has to wait for (engine_wait)
@@ -271,6 +282,13 @@ void zlhip_engine_destroy(zlhip_engine *e)
         for (auto &x : c.evK2) if (x) (void)hipEventDestroy(x);
         hipEvent_t evs[] = { c.evBegin, c.evEnd, c.done };
         for (hipEvent_t x : evs) if (x) (void)hipEventDestroy(x);
+    }
+    if (e->bnc.copyStream) { (void)hipStreamSynchronize(e->bnc.copyStream); (void)hipStreamDestroy(e->bnc.copyStream); }
+    for (int i = 0; i < zlhip_engine::Bounce::NBUF; ++i) {
+        if (e->bnc.bus[i]) (void)hipFree(e->bnc.bus[i]);
+        if (e->bnc.pcm[i]) (void)hipFree(e->bnc.pcm[i]);
+        if (e->bnc.rendered[i]) (void)hipEventDestroy(e->bnc.rendered[i]);
+        if (e->bnc.copied[i]) (void)hipEventDestroy(e->bnc.copied[i]);
     }
     if (e->planStream) (void)hipStreamDestroy(e->planStream);
     if (e->asmStream) (void)hipStreamDestroy(e->asmStream);
@@ -825,7 +843,9 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         }
     }
     const int nwin = (int)wins.size();
-    const bool overlap = e->ps[1].hdr != nullptr && (nwin > 1 || behindPrev);
+    // (a bounce queues its sub-batches back to back: planning on the planning stream from the first one on orders the second
+    // sub-batch's planning behind the first one's PLANNING, not behind its rendering)
+    const bool overlap = e->ps[1].hdr != nullptr && (nwin > 1 || behindPrev || e->bnc.active);
     hipStream_t ps = overlap ? e->planStream : s;
     // The call's inputs (clocks, voice operations, cleared statistics) go to the planning stream itself: it is in order
     // with the planning of the previous call, so window 0 of this call is planned while the previous call still renders.
@@ -913,6 +933,104 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     e->lastK = nblocks; e->lastN = nframes; e->lastBus = A.bus; e->lastWindows = nwin;
     e->outstanding = true; e->reportsFresh = true;
     return ZLHIP_OK;
+}
+
+// ---- offline bounce ---------------------------------------------------------------------------------
+int zlhip_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) return ZLHIP_ERR_INVALID;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes) == hipSuccess ? ZLHIP_OK : ZLHIP_ERR_CAPACITY;
+}
+
+void zlhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+static int bounce_body(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_clock *clocks, void *host_out, bool pcm, int64_t sub)
+{
+    constexpr int NBUF = zlhip_engine::Bounce::NBUF;
+    zlhip_engine::Bounce &q = e->bnc;
+    const int B = e->cfg.num_buses;
+    const size_t total = (size_t)nblocks * (size_t)nframes;          // frames per bus channel in host_out
+    static const bool stamps = std::getenv("ZL_BOUNCE_STAMPS") != nullptr;     // diagnostics: host time of every step (stderr)
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t00 = stamps ? now_us() : 0.0;
+    int j = 0;
+    for (int64_t k0 = 0; k0 < nblocks; k0 += sub, ++j) {
+        const int nb = (int)std::min<int64_t>(sub, nblocks - k0);
+        const int i = j % NBUF;
+        const size_t frames = (size_t)nb * (size_t)nframes;
+        // the buffer is free again when the sub-batch rendered into it three sub-batches ago has left it
+        if (j >= NBUF) ZL_HIP(e, hipStreamWaitEvent(e->stream, q.copied[i], 0));
+        const double t0 = stamps ? now_us() : 0.0;
+        int rc = zlhip_render_batch_fanout(e, nb, nframes, clocks + k0, q.bus[i], nullptr, nullptr, nullptr);
+        if (rc != ZLHIP_OK) return rc;
+        const double t1 = stamps ? now_us() : 0.0;
+        const size_t off = (size_t)k0 * (size_t)nframes * 4;         // byte offset of block k0 in a row of host_out (4 bytes per frame and row in both formats)
+        // delivery by the copy engine (SDMA), not by a kernel storing to mapped host memory: measured, a kernel on the copy stream gets no
+        // compute units while the next sub-batch's render kernel fills the chip (5.5 ms against 4.1 ms for the bench shape)
+        if (pcm) ZL_KERNEL(e, zl_launch_deliver(q.bus[i], q.pcm[i], 1, B, (long long)frames, (long long)frames, e->stream));
+        ZL_HIP(e, hipEventRecord(q.rendered[i], e->stream));
+        ZL_HIP(e, hipStreamWaitEvent(q.copyStream, q.rendered[i], 0));
+        // rows of frames * 4 bytes: [B][total][2] 16-bit = one per bus, [B][2][total] fp32 = one per bus channel
+        ZL_HIP(e, hipMemcpy2DAsync((char *)host_out + off, total * 4, pcm ? (const void *)q.pcm[i] : (const void *)q.bus[i], frames * 4, frames * 4,
+                                   pcm ? (size_t)B : (size_t)B * 2, hipMemcpyDeviceToHost, q.copyStream));
+        ZL_HIP(e, hipEventRecord(q.copied[i], q.copyStream));
+        if (stamps) std::fprintf(stderr, "zlhip_bounce sub-batch %d: at %.0f us, render_batch %.0f us, delivery commands %.0f us\n", j, t0 - t00, t1 - t0, now_us() - t1);
+    }
+    const double t2 = stamps ? now_us() : 0.0;
+    ZL_HIP(e, hipStreamSynchronize(q.copyStream));
+    if (stamps) std::fprintf(stderr, "zlhip_bounce: commands done at %.0f us, delivered at %.0f us\n", t2 - t00, now_us() - t00);
+    return ZLHIP_OK;
+}
+
+int zlhip_bounce(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_clock *clocks, void *host_out, int32_t format, int32_t sub_blocks)
+{
+    if (!e || !clocks || !host_out || nblocks < 1 || !(format == ZLHIP_BOUNCE_F32_PLANAR || format == ZLHIP_BOUNCE_PCM16_STEREO)) return ZLHIP_ERR_INVALID;
+    if (nframes < 64 || nframes > e->cfg.max_frames || (nframes % 64) != 0 || (nframes > 256 && (nframes % 256) != 0))
+        return fail(e, ZLHIP_ERR_INVALID, "nframes must be a multiple of 64 (of 256 above 256) and <= max_frames");
+    ZL_HIP(e, hipSetDevice(e->device));
+    constexpr int NBUF = zlhip_engine::Bounce::NBUF;
+    const int B = e->cfg.num_buses;
+    // sub-batches: long enough that a K2 launch is efficient and its planning hides behind the previous one, short enough that the
+    // first delivery starts early and the last one is short (a sixth of the bounce)
+    int64_t sub = sub_blocks > 0 ? sub_blocks : std::max<int64_t>(256, (nblocks + 5) / 6);
+    sub = std::min<int64_t>(std::min<int64_t>(sub, e->cfg.max_batch_blocks), nblocks);
+    const bool pcm = format == ZLHIP_BOUNCE_PCM16_STEREO;
+    zlhip_engine::Bounce &q = e->bnc;
+    if (!q.copyStream) {
+        ZL_HIP(e, hipStreamCreateWithFlags(&q.copyStream, hipStreamNonBlocking));
+        for (int i = 0; i < NBUF; ++i) {
+            ZL_HIP(e, hipEventCreateWithFlags(&q.rendered[i], hipEventDisableTiming));
+            ZL_HIP(e, hipEventCreateWithFlags(&q.copied[i], hipEventDisableTiming));
+        }
+    }
+    const size_t needFloats = (size_t)B * 2 * (size_t)sub * (size_t)nframes, needFrames = (size_t)B * (size_t)sub * (size_t)nframes;
+    if (q.busFloats < needFloats || (pcm && q.pcmFrames < needFrames)) {
+        { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
+        ZL_HIP(e, hipStreamSynchronize(q.copyStream));
+        for (int i = 0; i < NBUF; ++i) {
+            if (q.busFloats < needFloats) {
+                if (q.bus[i]) { ZL_HIP(e, hipFree(q.bus[i])); q.bus[i] = nullptr; }
+                ZL_HIP(e, hipMalloc((void **)&q.bus[i], needFloats * sizeof(float)));
+            }
+            if (pcm && q.pcmFrames < needFrames) {
+                if (q.pcm[i]) { ZL_HIP(e, hipFree(q.pcm[i])); q.pcm[i] = nullptr; }
+                ZL_HIP(e, hipMalloc((void **)&q.pcm[i], needFrames * 2 * sizeof(int16_t)));
+            }
+        }
+        q.busFloats = std::max(q.busFloats, needFloats);
+        if (pcm) q.pcmFrames = std::max(q.pcmFrames, needFrames);
+    }
+    q.active = true;
+    const int rc = bounce_body(e, nblocks, nframes, clocks, host_out, pcm, sub);
+    q.active = false;
+    // (also after an error: nothing of this call may still be writing the caller's buffer when it returns)
+    const hipError_t cs = hipStreamSynchronize(q.copyStream);
+    const int w = engine_wait(e);
+    e->outstanding = false;
+    if (rc != ZLHIP_OK) return rc;
+    if (cs != hipSuccess) { e->err = std::string("bounce copy stream: ") + hipGetErrorString(cs); return ZLHIP_ERR_HIP; }
+    return w;
 }
 
 int zlhip_synchronize(zlhip_engine *e)

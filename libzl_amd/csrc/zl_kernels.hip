@@ -1388,6 +1388,29 @@ __global__ void __launch_bounds__(256) zl_k_passthrough(const ZlPassParams *para
     }
 }
 
+// Bounce delivery (zlhip_bounce): a rendered sub-batch [B][2][frames] fp32 leaves the device buffer for its place in the caller's
+// buffer, whose rows are `total` frames long.  PCM = the recorder's 16-bit format (zl_render.h, zl_pcm16), [B][total][2]; otherwise
+// the floats as they are, [B][2][total].  Four frames per lane: 16-byte loads, one (PCM) or two 16-byte stores.  The engine uses it
+// for the 16-bit conversion into a device staging buffer (total = frames); the copy engine moves the rows to the host.
+template <bool PCM>
+__global__ void __launch_bounds__(256) zl_k_deliver(const float *bus, void *out, long long frames, long long total)
+{
+    const int b = blockIdx.y;
+    const float4 *L = reinterpret_cast<const float4 *>(bus + (size_t)b * 2 * frames), *R = reinterpret_cast<const float4 *>(bus + ((size_t)b * 2 + 1) * frames);
+    const long long nvec = frames / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const float4 l = L[i], r = R[i];
+        if (PCM) {
+            auto pair = [](float a, float c) { return (uint32_t)(uint16_t)zl_pcm16(a) | ((uint32_t)(uint16_t)zl_pcm16(c) << 16); };
+            reinterpret_cast<uint4 *>(static_cast<int16_t *>(out) + (size_t)b * 2 * total)[i] = make_uint4(pair(l.x, r.x), pair(l.y, r.y), pair(l.z, r.z), pair(l.w, r.w));
+        } else {
+            float *o = static_cast<float *>(out) + (size_t)b * 2 * total;
+            reinterpret_cast<float4 *>(o)[i] = l;
+            reinterpret_cast<float4 *>(o + total)[i] = r;
+        }
+    }
+}
+
 // planar (L, R) -> interleaved arena layout; R == nullptr copies mono
 __global__ void zl_k_interleave(const float *L, const float *R, float *dst, int length, int pad)
 {
@@ -1525,6 +1548,17 @@ int zl_launch_passthrough(const void *params_dev, const float *in, float *out, i
     if (nb < 1) nb = 1;
     if (vec) hipLaunchKernelGGL(zl_k_passthrough<4>, dim3((unsigned)nb, B), dim3(256), 0, s, (const ZlPassParams *)params_dev, in, out, frames);
     else     hipLaunchKernelGGL(zl_k_passthrough<1>, dim3((unsigned)nb, B), dim3(256), 0, s, (const ZlPassParams *)params_dev, in, out, frames);
+    ZL_LAUNCH_CHECK();
+    return 0;
+}
+
+int zl_launch_deliver(const float *bus, void *out, int pcm16, int B, long long frames, long long total, hipStream_t s)
+{
+    long long nb = (frames / 4 + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    if (pcm16) hipLaunchKernelGGL(zl_k_deliver<true>, dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, frames, total);
+    else       hipLaunchKernelGGL(zl_k_deliver<false>, dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, frames, total);
     ZL_LAUNCH_CHECK();
     return 0;
 }

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/libzl_hotpath.h"
+#include "zl_render.h"       // zl_pcm16: the recorder's 16-bit sample format
 
 namespace {
 
@@ -371,33 +372,44 @@ int libzl_wav_read(const char *path, float **left, float **right, int *length, d
 
 void libzl_wav_free(float *plane) { std::free(plane); }
 
-int libzl_wav_write(const char *path, const float *left, const float *right, int length, double sampleRate, int bitsPerSample)
+static void wav_header(unsigned char *h, uint32_t frames, int ch, double sampleRate, int bitsPerSample)
 {
-    if (!path || !left || length < 0 || !(bitsPerSample == 16 || bitsPerSample == 32)) return ZLHIP_ERR_INVALID;
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return ZLHIP_ERR_INVALID;
-    const int ch = right ? 2 : 1, bytesPer = bitsPerSample / 8;
-    const uint32_t dataBytes = (uint32_t)length * ch * bytesPer, rate = (uint32_t)sampleRate;
-    unsigned char h[44];
+    const int bytesPer = bitsPerSample / 8;
+    const uint32_t dataBytes = frames * (uint32_t)ch * (uint32_t)bytesPer, rate = (uint32_t)sampleRate;
     auto w32 = [&](int o, uint32_t v) { h[o] = v & 255; h[o + 1] = (v >> 8) & 255; h[o + 2] = (v >> 16) & 255; h[o + 3] = (v >> 24) & 255; };
     auto w16 = [&](int o, uint16_t v) { h[o] = v & 255; h[o + 1] = (v >> 8) & 255; };
     std::memcpy(h, "RIFF", 4); w32(4, 36 + dataBytes); std::memcpy(h + 8, "WAVEfmt ", 8); w32(16, 16);
     w16(20, bitsPerSample == 32 ? 3 : 1); w16(22, (uint16_t)ch); w32(24, rate); w32(28, rate * ch * bytesPer); w16(32, (uint16_t)(ch * bytesPer));
     w16(34, (uint16_t)bitsPerSample); std::memcpy(h + 36, "data", 4); w32(40, dataBytes);
-    std::fwrite(h, 1, 44, f);
+}
+
+int libzl_wav_write(const char *path, const float *left, const float *right, int length, double sampleRate, int bitsPerSample)
+{
+    if (!path || !left || length < 0 || !(bitsPerSample == 16 || bitsPerSample == 32)) return ZLHIP_ERR_INVALID;
+    const int ch = right ? 2 : 1;
+    // interleave (and convert) in memory, then one write: the format of the reference's recorder (AudioLevels.cpp:53-58), zl_pcm16
+    std::vector<unsigned char> data((size_t)length * ch * (bitsPerSample / 8));
     for (int i = 0; i < length; ++i) {
         for (int c = 0; c < ch; ++c) {
             const float v = c ? right[i] : left[i];
-            if (bitsPerSample == 32) std::fwrite(&v, 4, 1, f);
-            else {
-                const float cl = std::max(-1.0f, std::min(1.0f, v));
-                const int16_t s = (int16_t)std::lrintf(cl * 32767.0f);
-                std::fwrite(&s, 2, 1, f);
-            }
+            if (bitsPerSample == 32) std::memcpy(&data[((size_t)i * ch + c) * 4], &v, 4);
+            else { const int16_t q = zl_pcm16(v); std::memcpy(&data[((size_t)i * ch + c) * 2], &q, 2); }
         }
     }
-    std::fclose(f);
-    return ZLHIP_OK;
+    return libzl_wav_write_interleaved(path, data.data(), length, ch, sampleRate, bitsPerSample);
+}
+
+int libzl_wav_write_interleaved(const char *path, const void *frames, int length, int channels, double sampleRate, int bitsPerSample)
+{
+    if (!path || (!frames && length > 0) || length < 0 || channels < 1 || channels > 2 || !(bitsPerSample == 16 || bitsPerSample == 32)) return ZLHIP_ERR_INVALID;
+    if ((uint64_t)length * (uint64_t)channels * (uint64_t)(bitsPerSample / 8) > 0xffffffffull - 36) return ZLHIP_ERR_CAPACITY;   // RIFF sizes are 32 bit
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return ZLHIP_ERR_INVALID;
+    unsigned char h[44];
+    wav_header(h, (uint32_t)length, channels, sampleRate, bitsPerSample);
+    const size_t bytes = (size_t)length * channels * (bitsPerSample / 8);
+    const bool ok = std::fwrite(h, 1, 44, f) == 44 && (bytes == 0 || std::fwrite(frames, 1, bytes, f) == bytes);
+    return (std::fclose(f) == 0 && ok) ? ZLHIP_OK : ZLHIP_ERR_INVALID;
 }
 
 // ---- engine lifecycle -----------------------------------------------------------------------------

@@ -129,3 +129,19 @@ ZL_HD inline void zl_render_frame(const ZlVoiceConst &vc, const float *src, doub
     zl_mix_frame<MODE>(t, alpha, inb, wide, stereo, vc.lgain, vc.rgain, env, vc.clip_volume, vc.lpan, vc.rpan, lout, rout);
     pos_out = pos;
 }
+
+// One sample of a 16-bit WAV as the reference's recorder writes it (AudioLevels.cpp:53-58: a juce::WavAudioFormat writer, 16 bit,
+// fed floats through AudioFormatWriter::ThreadedWriter): float -> 32-bit fixed point (clamped at +-1, times 0x7fffffff in double,
+// round to nearest even) -> its upper 16 bits.  JUCE is not in the tree: restated from its public source (convertFloatsToInts +
+// the Int32 -> Int16 little-endian write), version unpinned like the ADSR.  NaN, which JUCE leaves
+// undefined, is written as 0.  The reader side (zl_libzl.cpp, libzl_wav_read) is the inverse convention.
+ZL_HD inline int16_t zl_pcm16(float x)
+{
+    const double d = (double)x;
+    int32_t q;
+    if (d <= -1.0) q = INT32_MIN;
+    else if (d >= 1.0) q = INT32_MAX;
+    else if (d != d) q = 0;
+    else q = (int32_t)rint(2147483647.0 * d);                   // |.| < 2^31: fits
+    return (int16_t)(q >> 16);
+}

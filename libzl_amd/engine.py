@@ -52,6 +52,18 @@ def synthetic_clocks(nblocks: int, nframes: int, sample_rate: float, start_block
     return arr
 
 
+def pinned_array(lib, shape, dtype) -> np.ndarray:
+    """A numpy array in page-locked host memory (zlhip_host_alloc); freed when the array and its views are gone."""
+    import weakref
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    if lib.zlhip_host_alloc(max(nbytes, 1), C.byref(p)) != 0 or not p.value:
+        raise MemoryError(f"zlhip_host_alloc({nbytes}) failed")
+    buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+    weakref.finalize(buf, lib.zlhip_host_free, p.value)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 @dataclass
 class BatchResult:
     bus: np.ndarray            # [num_buses, 2, nblocks*nframes] float32
@@ -193,6 +205,23 @@ class SamplerSynth:
 
     def synchronize(self):
         self._ck(self._lib.zlhip_synchronize(self._e), "synchronize")
+
+    def bounce(self, nblocks: int, nframes: int, clocks, fmt: str = "f32", sub_blocks: int = 0, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Offline bounce to HOST memory (zlhip_bounce): "f32" -> float32 [num_buses, 2, nblocks*nframes]; "pcm16" -> int16
+        [num_buses, nblocks*nframes, 2], the data chunk of one 16-bit stereo WAV per bus.  Without `out` the result lives in
+        page-locked memory owned by the returned array."""
+        pcm = {"f32": False, "pcm16": True}[fmt]
+        shape = (self.num_buses, nblocks * nframes, 2) if pcm else (self.num_buses, 2, nblocks * nframes)
+        dtype = np.int16 if pcm else np.float32
+        if out is None:
+            out = pinned_array(self._lib, shape, dtype)
+        if out.shape != shape or out.dtype != dtype or not out.flags.c_contiguous:
+            raise ValueError(f"bounce: out must be a C-contiguous {np.dtype(dtype).name} array of shape {shape}")
+        self._ck(self._lib.zlhip_bounce(self._e, nblocks, nframes, C.cast(clocks, C.c_void_p), out.ctypes.data, 1 if pcm else 0, sub_blocks), "bounce")
+        # what read_bus / block_peaks / levels_tick see afterwards: the last sub-batch (the split of zlhip_bounce)
+        sub = min(sub_blocks if sub_blocks > 0 else max(256, (nblocks + 5) // 6), self.cfg.max_batch_blocks, nblocks)
+        self._last = (nblocks - sub * ((nblocks - 1) // sub), nframes)
+        return out
 
     def read_bus(self) -> np.ndarray:
         K, N = self._last

@@ -76,6 +76,7 @@ SIGNATURES = {
     "libzl_wav_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "libzl_wav_free": (None, [C.POINTER(C.c_float)]),
     "libzl_wav_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int]),
+    "libzl_wav_write_interleaved": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int]),
 }
 
 

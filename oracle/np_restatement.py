@@ -460,3 +460,12 @@ def passthrough(inL, inR, dry, fx1, fx2, pan, muted):
             out[2 * k][f] = f32(f32(amt * f32(inL[f])) * lm)
             out[2 * k + 1][f] = f32(f32(amt * f32(inR[f])) * rm)
     return out
+
+
+def pcm16(x):
+    """16-bit samples of the recorder (AudioLevels.cpp:53-58: juce::WavAudioFormat 16 bit; restated from public JUCE source, version
+    unpinned): clamp, INT_MAX * x in double rounded half to even, upper 16 bits.  NaN -> 0."""
+    d = np.asarray(x, dtype=np.float32).astype(np.float64)
+    q = np.rint(2147483647.0 * np.where(np.isnan(d), 0.0, np.clip(d, -1.0, 1.0)))
+    q = np.where(d <= -1.0, -2147483648.0, np.where(d >= 1.0, 2147483647.0, q)).astype(np.int64)
+    return (q >> 16).astype(np.int16)

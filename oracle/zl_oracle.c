@@ -746,6 +746,28 @@ float zlo_block_rms(const float *x, uint32_t n, uint32_t off)
     return n ? sqrtf(zlo_block_sumsq(x, n, off) / (float)n) : 0.0f;
 }
 
+/* =============================== recorder sample format ====================================== */
+/* 16-bit WAV samples as the reference's recorder writes them: AudioLevels.cpp:53-58 creates a juce::WavAudioFormat writer with
+ * bitRate 16 and feeds it float blocks through AudioFormatWriter::ThreadedWriter (:72-76).  JUCE is not in the tree;
+ * restated from its public source, version unpinned: AudioFormatWriter::write converts floats to 32-bit fixed point
+ * (x <= -1 -> INT_MIN, x >= 1 -> INT_MAX, else roundToInt(INT_MAX * (double) x), round half to even) and the WAV writer stores
+ * the upper 16 bits little-endian.  NaN (undefined in JUCE) is written as 0.  Stereo frames interleaved L, R. */
+int16_t zlo_pcm16_sample(float x)
+{
+    const double d = (double)x;
+    int32_t q;
+    if (d <= -1.0) q = INT32_MIN;
+    else if (d >= 1.0) q = INT32_MAX;
+    else if (d != d) q = 0;
+    else q = (int32_t)nearbyint(2147483647.0 * d);
+    return (int16_t)(q >> 16);
+}
+
+void zlo_pcm16_stereo(const float *L, const float *R, uint32_t n, int16_t *out)
+{
+    for (uint32_t i = 0; i < n; ++i) { out[2 * i] = zlo_pcm16_sample(L[i]); out[2 * i + 1] = zlo_pcm16_sample(R[i]); }
+}
+
 /* =============================== JackPassthrough ============================================= */
 
 void zlo_passthrough_init(zlo_passthrough *p)                   /* JackPassthrough.cpp:27-31 */

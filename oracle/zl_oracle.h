@@ -236,6 +236,10 @@ void    zlo_levels_tick(zlo_levels_channel *c, const float *L, const float *R, u
 float   zlo_block_sumsq(const float *x, uint32_t n, uint32_t off);
 float   zlo_block_rms(const float *x, uint32_t n, uint32_t off);
 
+/* ---- recorder sample format (AudioLevels.cpp:53-58,72-76; juce::WavAudioFormat 16 bit, restated, version unpinned) ---- */
+int16_t zlo_pcm16_sample(float x);
+void    zlo_pcm16_stereo(const float *L, const float *R, uint32_t n, int16_t *out);     /* out [n][2] */
+
 /* ---- JackPassthrough (JackPassthrough.cpp:45-115) ------------------------------------------ */
 typedef struct zlo_passthrough {
     float dryAmount, wetFx1Amount, wetFx2Amount, panAmount;

@@ -154,6 +154,8 @@ _SIGS = {
     "zlo_levels_tick": (None, [C.POINTER(LevelsChannel), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "zlo_block_sumsq": (C.c_float, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "zlo_block_rms": (C.c_float, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "zlo_pcm16_sample": (C.c_int16, [C.c_float]),
+    "zlo_pcm16_stereo": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zlo_passthrough_init": (None, [C.POINTER(Passthrough)]),
     "zlo_passthrough_process": (None, [C.POINTER(Passthrough), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]),
     "zlo_render_batch": (None, [C.POINTER(Channel), C.c_int32, C.POINTER(Sound), C.POINTER(Clip), C.POINTER(Clock), C.c_uint32, C.c_uint32,

@@ -131,17 +131,19 @@ def run_oracle(scene: Scene, batch: int = 1 << 30, threads: int = 1, fast: bool 
 
 
 def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bool = False, force_slow: bool = False,
-                pipelined: bool = False, no_periodic: bool = False, fanout=None, **factory_kw):
+                pipelined: bool = False, no_periodic: bool = False, fanout=None, bounce=None, **factory_kw):
     """factory(**kwargs) -> object with the libzl_amd.SamplerSynth surface (engine or CPU harness).
     pipelined (GPU engine only): every call renders into its own device buffer on one HIP stream and nothing is read
     back or synchronised until the end, so consecutive zlhip_render_batch calls overlap.
     fanout (GPU engine only): a PassthroughParams per bus; every call also writes the fused JackPassthrough fan-out, which
-    is left in syn.fan_result as [num_buses][6][frames]."""
+    is left in syn.fan_result as [num_buses][6][frames].
+    bounce (GPU engine only): (format, sub_blocks) -- every segment between events goes through zlhip_bounce in sub-batches of
+    sub_blocks blocks (the engine is created with max_batch_blocks = sub_blocks); "pcm16" results are [num_buses][frames][2]."""
     # the oracle's setters are the single source of clip parameters for both sides
     ref = zo.OracleSynth(1, 1, scene.fs, scene.mode, max_sounds=max(8, len(scene.sounds)))
     syn = factory(num_buses=scene.num_buses, voices_per_bus=scene.voices_per_bus, mode=scene.mode,
                   playback_sample_rate=scene.fs, voices_per_task=scene.mix_group, max_frames=max(64, scene.nframes),
-                  max_batch_blocks=max(1, min(batch, scene.nblocks)), max_sounds=max(8, len(scene.sounds)),
+                  max_batch_blocks=max(1, min(bounce[1] if bounce else batch, scene.nblocks)), max_sounds=max(8, len(scene.sounds)),
                   sound_arena_bytes=max(1 << 20, sum((s[0].shape[0] + 16) * 8 for s in scene.sounds) + (1 << 16)), **factory_kw)
     for i, (L, R, sr) in enumerate(scene.sounds):
         assert ref.register_clip(L, R, sr) == i
@@ -170,6 +172,9 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
         if fanout is not None:
             fans.append(torch.full((scene.num_buses, 6, n * scene.nframes), 7.0, device="cuda", dtype=torch.float32))
             fan_kw = dict(fan_params=fanout, fan_out_dev=fans[-1].data_ptr())
+        if bounce is not None:
+            buses.append(np.array(syn.bounce(n, scene.nframes, scene.make_clocks(k0, n), fmt=bounce[0], sub_blocks=bounce[1]), copy=True))
+            continue
         if pipelined:
             out = torch.zeros((scene.num_buses, 2, n * scene.nframes), device="cuda", dtype=torch.float32)
             syn.render_batch(n, scene.nframes, scene.make_clocks(k0, n), bus_out_dev=out.data_ptr(), stream=stream.cuda_stream, **fan_kw)
@@ -188,7 +193,7 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
         torch.cuda.synchronize()
         syn.fan_result = np.concatenate([f.cpu().numpy() for f in fans], axis=2)
     reports = syn.voice_reports()
-    return np.concatenate(buses, axis=2), reports, syn, (np.concatenate(traces, axis=0) if traces else None)
+    return np.concatenate(buses, axis=1 if (bounce and bounce[0] == "pcm16") else 2), reports, syn, (np.concatenate(traces, axis=0) if traces else None)
 
 
 def oracle_trace(scene: Scene):

@@ -1,0 +1,111 @@
+"""Offline bounce (zlhip_bounce, BASELINE configs[4]) and the recorder's 16-bit sample format (AudioLevels.cpp:53-58)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import np_restatement as npr
+from oracle import zl_oracle as zo
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def Engine(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; the engine has no CPU path")
+    from libzl_amd import SamplerSynth
+    return SamplerSynth
+
+
+def test_pcm16_known_answers_and_restatements_agree(built):
+    lib = zo.load()
+    # hand-derived: q = rint(0x7fffffff * x) (half to even), sample = q >> 16 (arithmetic: towards minus infinity)
+    kat = [(0.0, 0), (1.0, 32767), (-1.0, -32768), (2.0, 32767), (-3.0, -32768), (0.5, 16384), (-0.5, -16384),
+           (2.0 ** -15, 1), (2.0 ** -16, 0), (-1e-9, -1), (1e-9, 0), (float("inf"), 32767), (float("-inf"), -32768), (float("nan"), 0),
+           (0.999969482421875, 32766), (np.nextafter(f32(1.0), f32(0.0)), 32767)]
+    for x, want in kat:
+        assert lib.zlo_pcm16_sample(float(f32(x))) == want, (x, want)
+        assert int(npr.pcm16(np.array([x], dtype=f32))[0]) == want, (x, want)
+    rng = np.random.default_rng(16)
+    x = np.concatenate([rng.uniform(-1.2, 1.2, 100000), rng.normal(0, 1e-4, 20000), (np.arange(-40000, 40000) + 0.5) / 32768.0]).astype(f32)
+    out = np.empty((len(x), 2), dtype=np.int16)
+    lib.zlo_pcm16_stereo(x.ctypes.data, x[::-1].copy().ctypes.data, len(x), out.ctypes.data)
+    assert np.array_equal(out[:, 0], npr.pcm16(x)) and np.array_equal(out[:, 1], npr.pcm16(x[::-1]))
+
+
+def test_wav_16_bit_files_hold_the_recorder_format(built, tmp_path):
+    from libzl_amd import libzl
+    zl = libzl.load()
+    rng = np.random.default_rng(17)
+    L = rng.uniform(-1.1, 1.1, 999).astype(f32); R = rng.uniform(-1.1, 1.1, 999).astype(f32)
+    a, b = str(tmp_path / "a.wav").encode(), str(tmp_path / "b.wav").encode()
+    assert zl.libzl_wav_write(a, L.ctypes.data, R.ctypes.data, len(L), 48000.0, 16) == 0
+    frames = np.stack([npr.pcm16(L), npr.pcm16(R)], axis=1).copy()
+    assert zl.libzl_wav_write_interleaved(b, frames.ctypes.data, len(L), 2, 48000.0, 16) == 0
+    blob = open(a, "rb").read()
+    assert blob == open(b, "rb").read()
+    assert blob[:4] == b"RIFF" and blob[36:40] == b"data" and np.array_equal(np.frombuffer(blob[44:], dtype="<i2").reshape(-1, 2), frames)
+    assert zl.libzl_wav_write_interleaved(b, frames.ctypes.data, len(L), 3, 48000.0, 16) != 0      # mono or stereo only
+    assert zl.libzl_wav_write_interleaved(b, None, 4, 2, 48000.0, 16) != 0
+
+
+@pytest.mark.gpu
+def test_bounce_equals_consecutive_batches_and_the_oracle(Engine):
+    """A scene with commands in the middle: every stretch between events is one zlhip_bounce call cut into ragged sub-batches;
+    the host buffers hold the oracle's mix bit for bit, and reports / levels carry on as after zlhip_render_batch."""
+    from scenario import compare_runs, random_scene, run_backend, run_oracle
+    sc = random_scene(0xB0, num_buses=5, voices_per_bus=8, nclips=12, nframes=128, nblocks=61)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, bounce=("f32", 7))
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 40)
+    # the engine's own last sub-batch is still readable on the device side, with its levels
+    last = syn.read_bus()
+    K = last.shape[2] // sc.nframes
+    assert np.array_equal(last.view(np.int32), bus[:, :, -last.shape[2]:].view(np.int32))
+    exp = np.abs(f32(131072.0) * last.reshape(5, 2, K, sc.nframes)).astype(np.int64).max(axis=3).transpose(2, 0, 1)
+    assert np.array_equal(syn.block_peaks(), exp)
+    syn.close()
+    pcm, _, syn, _ = run_backend(sc, Engine, bounce=("pcm16", 7))
+    want = np.stack([npr.pcm16(ref_bus[:, 0]), npr.pcm16(ref_bus[:, 1])], axis=2)
+    assert np.array_equal(pcm, want)
+    syn.close()
+
+
+@pytest.mark.gpu
+def test_bounce_into_caller_memory_and_argument_checks(Engine):
+    from libzl_amd.engine import ZlHipError, synthetic_clocks
+    syn = Engine(num_buses=2, voices_per_bus=4, max_frames=256, max_batch_blocks=8, max_sounds=4)
+    rng = np.random.default_rng(3)
+    L = rng.uniform(-1, 1, 5000).astype(f32)
+    cid = syn.register_clip(L, None, 48000.0)
+    from scenario import engine_cmd, play_cmd
+    syn.handle_clip_command(engine_cmd(**play_cmd(cid)), 0)
+    clocks = synthetic_clocks(20, 256, 48000.0)
+    out = np.full((2, 2, 20 * 256), 9.0, dtype=f32)               # pageable memory of the caller: works, through staging copies
+    got = syn.bounce(20, 256, clocks, out=out)
+    assert got is out and np.abs(out[0]).max() > 0.1 and not (out == 9.0).any()
+    pinned = syn.bounce(20, 256, synthetic_clocks(20, 256, 48000.0, start_block=20))
+    assert pinned.shape == out.shape and np.isfinite(pinned).all()
+    # both delivery paths (kernel stores into mapped page-locked memory / copy commands into pageable memory) give the same bytes
+    syn2 = Engine(num_buses=2, voices_per_bus=4, max_frames=256, max_batch_blocks=8, max_sounds=4)
+    syn2.register_clip(L, None, 48000.0)
+    syn2.handle_clip_command(engine_cmd(**play_cmd(cid)), 0)
+    first = syn2.bounce(20, 256, clocks)
+    assert np.array_equal(first.view(np.int32), out.view(np.int32))
+    pcm_pageable = syn.bounce(20, 256, synthetic_clocks(20, 256, 48000.0, start_block=40), fmt="pcm16", out=np.zeros((2, 20 * 256, 2), dtype=np.int16))
+    syn2.bounce(20, 256, synthetic_clocks(20, 256, 48000.0, start_block=20))
+    pcm_pinned = syn2.bounce(20, 256, synthetic_clocks(20, 256, 48000.0, start_block=40), fmt="pcm16")
+    assert np.array_equal(pcm_pageable, pcm_pinned) and np.abs(pcm_pinned.astype(np.int32)).max() > 3000
+    syn2.close()
+    with pytest.raises(ValueError):
+        syn.bounce(20, 256, clocks, out=np.zeros((2, 2, 5), dtype=f32))
+    with pytest.raises(ZlHipError):
+        syn.bounce(20, 100, clocks)                                # nframes not a multiple of 64
+    with pytest.raises(ZlHipError):
+        syn.bounce(0, 256, clocks)
+    syn.close()

@@ -306,6 +306,21 @@ def test_baseline_configs_4_96k_batched_bounce(Engine):
     bus, rep, syn, _ = run_backend(sc, Engine, batch=48, plan_window_blocks=16)
     compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, V)
     syn.close()
+    # the bounce proper (zlhip_bounce): the same blocks delivered to host memory in sub-batches of 10 (the last one ragged) while the
+    # next sub-batch renders; as floats, and in the recorder's 16-bit format converted on the GPU
+    bus, rep, syn, _ = run_backend(sc, Engine, bounce=("f32", 10), plan_window_blocks=4)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, V)
+    syn.close()
+    pcm, rep, syn, _ = run_backend(sc, Engine, bounce=("pcm16", 10))
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    for b in range(B):
+        want = np.empty((sc.nblocks * sc.nframes, 2), dtype=np.int16)
+        Lr, Rr = np.ascontiguousarray(ref_bus[b, 0]), np.ascontiguousarray(ref_bus[b, 1])
+        lib.zlo_pcm16_stereo(Lr.ctypes.data, Rr.ctypes.data, len(Lr), want.ctypes.data)
+        assert np.array_equal(pcm[b], want)
+    assert len(np.unique(pcm)) > 1000                              # (a real signal, not a constant)
+    syn.close()
 
 
 def test_baseline_configs_3_pitched_hermite_shard(Engine):

@@ -40,7 +40,8 @@ def test_wav_roundtrip_float_and_pcm16(zl, tmp_path):
     assert sr == 44100.0 and np.array_equal(l2, L) and np.array_equal(r2, R)
     l3, r3, _ = _read(zl, _wav(tmp_path, zl, L, None, 48000.0, 16, "b.wav"))
     assert r3 is None
-    q = np.rint(np.clip(L, -1, 1) * f32(32767.0)).astype(np.int32)
+    from oracle import np_restatement as npr
+    q = npr.pcm16(L).astype(np.int32)                              # the recorder's format (tests/test_bounce.py)
     np.testing.assert_array_equal(l3, (q << 16).astype(np.float32) * f32(1.0 / 2147483648.0))   # JUCE int->float convention
     assert zl.libzl_wav_read(b"/nonexistent.wav", C.byref(C.POINTER(C.c_float)()), C.byref(C.POINTER(C.c_float)()), C.byref(C.c_int()), C.byref(C.c_double())) != 0
     assert zl.ClipAudioSource_new(b"/nonexistent.wav", False) is None       # reference: failures are logged, not raised

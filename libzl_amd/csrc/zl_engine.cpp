@@ -135,9 +135,12 @@ struct zlhip_engine {
 
     // resident real-time kernel (zl_k_rt_loop): the mailbox in mapped host memory, its stream, what it was launched for
     struct Rt {
-        bool enabled = false, running = false;
+        bool enabled = false, running = false, wide = false;
         ZlRtShared *h = nullptr, *d = nullptr;
         ZlRtDev *dev = nullptr;                            // the kernel's own hand-off words in HBM
+        ZlOpRange *devRanges = nullptr;                    // wide buses: workgroup 0's copy of a block's operation ranges
+        int capacity[2] = {-1, -1};                        // workgroups of the kernel the device holds at once (narrow, wide); -1 = not asked yet
+        int vw = 0;                                        // wide buses: voices per resident workgroup (a divisor of voices_per_bus)
         hipStream_t stream = nullptr;
         int nframes = 0;
         unsigned long long seq = 0;
@@ -260,6 +263,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (e->rt.stream) (void)hipStreamDestroy(e->rt.stream);
     if (e->rt.h) (void)hipHostFree(e->rt.h);
     if (e->rt.dev) (void)hipFree(e->rt.dev);
+    if (e->rt.devRanges) (void)hipFree(e->rt.devRanges);
     for (auto &c : e->slots) if (c.inflight && c.done) (void)hipEventSynchronize(c.done);   // calls queued on a caller's stream
     for (hipEvent_t ev : e->joins) if (ev) (void)hipEventSynchronize(ev);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -461,6 +465,11 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         // ZL_RT_PERSISTENT=0 keeps the launched path
         const char *rp = std::getenv("ZL_RT_PERSISTENT");
         e->rt.enabled = !(rp && std::atoi(rp) == 0);
+        // ZL_RT_WIDE=1: wide buses (32 voices and more) through the resident kernel too, a workgroup per few voices.  Built, exact,
+        // and measured SLOWER than launches (1024 voices on 8 buses: 100 against 53 us; 256 voices: 66 against 44) -- every resident
+        // workgroup walks the K0..K2 latency chain of its voices alone, where a launch runs a thousand of them side by side: opt-in
+        const char *rw = std::getenv("ZL_RT_WIDE");
+        e->rt.wide = rw && std::atoi(rw) == 1;
         e->rt.stampsOn = std::getenv("ZL_RT_STAMPS") != nullptr;
     }
     e->hc.init(cfg->num_buses, cfg->voices_per_bus, cfg->max_sounds, cfg->playback_sample_rate);
@@ -1042,11 +1051,29 @@ int zlhip_synchronize(zlhip_engine *e)
     return ZLHIP_OK;
 }
 
-static bool rt_eligible(const zlhip_engine *e, int nframes)
+// wide buses: one resident workgroup per voice (the per-voice split of pick_group, inside the residency)
+static bool rt_wide(const zlhip_engine *e) { return e->cfg.voices_per_bus >= ZL_RT_SPLIT_MIN_VOICES; }
+
+static bool rt_eligible(zlhip_engine *e, int nframes)
 {
-    // one workgroup renders the whole cycle: buses summed whole (no per-voice split, no mix groups), one frame tile, no debug trace
-    return e->rt.enabled && nframes <= 256 && e->cfg.voices_per_task <= 0 && e->cfg.voices_per_bus < ZL_RT_SPLIT_MIN_VOICES && !e->trace
-           && e->cfg.num_buses <= 64;                             // one resident workgroup per bus
+    // the workgroups of one cycle are all resident: buses summed whole by one workgroup each (narrow) or one workgroup per voice and
+    // the ordered sum by the bus's last arrival (wide); the reference's summation order either way (no mix groups), one frame tile,
+    // no debug trace
+    if (!(e->rt.enabled && nframes <= 256 && e->cfg.voices_per_task <= 0 && !e->trace)) return false;
+    const bool wide = rt_wide(e);
+    if (wide && !e->rt.wide) return false;                         // opt-in (ZL_RT_WIDE=1): measured slower than launches
+    if (e->cfg.num_buses > (wide ? ZL_RT_MAX_BUSES : 64)) return false;
+    int &cap = e->rt.capacity[wide ? 1 : 0];
+    if (cap < 0) cap = zl_rt_loop_capacity(e->cfg.mode, wide ? 1 : 0, 256, e->device);
+    // (room is left for the level-tick and upload kernels of the same process: three quarters of the device at most)
+    if (!wide) return (long long)e->cfg.num_buses * 4 <= (long long)cap * 3;
+    // wide: as few voices per workgroup as the device holds (their K2 bodies run one after the other), never across a bus
+    if (e->rt.vw == 0) {
+        e->rt.vw = -1;
+        for (int vw = 1; vw <= 8; vw *= 2)
+            if (e->cfg.voices_per_bus % vw == 0 && (long long)(e->V / vw) * 4 <= (long long)cap * 3) { e->rt.vw = vw; break; }
+    }
+    return e->rt.vw > 0;
 }
 
 static int rt_start(zlhip_engine *e, int nframes)
@@ -1060,6 +1087,7 @@ static int rt_start(zlhip_engine *e, int nframes)
         std::memset(e->rt.h, 0, sizeof(ZlRtShared));
         ZL_HIP(e, hipStreamCreateWithFlags(&e->rt.stream, hipStreamNonBlocking));
         ZL_HIP(e, hipMalloc((void **)&e->rt.dev, sizeof(ZlRtDev)));
+        ZL_HIP(e, hipMalloc((void **)&e->rt.devRanges, (size_t)std::max(e->V, 1) * sizeof(ZlOpRange)));   // at most one range per voice
     }
     // the hand-off words start from the last block the previous residency finished
     {
@@ -1071,8 +1099,9 @@ static int rt_start(zlhip_engine *e, int nframes)
     zlhip_engine::PlanSet &q = e->ps[0];
     ZlBatch A; std::memset(&A, 0, sizeof A);
     A.V = e->V; A.B = e->cfg.num_buses; A.VPB = e->cfg.voices_per_bus; A.N = nframes; A.K = 1; A.Ktot = 1; A.k0 = 0;
-    A.G = A.VPB; A.groups = 1;
-    A.NB = 1;                                                       // one workgroup per bus
+    if (rt_wide(e)) { A.G = 1; A.groups = A.VPB; }                  // one workgroup per voice, the bus summed from partial rows (q.partials)
+    else { A.G = A.VPB; A.groups = 1; }                             // one workgroup per bus
+    A.NB = 1;
     A.clocks_regular = 1; A.inline_clock = 1; A.fuse_assemble = 1;
     A.mode = e->cfg.mode;
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena; A.voices = e->dVoices; A.reports = c.dReports; A.pass_cache = e->dPassCache;
@@ -1082,7 +1111,7 @@ static int rt_start(zlhip_engine *e, int nframes)
     A.ctl_slots = e->ctlSlotsOverride >= 0 ? std::min<int>(e->ctlSlotsOverride, (int)(e->ctlPoolFrames / (size_t)nframes)) : (int)std::min<size_t>(e->ctlPoolFrames / (size_t)nframes, 0x7fffffff);
     // (every cycle is a plan window of its own: its pool base travels in the mailbox)
     e->rt.h->state = 0;
-    ZL_KERNEL(e, zl_launch_rt_loop(A, e->rt.d, e->rt.dev, e->rt.seq, e->rt.idleTicks, e->dGain, c.hReportsDev, c.hGainDev, std::min(256, nframes), e->rt.stream));
+    ZL_KERNEL(e, zl_launch_rt_loop(A, e->rt.d, e->rt.dev, e->rt.seq, e->rt.idleTicks, e->dGain, c.hReportsDev, c.hGainDev, e->rt.devRanges, std::max(e->rt.vw, 1), std::min(256, nframes), e->rt.stream));
     e->rt.running = true; e->rt.nframes = nframes;
     return ZLHIP_OK;
 }
@@ -1111,6 +1140,7 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
     __atomic_store_n(&sh->cmd_seq, seq, __ATOMIC_RELEASE);
     // spin: a block takes some tens of microseconds.  The kernel may have left (idle timeout) just before the post: then start
     // it again -- it picks the posted block up at once (first_seq = the last block it saw finished).
+    const auto spin0 = std::chrono::steady_clock::now();
     for (unsigned long long spins = 0;; ++spins) {
         if (__atomic_load_n(&sh->done_seq, __ATOMIC_ACQUIRE) == seq) break;
         if ((spins & 0xfffu) == 0xfffu) {
@@ -1123,7 +1153,12 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
                 e->rt.seq = seq;
                 if (rc != ZLHIP_OK) return rc;
             }
-            if (spins > (1ull << 33)) return fail(e, ZLHIP_ERR_STATE, "resident real-time kernel does not answer");
+            // (two seconds: hundreds of block periods.  Stop asking the kernel for blocks and fall back to launches from now on)
+            if (std::chrono::steady_clock::now() - spin0 > std::chrono::seconds(2)) {
+                e->rt.enabled = false;
+                (void)rt_stop(e);
+                return fail(e, ZLHIP_ERR_STATE, "resident real-time kernel does not answer");
+            }
         }
     }
     const size_t B = (size_t)e->cfg.num_buses, N = (size_t)nframes;

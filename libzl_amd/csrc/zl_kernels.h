@@ -17,4 +17,5 @@ int zl_launch_interleave(const float *L, const float *R, float *dst, int length,
 int zl_launch_reduce_scan(const float *pieces, int npieces, long long stride, long long units, int N, int off, float *out, ZlUnitLevels *lv, hipStream_t s);
 int zl_launch_levels_import(const ZlUnitLevels *units, ZlBlockLevels *levels, int B, int K, hipStream_t s);
 int zl_launch_rt_loop(const ZlBatch &A, void *mailbox_dev, void *dev_state, unsigned long long first_seq, unsigned long long idle_ticks, float *gain_out,
-                      ZlReport *host_reports, float *host_gain, int threads, hipStream_t s);
+                      ZlReport *host_reports, float *host_gain, ZlOpRange *dev_ranges, int vw, int threads, hipStream_t s);
+int zl_rt_loop_capacity(uint32_t mode, int wide, int threads, int device);

@@ -1031,16 +1031,24 @@ __global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_M
 // HBM with agent-scope atomics; the last workgroup to finish (an arrival counter) tells the host.  Only workgroup 0 decides to
 // leave -- on a stop request or after idle_ticks (100 MHz) without a block -- and publishes that too, so every block is either
 // rendered by all workgroups or by none, and every wave reaches the exit.
-template <uint32_t MODE>
+//
+// WIDE (buses of 32 voices and more): one workgroup PER VOICE instead -- a single block has no other parallelism than its voices.
+// Every workgroup renders its voice into the bus's partial rows (K2 body with one voice per mix group); the workgroup that is the
+// last of its bus to arrive (a counter per bus, no waiting) sums the rows in voice order, 0 + v0 + v1 + ... -- the reference's
+// order, bit for bit (K3 body) -- writes the bus into host memory and scans its levels.  The voice-operation ranges of the block
+// are copied from host memory into HBM once, by workgroup 0 before it publishes the block (a thousand workgroups reading the
+// same host memory would queue on PCIe).  Hand-offs between workgroups on different XCDs use agent-scope release / acquire fences.
+static __device__ __forceinline__ void zl_k3_body(const ZlBatch &A, const float *bus_in, int k, int bus);
+template <uint32_t MODE, bool WIDE>
 __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared *sh, ZlRtDev *dev, unsigned long long first_seq, unsigned long long idle_ticks,
-                                                    float *gain_out, ZlReport *host_reports, float *host_gain)
+                                                    float *gain_out, ZlReport *host_reports, float *host_gain, ZlOpRange *dev_ranges, int vw)
 {
     __shared__ unsigned long long s_cmd[ZL_RT_CMD_WORDS + 1];     // [0] = the block's sequence number (0 with s_go = 0: leave)
-    __shared__ int s_go;
+    __shared__ int s_go, s_last;
     __shared__ ZlClock s_clk0;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int z = blockIdx.x, W = gridDim.x;                       // one workgroup per bus
-    const int vbeg = z * A0.VPB, vend = vbeg + A0.VPB;
+    const int z = blockIdx.x, W = gridDim.x;                       // one workgroup per bus (WIDE: per vw voices of one bus; vw divides VPB)
+    const int vbeg = WIDE ? z * vw : z * A0.VPB, vend = WIDE ? vbeg + vw : vbeg + A0.VPB;
     unsigned long long last = first_seq;
     if (z == 0 && tid == 0) __hip_atomic_store(&sh->state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (;;) {
@@ -1060,7 +1068,8 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
 #pragma unroll
                         for (int i = 0; i < ZL_RT_CMD_WORDS; ++i) { s_cmd[1 + i] = w[i]; __hip_atomic_store(&dev->cmd[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __hip_atomic_store(&dev->pub_seq, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (WIDE: published below, after the workgroup has copied the operation ranges)
+                        if (!WIDE) __hip_atomic_store(&dev->pub_seq, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_cmd[0] = q; go = 1;
                         break;
                     }
@@ -1080,7 +1089,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
                         s_cmd[0] = q; go = 1;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    if (WIDE) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);   // (a thousand pollers: longer naps)
                 }
             }
             s_go = go;
@@ -1096,11 +1105,30 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         A.clock0.current_usecs = s_cmd[5]; A.clock0.next_usecs = s_cmd[6]; A.clock0.playhead = s_cmd[7]; A.clock0.playhead_usecs = s_cmd[8];
         A.clock0.subbeat_usecs = s_cmd[9]; A.clock0.usecs_per_frame = s_cmd[10];
         A.inline_clock = 1; A.fuse_assemble = 1;
-        // ---- K0: the operations of this bus's voices (the ranges are sorted by voice; host memory, read in place -- behind a
-        //      system-scope acquire: the host reuses the same buffers every block and plain loads may hit stale cached lines)
-        if (A.n_op_ranges > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (WIDE && z == 0) {
+            // workgroup 0: the block's operation ranges host memory -> HBM (behind a system-scope acquire: the host reuses its buffers
+            // every block and plain loads may hit stale cached lines), then the block is published for the other workgroups
+            if (A.n_op_ranges > 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                for (int i = tid; i < A.n_op_ranges; i += (int)blockDim.x) dev_ranges[i] = A.op_ranges[i];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&dev->pub_seq, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- K0: the operations of this workgroup's voices (the ranges are sorted by voice).  Narrow buses read ranges and
+        //      operations in host memory in place (system-scope acquire, as above); wide buses read the ranges from workgroup 0's
+        //      copy in HBM (agent-scope acquire: it may sit in another XCD's L2) and only their own operations from host memory
+        if (A.n_op_ranges > 0) {
+            if (WIDE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        }
+        const ZlOpRange *ranges = WIDE ? dev_ranges : A.op_ranges;
         for (int i = tid; i < A.n_op_ranges; i += (int)blockDim.x) {
-            const ZlOpRange rg = A.op_ranges[i];
+            const ZlOpRange rg = ranges[i];
             if (rg.voice < vbeg || rg.voice >= vend) continue;
             ZlVoiceState st = A.voices[rg.voice];
             for (int j = 0; j < rg.count; ++j) zl_apply_op(st, A.ops[rg.first + j]);
@@ -1110,7 +1138,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         __threadfence_block();
         __syncthreads();
         if (z == 0 && tid == 0) sh->stamps[1] = __builtin_amdgcn_s_memrealtime();
-        // ---- K1: one lane per voice of the bus, the single block of this cycle
+        // ---- K1: one lane per voice of the workgroup, the single block of this cycle
         for (int v = vbeg + tid; v < vend; v += (int)blockDim.x) {
             ZlPlanner pl;
             pl.begin(A, v, 0);
@@ -1131,10 +1159,30 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         __threadfence_block();
         __syncthreads();
         if (z == 0 && tid == 0) sh->stamps[3] = __builtin_amdgcn_s_memrealtime();
-        // ---- K2: this bus
-        zl_k2_body<MODE, 1, false>(A, 0u, 0u, (unsigned)z, 1u, 1u);
+        // ---- K2: this bus (WIDE: each of this workgroup's voices into its own partial row: A.groups = voices per bus, one voice per group)
+        if (WIDE) { for (int v = vbeg; v < vend; ++v) zl_k2_body<MODE, 1, false>(A, 0u, 0u, (unsigned)v, 1u, 1u); }
+        else zl_k2_body<MODE, 1, false>(A, 0u, 0u, (unsigned)z, 1u, 1u);
         __threadfence_block();
         __syncthreads();
+        if (WIDE) {
+            // ---- the bus: the last of its workgroups to get here sums the partial rows in voice order, writes the mix, scans the levels
+            const int bus = vbeg / A.VPB;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // this voice's partial rows, for a workgroup that may run on another XCD
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int old = __hip_atomic_fetch_add(&dev->bus_arrive[bus], (unsigned int)vw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int lastOne = old + (unsigned int)vw == (unsigned int)A.VPB;
+                if (lastOne) __hip_atomic_store(&dev->bus_arrive[bus], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = lastOne;
+            }
+            __syncthreads();
+            if (s_last) {                                              // (uniform over the workgroup)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                zl_k3_body(A, nullptr, 0, bus);
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
         if (z == 0 && tid == 0) sh->stamps[4] = __builtin_amdgcn_s_memrealtime();
         // ---- reports (gain = peakGain * 0.5f, SamplerSynthVoice.cpp:266) straight into host memory
         for (int v = vbeg + tid; v < vend; v += (int)blockDim.x) {
@@ -1148,7 +1196,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (z == 0) sh->stamps[5] = __builtin_amdgcn_s_memrealtime();
             const unsigned int old = __hip_atomic_fetch_add(&dev->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned int)W - 1u) {                     // the last bus: the block is complete
+            if (old == (unsigned int)W - 1u) {                     // the last workgroup: the block is complete
                 __hip_atomic_store(&dev->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&sh->done_seq, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1189,9 +1237,9 @@ static __device__ __forceinline__ ZlBlockLevels zl_scan_rows(const float *inL, c
 // ------------------------------------------------------------------------------------------------
 // K3: one workgroup per (block, bus).  Sums the mix-group partials in group order (when there are
 // any), writes the bus, and scans it for the AudioLevels integer peak and the RMS extension.
-__global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const float *bus_in)
+static __device__ __forceinline__ void zl_k3_body(const ZlBatch &A, const float *bus_in, int k, int bus)
 {
-    const int k = blockIdx.x, bus = blockIdx.y, N = A.N;
+    const int N = A.N;
     const size_t KN = (size_t)A.Ktot * N;
     float *outL = A.bus ? A.bus + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N : nullptr;
     float *outR = outL ? outL + KN : nullptr;
@@ -1237,6 +1285,10 @@ __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const flo
         const ZlBlockLevels lv = zl_scan_rows(inL, inR, N, (A.mode & ZL_MODE_FIX_DELAY) ? 0 : 1, (int)threadIdx.x);
         if (threadIdx.x == 0) A.levels[(size_t)k * A.B + bus] = lv;
     }
+}
+__global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const float *bus_in)
+{
+    zl_k3_body(A, bus_in, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // K3 without partials to sum (the scan of an existing bus: N > 256, or a bus reduced over several GPUs): one WAVE per
@@ -1483,17 +1535,39 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEv
 }
 
 int zl_launch_rt_loop(const ZlBatch &A, void *mailbox_dev, void *dev_state, unsigned long long first_seq, unsigned long long idle_ticks, float *gain_out,
-                      ZlReport *host_reports, float *host_gain, int threads, hipStream_t s)
+                      ZlReport *host_reports, float *host_gain, ZlOpRange *dev_ranges, int vw, int threads, hipStream_t s)
 {
     ZlRtShared *sh = reinterpret_cast<ZlRtShared *>(mailbox_dev);
     ZlRtDev *dv = reinterpret_cast<ZlRtDev *>(dev_state);
+    const bool wide = A.groups > 1;                                // one workgroup per vw voices
     switch (A.mode & 7u) {
-#define ZL_CASE(M) case M: hipLaunchKernelGGL((zl_k_rt_loop<M>), dim3(A.B), dim3(threads), 0, s, A, sh, dv, first_seq, idle_ticks, gain_out, host_reports, host_gain); break;
+#define ZL_CASE(M) case M: \
+        if (wide) hipLaunchKernelGGL((zl_k_rt_loop<M, true>), dim3(A.V / vw), dim3(threads), 0, s, A, sh, dv, first_seq, idle_ticks, gain_out, host_reports, host_gain, dev_ranges, vw); \
+        else      hipLaunchKernelGGL((zl_k_rt_loop<M, false>), dim3(A.B), dim3(threads), 0, s, A, sh, dv, first_seq, idle_ticks, gain_out, host_reports, host_gain, dev_ranges, 0); \
+        break;
         ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
 #undef ZL_CASE
     }
     ZL_LAUNCH_CHECK();
     return 0;
+}
+
+// How many workgroups of the resident kernel the device holds at once (every one of them must be resident: a block is complete
+// when all have arrived).  0 on error.
+int zl_rt_loop_capacity(uint32_t mode, int wide, int threads, int device)
+{
+    int per_cu = 0, cus = 0;
+    hipError_t st = hipErrorUnknown;
+    switch (mode & 7u) {
+#define ZL_CASE(M) case M: \
+        st = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zl_k_rt_loop<M, true>, threads, 0) \
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zl_k_rt_loop<M, false>, threads, 0); \
+        break;
+        ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
+#undef ZL_CASE
+    }
+    if (st != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return per_cu * cus;
 }
 
 int zl_launch_finalize(const ZlBatch &A, const float *bus_in, hipStream_t s)

@@ -211,10 +211,12 @@ struct ZlRtShared {
 // workgroups (agent-scope atomics: eight-byte words, visible across XCDs without cache fences); `arrive` counts the workgroups
 // that have finished the block.
 #define ZL_RT_CMD_WORDS 12
+#define ZL_RT_MAX_BUSES 256
 struct ZlRtDev {
     unsigned long long pub_seq;                  // the block being rendered (~0ull: leave)
     unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words)
     unsigned int arrive, pad;
+    unsigned int bus_arrive[ZL_RT_MAX_BUSES];    // wide buses (one workgroup per voice): the voices of a bus that have written their partial mix
 };
 
 // Launch-wide arguments (passed by value to the kernels).

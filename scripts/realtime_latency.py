@@ -10,6 +10,7 @@ from libzl_amd.engine import synthetic_clocks
 
 def run(V, B, N, vpt=0, resident=False, blocks=10000, paced=False):
     os.environ["ZL_RT_PERSISTENT"] = "1" if resident else "0"
+    os.environ["ZL_RT_WIDE"] = "1" if resident else "0"         # (wide buses: opt-in, measured slower than launches)
     fs = 48000.0
     lf = 96000
     syn = SamplerSynth(B, V // B, max_frames=N, max_batch_blocks=4, max_sounds=V, playback_sample_rate=fs,
@@ -43,5 +44,9 @@ if __name__ == "__main__":
         run(96, 12, 128, resident=res, blocks=n)
     for res in (False, True):
         run(96, 12, 256, resident=res, blocks=1500, paced=True)
-    if not quick:
-        run(1024, 8, 128); run(1024, 8, 256); run(1024, 8, 256, vpt=16)   # wide buses: the launched path (per-voice split + K3)
+    if not quick or "--wide" in sys.argv:
+        # wide buses: launched (per-voice split + K3) against resident (one workgroup per few voices, the bus summed by its last arrival)
+        for res in (False, True):
+            run(1024, 8, 128, resident=res, blocks=n); run(1024, 8, 256, resident=res, blocks=n); run(256, 8, 256, resident=res, blocks=n)
+        run(1024, 8, 256, vpt=16, blocks=n)
+        run(1024, 8, 256, resident=True, blocks=1500, paced=True)

@@ -144,3 +144,78 @@ def test_resident_kernel_and_batches_interleave(built, rt_env):
         k += 1
     assert np.array_equal(out.view(np.int32), ref_bus.view(np.int32))
     syn.close()
+
+
+@pytest.fixture()
+def rt_wide_env(rt_env):
+    old = os.environ.get("ZL_RT_WIDE")
+    os.environ["ZL_RT_WIDE"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("ZL_RT_WIDE", None)
+    else:
+        os.environ["ZL_RT_WIDE"] = old
+
+
+@pytest.mark.parametrize("seed,mode,nframes,vpb,buses", [(320, 0, 256, 32, 3), (321, 4, 128, 64, 2), (322, 2, 64, 32, 2), (323, 0, 256, 128, 8)])
+def test_resident_kernel_on_wide_buses(built, rt_wide_env, seed, mode, nframes, vpb, buses):
+    """ZL_RT_WIDE=1 (opt-in: measured slower than launches).  Buses of 32 voices and more: one resident workgroup per voice (or few
+    voices), the bus summed in voice order by the last workgroup of the bus to arrive.  Commands and clip edits between cycles, an
+    idle spell, the levels; (323) is the bench shape."""
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    V = vpb * buses
+    sc = random_scene(seed, num_buses=buses, voices_per_bus=vpb, nclips=min(V, 160), mode=mode, nframes=nframes, nblocks=24 if V > 256 else 36)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc, threads=8)
+    bus, rep, syn = _play_blockwise(sc, pause_at=(11,))
+    assert np.array_equal(bus.view(np.int32), ref_bus.view(np.int32)), f"max diff {np.abs(bus - ref_bus).max()}"
+    for v in range(V):
+        assert bool(ref_syn.voices[v].isPlaying) == bool(rep[v].playing)
+        assert ref_rep[v].valid == rep[v].valid
+        if ref_rep[v].valid:
+            assert ref_rep[v].gain == rep[v].gain and ref_rep[v].progress == rep[v].progress
+    lv = syn.levels_tick(block_index=-1, with_hold_bus=1)
+    N = nframes
+    for b in range(buses):
+        ch = zo.LevelsChannel()
+        L = np.ascontiguousarray(bus[b, 0, -N:]); R = np.ascontiguousarray(bus[b, 1, -N:])
+        lib.zlo_levels_tick(C.byref(ch), L.ctypes.data, R.ctypes.data, N, 1 if b == 1 else 0)
+        assert (lv[b].peak_a, lv[b].peak_b) == (ch.peakA, ch.peakB)
+        assert lv[b].rms_a == lib.zlo_block_rms(L.ctypes.data, N, 0 if (mode & 2) else 1)
+    syn.close()
+
+
+def test_wide_resident_equals_launched_with_a_command_storm(built, rt_wide_env):
+    """The same wide engine through both real-time paths, every voice retriggered in one cycle (1024 operation ranges in one block)."""
+    from libzl_amd import SamplerSynth, clip_command
+    from libzl_amd.engine import synthetic_clocks
+    rng = np.random.default_rng(77)
+    src = [(rng.uniform(-1, 1, 3000 + 7 * i).astype(np.float32), rng.uniform(-1, 1, 3000 + 7 * i).astype(np.float32)) for i in range(16)]
+    outs = []
+    for resident in ("1", "0"):
+        old = os.environ.get("ZL_RT_PERSISTENT")
+        os.environ["ZL_RT_PERSISTENT"] = resident
+        try:
+            syn = SamplerSynth(num_buses=8, voices_per_bus=128, max_frames=256, max_batch_blocks=4, max_sounds=16, sound_arena_bytes=1 << 22)
+            for L, R in src:
+                syn.register_clip(L, R, 48000.0)
+            rows = []
+            for k in range(12):
+                if k in (0, 5):                                                 # 1024 starts in one cycle
+                    for v in range(1024):
+                        syn.start_voice(v // 128, v % 128, clip_command(clip=(v + k) % 16, midi_note=55 + v % 11, midi_channel=v // 128 - 2, start_playback=1,
+                                                                        looping=1, change_volume=1, volume=0.3 + 0.001 * (v % 97)), 0)
+                if k == 8:
+                    for v in range(0, 1024, 3):
+                        syn.stop_voice(v // 128, v % 128, True)
+                L, R = syn.process(256, synthetic_clocks(1, 256, 48000.0, start_block=k)[0])
+                rows.append(np.stack([L, R], axis=1).copy())
+            outs.append((np.concatenate(rows, axis=2), [(r.playing, r.valid, r.gain, r.progress) for r in syn.voice_reports()]))
+            syn.close()
+        finally:
+            if old is None:
+                os.environ.pop("ZL_RT_PERSISTENT", None)
+            else:
+                os.environ["ZL_RT_PERSISTENT"] = old
+    assert np.array_equal(outs[0][0].view(np.int32), outs[1][0].view(np.int32)) and np.abs(outs[0][0]).max() > 1.0
+    assert outs[0][1] == outs[1][1]

@@ -109,3 +109,39 @@ def test_bounce_into_caller_memory_and_argument_checks(Engine):
     with pytest.raises(ZlHipError):
         syn.bounce(0, 256, clocks)
     syn.close()
+
+
+@pytest.mark.gpu
+def test_bounce_to_wav_files_and_back(Engine, tmp_path):
+    """The whole n3 chain on real files: clips loaded from WAV files (decode side), bounced on the GPU in the recorder's 16-bit format,
+    one stereo WAV per bus written from the bounce buffer, read back: every sample is the oracle's mix in the oracle's 16-bit format."""
+    from libzl_amd import libzl
+    from scenario import compare_runs, random_scene, run_backend, run_oracle
+    zl = libzl.load()
+    sc = random_scene(0xB1, num_buses=3, voices_per_bus=8, nclips=8, nframes=256, nblocks=20, events=False)
+    # the scene's sources go through 32-bit float WAV files first (bit-preserving), as ClipAudioSource_new(path) would load them
+    for i, (L, R, sr) in enumerate(sc.sounds):
+        p = str(tmp_path / f"clip{i}.wav").encode()
+        assert zl.libzl_wav_write(p, L.ctypes.data, None if R is None else R.ctypes.data, len(L), sr, 32) == 0
+        Lp, Rp, n, rate = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_int(), C.c_double()
+        assert zl.libzl_wav_read(p, C.byref(Lp), C.byref(Rp), C.byref(n), C.byref(rate)) == 0 and n.value == len(L) and rate.value == sr
+        L2 = np.ctypeslib.as_array(Lp, (n.value,)).copy(); R2 = np.ctypeslib.as_array(Rp, (n.value,)).copy() if Rp else None
+        zl.libzl_wav_free(Lp); zl.libzl_wav_free(Rp)
+        assert np.array_equal(L2, L) and (R is None) == (R2 is None) and (R is None or np.array_equal(R2, R))
+        sc.sounds[i] = (L2, R2, sr)
+    ref_bus, _, _ = run_oracle(sc)
+    pcm, _, syn, _ = run_backend(sc, Engine, bounce=("pcm16", 6))
+    frames = sc.nblocks * sc.nframes
+    scale = f32(1.0 / 2147483648.0)
+    for b in range(sc.num_buses):
+        p = str(tmp_path / f"bus{b}.wav").encode()
+        row = np.ascontiguousarray(pcm[b])
+        assert zl.libzl_wav_write_interleaved(p, row.ctypes.data, frames, 2, sc.fs, 16) == 0
+        Lp, Rp, n, rate = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_int(), C.c_double()
+        assert zl.libzl_wav_read(p, C.byref(Lp), C.byref(Rp), C.byref(n), C.byref(rate)) == 0 and n.value == frames and rate.value == sc.fs
+        got = np.stack([np.ctypeslib.as_array(Lp, (frames,)).copy(), np.ctypeslib.as_array(Rp, (frames,)).copy()])
+        zl.libzl_wav_free(Lp); zl.libzl_wav_free(Rp)
+        want = (npr.pcm16(ref_bus[b]).astype(np.int32) << 16).astype(np.float32) * scale       # the reader's int -> float convention
+        assert np.array_equal(got, want)
+    assert np.abs(pcm.astype(np.int32)).max() > 2000
+    syn.close()

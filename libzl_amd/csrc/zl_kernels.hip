@@ -1015,9 +1015,10 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
 
 // the kernel: one workgroup = one (bus or group of narrow buses, mix group, block or BPW short blocks, frame tile)
 // (faithful linear mode, one block per workgroup -- the headline shape: ask for the 6 waves per SIMD its 78 registers
-// allow; left to itself the allocator takes 82 and drops to 5)
+// allow; left to itself the allocator takes 82 and drops to 5.  Two 128-frame blocks per workgroup: 5 waves -- what its 28.8 KB of
+// LDS allow -- instead of the 4 its 104 registers give: +2..3 % with 10 spilled registers, profiles/round2_e_k2_experiments.txt)
 template <uint32_t MODE, int BPW, bool ST>
-__global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 && BPW == 1) ? 6 : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
+__global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 && BPW <= 2) ? (BPW == 1 ? 6 : 5) : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
 {
     zl_k2_body<MODE, BPW, ST>(A, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }

@@ -235,3 +235,33 @@ def test_setters_race_free_next_to_the_process_thread(built, tmp_path):
     for c in clips:
         zl.ClipAudioSource_destroy(c)
     zl.shutdownJuce()
+
+
+def test_peak_conversion_of_non_finite_and_huge_samples(Engine):
+    """(int) abs(131072.f * x) on the device for the cases C leaves undefined -- NaN, infinities, values beyond int -- and at the
+    edges around them: the oracle's definition (NaN -> 0, saturation) bit for bit, through the scan of a device bus (K3; K2's fused
+    scan uses the same function)."""
+    import torch
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    special = np.array([np.nan, np.inf, -np.inf, 16383.99, 16384.0, -16384.0, 16384.004, 3.0e38, -3.0e38, 0.0, -0.0, 1e-45, -1e-39,
+                        7.62939453125e-06, 7.6293e-06, -1.0, 0.99999994, 16383.998046875], dtype=np.float32)
+    rng = np.random.default_rng(9)
+    N, K, B = 64, 6, 2
+    bus = rng.uniform(-0.5, 0.5, (B, 2, K * N)).astype(np.float32)
+    # one special value per (bus, channel, block) row at most, so that every one of them decides a peak or leaves it alone
+    rows = [(b, c, k) for b in range(B) for c in range(2) for k in range(K)]
+    for (b, c, k), v in zip(rows, special):
+        bus[b, c, k * N + 1 + int(rng.integers(0, N - 1))] = v
+    syn = Engine(num_buses=B, voices_per_bus=8, max_frames=N, max_batch_blocks=K, max_sounds=4, mode=2)     # FIX_DELAY: frame 0 counts like the others
+    dev = torch.from_numpy(bus).cuda()
+    syn.levels_scan_device(dev.data_ptr(), K, N)
+    got = syn.block_peaks()
+    want = np.zeros((K, B, 2), dtype=np.int64)
+    for b in range(B):
+        for c in range(2):
+            for k in range(K):
+                want[k, b, c] = max(lib.zlo_sample_to_peak_int(float(x)) for x in bus[b, c, k * N:(k + 1) * N])
+    assert np.array_equal(got, want)
+    assert want.max() == 2147483647 and (want == 0).sum() == 0
+    syn.close()

@@ -675,7 +675,9 @@ template <uint32_t MODE, int BPW, bool ST>
 static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsigned bx, const unsigned by, const unsigned bz, const unsigned gdx, const unsigned gdy)
 {
     constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U_HERMITE : ZL_K2_U;
-    constexpr int CH = ST ? ZL_ST_CHUNK : ZL_K2_CHUNK;    // voice records staged per pass (the staged variant trades them for ring space)
+    // voice records staged per pass (the staged variant trades them for ring space; four 64-frame blocks per workgroup stage
+    // 4 x the block records: 64 voices per pass keep the workgroup at 25 KB of LDS -- 5 workgroups per CU instead of 3 at 50 KB)
+    constexpr int CH = ST ? ZL_ST_CHUNK : (BPW == 4 ? 64 : ZL_K2_CHUNK);
     __shared__ ZlWin s_win_[ST ? CH * 4 : 1];             // [voice][wave of the workgroup]
     __shared__ unsigned long long s_stmask_[ST ? BPW * (CH / 64) : 1];   // per block: which voices of the pass are staged
     __shared__ ZlBlockPlan  s_plan_[BPW][CH];
@@ -1016,9 +1018,10 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
 // the kernel: one workgroup = one (bus or group of narrow buses, mix group, block or BPW short blocks, frame tile)
 // (faithful linear mode, one block per workgroup -- the headline shape: ask for the 6 waves per SIMD its 78 registers
 // allow; left to itself the allocator takes 82 and drops to 5.  Two 128-frame blocks per workgroup: 5 waves -- what its 28.8 KB of
-// LDS allow -- instead of the 4 its 104 registers give: +2..3 % with 10 spilled registers, profiles/round2_e_k2_experiments.txt)
+// LDS allow -- instead of the 4 its 104 registers give: +2..3 % with 10 spilled registers, profiles/round2_e_k2_experiments.txt;
+// four 64-frame blocks: likewise 5, with 64 voices per staging pass)
 template <uint32_t MODE, int BPW, bool ST>
-__global__ void __launch_bounds__(256, ST ? 3 : ((MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 && BPW <= 2) ? (BPW == 1 ? 6 : 5) : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
+__global__ void __launch_bounds__(256, ST ? 3 : (MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 ? (BPW == 1 ? 6 : 5) : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
 {
     zl_k2_body<MODE, BPW, ST>(A, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }

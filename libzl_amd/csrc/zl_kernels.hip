@@ -1524,7 +1524,10 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEv
     // 160 KB) -- one wave slot per SIMD stays free for the planner, and K2 itself is 0.5 % faster that way.
     static const int pad_env = [] { const char *e = getenv("ZL_K2_LDS_PAD"); return e ? atoi(e) : -1; }();
     static const int pad_env_h = [] { const char *e = getenv("ZL_K2_LDS_PAD_HERMITE"); return e ? atoi(e) : -1; }();
-    const int pad = (A.mode & ZL_MODE_HERMITE) ? (pad_env_h >= 0 ? pad_env_h : 0) : (pad_env >= 0 ? pad_env : 10240);
+    // (Since the planner sweeps a window in one go -- zl_k1_plan -- it is short enough not to need the room on large engines: there
+    // the sixth workgroup per CU is worth +1.5 % on the headline, +1.5..3 % on never-re-read sources.  Small engines, whose planning is
+    // as long as their rendering, keep the cap: K2 alone would gain 7 %, the call loses 1 %.)
+    const int pad = (A.mode & ZL_MODE_HERMITE) ? (pad_env_h >= 0 ? pad_env_h : 0) : (pad_env >= 0 ? pad_env : (A.V >= 512 ? 0 : 10240));
     // ev_start / ev_stop (profiling): the kernel's own begin / end timestamps, taken by the dispatch packet itself -- no
     // event packets around the launch for the command processor to handle
     // LDS-staged source windows (A.staged): batches only, whole 256-thread workgroups; the ring is dynamic LDS

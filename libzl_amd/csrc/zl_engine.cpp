@@ -827,7 +827,15 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     // Window layout: large windows keep K2 launches long (their ramp-up and drain are a fixed cost per launch), but
     // planning window i+1 must fit behind rendering window i, and the planning of the first window is hidden by
     // nothing but the previous call: windows start at 256 blocks and double up to the configured size.
-    int W = e->windowBlocks > 0 ? e->windowBlocks : (int)std::max<size_t>(1, e->windowFrames / (size_t)nframes);
+    // (ZL_WINDOW_MUL=4: blocks longer than 64 frames may fill the record arrays -- up to four windows' worth of frames in one K2
+    // launch.  Measured: K2 gains 4..9 % (fewer launch ramps; a bus's sources are re-read inside ONE launch, from the Infinity Cache),
+    // the headline call 2..3.5 %, but a call is then a single window whose planning is hidden by nothing but the previous call's
+    // launch: pitched voices -3 %, 128-frame blocks -5 %, 4096 voices -8 %, and one host-side stall of several milliseconds per
+    // timed region.  The default stays the fixed number of frames per window.)
+    static const int windowMul = [] { const char *v = std::getenv("ZL_WINDOW_MUL"); const int m = v ? std::atoi(v) : 1; return m < 1 ? 1 : (m > 64 ? 64 : m); }();
+    // (engines that split buses into mix groups keep the fixed size: their partial rows are sized for it)
+    const size_t mul = e->maxGroups > 1 ? 1 : (size_t)windowMul;
+    int W = e->windowBlocks > 0 ? e->windowBlocks : (int)std::max<size_t>(1, std::min<size_t>(mul * e->windowFrames / (size_t)nframes, (size_t)1 << 30));
     W = std::min(W, e->windowCap);
     W = std::min(W, (1 << 30) / nframes);                          // window time is a 32-bit frame index in K1 / K1c
     std::vector<std::pair<int, int>> &wins = e->wins;              // (first block, blocks); member: no allocation per call

@@ -63,7 +63,7 @@ static __device__ __forceinline__ void zl_k1c_block(const ZlBatch &A, ZlAssemble
 // ------------------------------------------------------------------------------------------------
 // K1: one lane per voice; the block clocks are staged in LDS so the per-block step of the planner
 // makes no dependent global load.  Cost is O(linear runs + events) per voice, not O(blocks) (zl_plan.h).
-#define ZL_K1_CLOCKS 1024    // (a planner iteration ends at the end of the staged clocks: 1024 blocks per stage = 8 stages per 8192-block window of 64-frame blocks)
+#define ZL_K1_CLOCKS 256     // (12 KB of LDS: a planner workgroup must fit next to the render kernel's workgroups on a CU -- with 1024 clocks it did not)
 __global__ void __launch_bounds__(64) zl_k1_plan(const ZlBatch A, int force_slow)
 {
     __shared__ ZlClock s_clk[ZL_K1_CLOCKS];
@@ -1524,10 +1524,10 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEv
     // 160 KB) -- one wave slot per SIMD stays free for the planner, and K2 itself is 0.5 % faster that way.
     static const int pad_env = [] { const char *e = getenv("ZL_K2_LDS_PAD"); return e ? atoi(e) : -1; }();
     static const int pad_env_h = [] { const char *e = getenv("ZL_K2_LDS_PAD_HERMITE"); return e ? atoi(e) : -1; }();
-    // (Since the planner sweeps a window in one go -- zl_k1_plan -- it is short enough not to need the room on large engines: there
-    // the sixth workgroup per CU is worth +1.5 % on the headline, +1.5..3 % on never-re-read sources.  Small engines, whose planning is
-    // as long as their rendering, keep the cap: K2 alone would gain 7 %, the call loses 1 %.)
-    const int pad = (A.mode & ZL_MODE_HERMITE) ? (pad_env_h >= 0 ? pad_env_h : 0) : (pad_env >= 0 ? pad_env : (A.V >= 512 ? 0 : 10240));
+    // (ZL_K2_LDS_PAD=0 -- the sixth workgroup per CU -- was measured again after the planner became a single sweep: K2 itself gains
+    // 1..3 %, but a planner launch that arrives just after K2 has filled the machine then waits for the whole K2 launch every now
+    // and then (2.5 ms instead of 35 us), and across boxes the calls gain nothing: the cap stays.)
+    const int pad = (A.mode & ZL_MODE_HERMITE) ? (pad_env_h >= 0 ? pad_env_h : 0) : (pad_env >= 0 ? pad_env : 10240);
     // ev_start / ev_stop (profiling): the kernel's own begin / end timestamps, taken by the dispatch packet itself -- no
     // event packets around the launch for the command processor to handle
     // LDS-staged source windows (A.staged): batches only, whole 256-thread workgroups; the ring is dynamic LDS

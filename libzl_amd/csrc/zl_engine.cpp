@@ -93,7 +93,7 @@ struct zlhip_engine {
     // Per-call resources, double buffered so that consecutive zlhip_render_batch calls pipeline: the host prepares
     // (and the planning stream plans) call i+1 while call i still renders; a slot is reused by call i+2.
     struct CallSlot {
-        ZlClock *hClocks = nullptr, *dClocks = nullptr;
+        ZlClock *hClocks = nullptr, *hClocksDev = nullptr;   // the call's block clocks, in host memory mapped into the device: K1 reads them in place
         ZlPassParams *hPass = nullptr, *dPass = nullptr;   // fused fan-out parameters of the call
         // the call's voice operations, in host memory mapped into the device: K0 reads them in place (no copy command)
         ZlVoiceOp *hOps = nullptr, *hOpsDev = nullptr; ZlOpRange *hRanges = nullptr, *hRangesDev = nullptr;
@@ -279,7 +279,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
         if (q.k1done) (void)hipEventDestroy(q.k1done);
     }
     for (auto &c : e->slots) {
-        void *cd[] = { c.dClocks, c.dReports, c.dStats, c.dPass };
+        void *cd[] = { c.dReports, c.dStats, c.dPass };
         for (void *p : cd) if (p) (void)hipFree(p);
         void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats, c.hPass, c.hOps, c.hRanges };
         for (void *p : ch) if (p) (void)hipHostFree(p);
@@ -409,10 +409,11 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             chk(hipEventCreate(&c.evBegin), "hipEventCreate");
             chk(hipEventCreate(&c.evEnd), "hipEventCreate");
             chk(hipEventCreate(&c.done), "hipEventCreate");        // (it can ride on a kernel dispatch as its stop event)
-            chk(dalloc(&c.dClocks, K), "clocks");
+
             chk(dalloc(&c.dReports, V), "reports");
             chk(dalloc(&c.dStats, 1), "stats");
             chk(hipHostMalloc((void **)&c.hClocks, K * sizeof(ZlClock)), "hClocks");
+            if (rc == ZLHIP_OK) chk(hipHostGetDevicePointer((void **)&c.hClocksDev, c.hClocks, 0), "hClocks device view");
             chk(dalloc(&c.dPass, B), "fan-out params");
             chk(hipHostMalloc((void **)&c.hPass, std::max<size_t>(B, 1) * sizeof(ZlPassParams)), "hPass");
             chk(hipHostMalloc((void **)&c.hReports, V * sizeof(ZlReport)), "hReports");
@@ -778,6 +779,8 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
 
     // this call's slot: wait for the call that used it two calls ago (the previous call may still be rendering)
+    static const bool callStamps = std::getenv("ZL_CALL_STAMPS") != nullptr;   // diagnostics: host time of the call's phases (stderr)
+    const auto tEnter = std::chrono::steady_clock::now();
     zlhip_engine::CallSlot &c = e->slots[e->callIndex & 1u];
     if (c.inflight) {
         ZL_HIP(e, hipEventSynchronize(c.done));
@@ -785,6 +788,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         int hrc = harvest_slot(e, c);
         if (hrc != ZLHIP_OK) return hrc;
     }
+    const auto tSlot = std::chrono::steady_clock::now();
     bool regular = true;                                           // monotone time, one period: lets K1 bisect for loop restarts
     for (int k = 0; k < nblocks; ++k) {
         ZlHostControl::fill_clock(c.hClocks[k], clocks[k], nframes);
@@ -869,8 +873,10 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     // the voice state is carried from call to call by K1: when this call plans on another stream than the previous one
     // did, order it behind that call's last planning kernel
     if (e->lastPlanStream && e->lastPlanStream != ps && e->lastPlanEvent) ZL_HIP(e, hipStreamWaitEvent(ps, e->lastPlanEvent, 0));
-    if (nblocks == 1) { A.inline_clock = 1; A.clock0 = c.hClocks[0]; A.fuse_assemble = 1; }   // a real-time block: fewer commands
-    else ZL_HIP(e, hipMemcpyAsync(c.dClocks, c.hClocks, (size_t)nblocks * sizeof(ZlClock), hipMemcpyHostToDevice, ps));
+    // The block clocks stay where fill_clock wrote them, in host memory mapped into the device (like the voice operations): the planner
+    // reads them at a voice's first block, in simulated blocks, and stage by stage for beat-locked loops.  (A copy command here blocked
+    // the host for 6-7 ms every now and then -- hipMemcpyAsync on the planning stream, seen at the fifth call of a run.)
+    if (nblocks == 1) { A.inline_clock = 1; A.clock0 = c.hClocks[0]; A.fuse_assemble = 1; }   // a real-time block: the clock travels with the kernel arguments
     if (fan_out_dev) {                                             // the rendering stream is ordered behind ps by the window events
         for (int b = 0; b < A.B; ++b) c.hPass[b] = pass_params(fan_params[b]);
         ZL_HIP(e, hipMemcpyAsync(c.dPass, c.hPass, (size_t)A.B * sizeof(ZlPassParams), hipMemcpyHostToDevice, ps));
@@ -888,7 +894,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         ZlBatch Aw = A;
         Aw.k0 = wins[(size_t)w].first;
         Aw.K = wins[(size_t)w].second;
-        Aw.clocks = c.dClocks + Aw.k0;
+        Aw.clocks = c.hClocksDev + Aw.k0;
         Aw.levels = e->dLevels + (size_t)Aw.k0 * A.B;
         Aw.pos_trace = traceBase ? traceBase + (size_t)Aw.k0 * e->V * nframes : nullptr;
         Aw.vconst = q.vconst; Aw.runs = q.runs; Aw.tsegs = q.tsegs; Aw.plan_hdr = q.hdr; Aw.plan_seg0 = q.seg0; Aw.plan_seg1 = q.seg1;
@@ -949,6 +955,11 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     e->callIndex += 1;
     e->lastK = nblocks; e->lastN = nframes; e->lastBus = A.bus; e->lastWindows = nwin;
     e->outstanding = true; e->reportsFresh = true;
+    if (callStamps) {
+        const auto tEnd = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "zlhip_render_batch #%u: slot wait %.0f us, commands %.0f us, %d window(s)\n", e->callIndex - 1, us(tEnter, tSlot), us(tSlot, tEnd), nwin);
+    }
     return ZLHIP_OK;
 }
 

@@ -14,8 +14,14 @@
  *     as SamplerSynthSound.cpp:45) instead of going through JUCE / tracktion.
  *   - audio is pulled with libzl_hotpath_process() by whoever owns the JACK callback (the reference's
  *     SamplerChannel::process, SamplerSynth.cpp:116-148) instead of being pushed to JACK from inside.
- *   - ClipAudioSource_play/stop act on the next rendered block (the reference schedules them through
- *     SyncTimer with delay 0, ClipAudioSource.cpp:428,437, which is the same block).
+ *   - ClipAudioSource_play/stop go through SyncTimer::scheduleClipCommand with delay 0 as in the reference
+ *     (ClipAudioSource.cpp:428,437; SyncTimer.cpp:1011-1048): equivalent commands that meet in one step are merged, and
+ *     a command reaches the sampler with the playhead of the step it is dispatched in (SyncTimer.cpp:553-558).  Two ways
+ *     to run the cycle: libzl_hotpath_process (the host's own SyncTimer owns the transport and hands its getters over in
+ *     zlhip_clock) and libzl_hotpath_cycle (this library runs the step ring itself, SyncTimer.cpp:452-702).
+ *   - threading: setters, play / stop / queue calls and getters never take a lock the cycle holds (they publish a
+ *     snapshot or post a request that the next cycle picks up); clip creation / destruction, initJuce / shutdownJuce do.
+ *     The progress / level callbacks fire on the cycle's thread after its lock is released: they may call this API.
  */
 #ifndef LIBZL_HOTPATH_H
 #define LIBZL_HOTPATH_H
@@ -67,8 +73,19 @@ void ClipAudioSource_setADSRSustain(ClipAudioSource *c, float newValue);        
 float ClipAudioSource_adsrRelease(ClipAudioSource *c);                                  /* libzl.h:60 */
 void ClipAudioSource_setADSRRelease(ClipAudioSource *c, float newValue);                /* libzl.h:61 */
 
-/* ---- misc (libzl.h:72,84-90) ----------------------------------------------------------------- */
+/* ---- SyncTimer API bridge, the part that schedules ClipCommands (libzl.h:69-79, libzl.cpp:311-349) ----
+ * Served by the step ring of libzl_hotpath_cycle.  SyncTimer_instance and the timer-callback registration belong to the
+ * reference's timer thread / Qt object and are not declared here. */
+void SyncTimer_startTimer(int interval);                                                /* libzl.h:70: SyncTimer::start(bpm), SyncTimer.cpp:870-879 */
+void SyncTimer_setBpm(unsigned int bpm);                                                /* libzl.h:71, SyncTimer.cpp:954-975 */
 int  SyncTimer_getMultiplier(void);                                                     /* libzl.h:72, SyncTimer.cpp:946-948 */
+void SyncTimer_stopTimer(void);                                                         /* libzl.h:73, SyncTimer.cpp:881-925 */
+void SyncTimer_queueClipToStart(ClipAudioSource *clip);                                 /* libzl.h:76 */
+void SyncTimer_queueClipToStartOnChannel(ClipAudioSource *clip, int midiChannel);       /* libzl.h:77, SyncTimer.cpp:815-832 */
+void SyncTimer_queueClipToStop(ClipAudioSource *clip);                                  /* libzl.h:78 */
+void SyncTimer_queueClipToStopOnChannel(ClipAudioSource *clip, int midiChannel);        /* libzl.h:79, SyncTimer.cpp:834-860 */
+
+/* ---- misc (libzl.h:84-90) ----------------------------------------------------------------- */
 void initJuce(void);                                                                    /* libzl.h:84: brings the engine up (12 channels x 8 voices) */
 void shutdownJuce(void);                                                                /* libzl.h:85 */
 void stopClips(int size, ClipAudioSource **clips);                                      /* libzl.h:89 */
@@ -105,6 +122,20 @@ ClipAudioSource *ClipAudioSource_newFromBuffer(const float *left, const float *r
  * out_left / out_right: [num_buses][nframes].  Afterwards the per-clip positions models are updated from
  * the voice reports and the progress / audio-level callbacks fire (ClipAudioSource.cpp:88-113,225-240). */
 int  libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right);
+/* The same cycle with this library's own transport: SyncTimerPrivate::process (SyncTimer.cpp:452-702) for the JACK cycle
+ * [current_usecs, next_usecs) -- the steps of the 32768-step ring that fall due are played, their ClipCommands dispatched
+ * with the playhead (:553-558), SetBpm commands applied, playhead and step clock rolled -- then every channel is rendered
+ * with the clock SyncTimer's getters return (:990-1009), and, while the timer runs, the timer thread's tick
+ * (hiResTimerCallback, :391-418) is taken once.  Arguments as jack_get_cycle_times returns them (SamplerSynth.cpp:128). */
+int  libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, float *out_left, float *out_right);
+/* SyncTimer::scheduleClipCommand(command, delay) (SyncTimer.cpp:1011-1048): what ClipAudioSource_play / _stop call with delay 0;
+ * command->clip is the zlhip clip id (ClipAudioSource_engineClip) */
+void libzl_hotpath_schedule_clip_command(const zlhip_clip_command *command, uint64_t delay);
+/* one more tick of the timer thread (hiResTimerCallback) before the next libzl_hotpath_cycle */
+void libzl_hotpath_timer_tick(void);
+/* SyncTimer::jackPlayhead / jackPlayheadUsecs / jackSubbeatLengthInMicroseconds (SyncTimer.cpp:990-1009) of the library's own
+ * transport, in the playhead fields of *out */
+int  libzl_hotpath_transport(zlhip_clock *out);
 /* ClipAudioSourcePositionsModel read-outs of a clip (ClipAudioSourcePositionsModel.cpp:160-185) */
 float  ClipAudioSource_peakGain(ClipAudioSource *c);
 double ClipAudioSource_firstProgress(ClipAudioSource *c);

@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define ZLHIP_ABI_VERSION 1
+/* 2: zlhip_config grew (rt_idle_timeout_us; struct_size tells the library which fields the caller knows); ZLHIP_MODE_HERMITE is
+ *    the tap-weight form fixed in round 2 (it differs from the Horner form of ABI 1 in the last bits);
+ *    new entry points: zlhip_bounce, zlhip_host_alloc/free, zlhip_bus_reduce_sum_scan, zlhip_levels_import_units,
+ *    zlhip_sound_upload_device_on; zlhip_clip_set no longer waits for the device (the edit lands at the next render call). */
+#define ZLHIP_ABI_VERSION 2
 
 /* status codes */
 #define ZLHIP_OK                 0
@@ -69,6 +73,10 @@ typedef struct zlhip_config {
     int32_t  plan_window_blocks;     /* blocks planned per window (planning of window i+1 overlaps rendering of window i);
                                         0 = automatic: 512 Ki frames at 1024 voices (2048 blocks of 256), proportionally
                                         more frames for fewer voices (up to 16 Mi), never more than max_batch_blocks */
+    int32_t  rt_idle_timeout_us;     /* (ABI 2) how long the resident real-time kernel behind zlhip_render stays on the device
+                                        without a cycle before it leaves (it is started again by the next cycle); 0 = 200 000.
+                                        A host that makes device-synchronising HIP calls of its own (hipFree, hipDeviceSynchronize)
+                                        waits at most this long behind an idle engine; calls made through this library do not wait. */
 } zlhip_config;
 
 /* clock inputs of one block: JACK cycle times + SyncTimer playhead getters
@@ -164,8 +172,16 @@ int zlhip_sound_upload(zlhip_engine *e, const float *left, const float *right, i
  * (hipDeviceSynchronize) before it reads them: whatever stream produced the planes, they are complete. */
 int zlhip_sound_upload_device(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length,
                               double sample_rate, int32_t *out_id);
+/* Same, with the stream the planes were produced on (hipStream_t; NULL = the null stream): the engine waits for that stream only
+ * (an event), not for the device. */
+int zlhip_sound_upload_device_on(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length,
+                                 double sample_rate, void *producer_stream, int32_t *out_id);
 int zlhip_sound_release(zlhip_engine *e, int32_t id);          /* SamplerSynth::unregisterClip */
 void zlhip_clip_params_default(zlhip_clip_params *p, float duration_seconds);   /* ClipAudioSource ctor defaults */
+/* The parameters a voice reads per block (SamplerSynthVoice.cpp:189-196).  Host-only and wait-free: the edit is recorded and the
+ * device applies it at the start of the next render call / real-time cycle, the block boundary at which the reference's voices
+ * would read it; commands handled after the call see the new values (startNote, SamplerSynthVoice.cpp:115-121).  The resident
+ * real-time kernel keeps running. */
 int zlhip_clip_set(zlhip_engine *e, int32_t id, const zlhip_clip_params *p);
 
 /* ---- commands ------------------------------------------------------------------------------ */

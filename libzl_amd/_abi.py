@@ -30,6 +30,7 @@ class Config(C.Structure):
         ("voices_per_bus", C.c_int32), ("max_frames", C.c_int32), ("max_batch_blocks", C.c_int32),
         ("max_sounds", C.c_int32), ("mode", C.c_uint32), ("playback_sample_rate", C.c_double),
         ("sound_arena_bytes", C.c_uint64), ("voices_per_task", C.c_int32), ("plan_window_blocks", C.c_int32),
+        ("rt_idle_timeout_us", C.c_int32),
     ]
 
 
@@ -106,6 +107,7 @@ SIGNATURES = {
     "zlhip_strerror": (C.c_char_p, [C.c_int]),
     "zlhip_sound_upload": (C.c_int, [_E, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_int32)]),
     "zlhip_sound_upload_device": (C.c_int, [_E, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_int32)]),
+    "zlhip_sound_upload_device_on": (C.c_int, [_E, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.POINTER(C.c_int32)]),
     "zlhip_sound_release": (C.c_int, [_E, C.c_int32]),
     "zlhip_clip_params_default": (None, [C.POINTER(ClipParams), C.c_float]),
     "zlhip_clip_set": (C.c_int, [_E, C.c_int32, C.POINTER(ClipParams)]),

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(ROOT, "libzl_amd", "lib")
 LIB = os.path.join(LIBDIR, "libzlhip.so")
 
 HIP_SOURCES = ["zl_kernels.hip", "zl_engine.cpp", "zl_libzl.cpp"]
-HEADERS = ["zl_types.h", "zl_plan.h", "zl_render.h", "zl_kernels.h", "zl_host.h",
+HEADERS = ["zl_types.h", "zl_plan.h", "zl_render.h", "zl_kernels.h", "zl_host.h", "zl_sched.h",
            os.path.join("..", "..", "include", "zlhip.h"), os.path.join("..", "..", "include", "libzl_hotpath.h")]
 
 
@@ -61,29 +61,63 @@ def build_engine(force: bool = False, verbose: bool = False, stamps: bool = Fals
     return _build_engine(force, verbose, [])
 
 
+# per source: the headers it includes (a change of one of them recompiles only the sources that see it)
+_INC = os.path.join("..", "..", "include")
+SOURCE_DEPS = {
+    "zl_kernels.hip": ["zl_types.h", "zl_plan.h", "zl_render.h", "zl_kernels.h"],
+    "zl_engine.cpp": ["zl_types.h", "zl_plan.h", "zl_host.h", "zl_kernels.h", os.path.join(_INC, "zlhip.h")],
+    "zl_libzl.cpp": ["zl_render.h", "zl_types.h", "zl_sched.h", os.path.join(_INC, "zlhip.h"), os.path.join(_INC, "libzl_hotpath.h")],
+}
+
+
 def _build_engine(force: bool, verbose: bool, extra: list) -> str:
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    if not force and not _stale(LIB, deps):
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [
-        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    """One object per source (cached under lib/obj/<library name>/), then one link: editing the host code does not recompile
+    the kernels (two minutes)."""
+    names = [s for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    envflags = [f for f in os.environ.get("ZL_EXTRA_HIPCC_FLAGS", "").split() if f]
+    objdir = os.path.join(LIBDIR, "obj", os.path.splitext(os.path.basename(LIB))[0])
+    os.makedirs(objdir, exist_ok=True)
+    flagfile = os.path.join(objdir, "flags.txt")
+    flags = " ".join(extra + envflags)
+    alldeps = [os.path.join(CSRC, n) for n in names] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if not force and not extra and not envflags and not _stale(LIB, alldeps):
+        return LIB                      # (the GPU box receives the library without the object cache)
+    if not os.path.exists(flagfile) or open(flagfile).read() != flags:
+        force = True
+    common = [
+        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         # the oracle defines an un-fused rounding sequence; never contract a*b+c into fma
         "-ffp-contract=off", "-fno-fast-math",
-        "-x", "hip",
         "-I", os.path.join(ROOT, "include"), "-I", CSRC,
         "-Wall", "-Wno-unused-function",
-        "-o", LIB,
-    ] + extra + [f for f in os.environ.get("ZL_EXTRA_HIPCC_FLAGS", "").split() if f] + srcs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building libzlhip.so")
-    if verbose and res.stderr:
-        sys.stderr.write(res.stderr)
+    ] + extra + envflags
+    objs, rebuilt = [], False
+    for name in names:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(objdir, os.path.splitext(name)[0] + ".o")
+        deps = [src, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in SOURCE_DEPS.get(name, HEADERS)]
+        if force or _stale(obj, deps):
+            cmd = common + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                sys.stderr.write(res.stdout + res.stderr)
+                raise RuntimeError(f"hipcc failed compiling {name}")
+            if verbose and res.stderr:
+                sys.stderr.write(res.stderr)
+            rebuilt = True
+        objs.append(obj)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError("hipcc failed linking libzlhip.so")
+        with open(flagfile, "w") as f:
+            f.write(flags)
     return LIB
 
 

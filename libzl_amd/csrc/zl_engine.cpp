@@ -8,11 +8,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -98,6 +100,7 @@ struct zlhip_engine {
         // the call's voice operations, in host memory mapped into the device: K0 reads them in place (no copy command)
         ZlVoiceOp *hOps = nullptr, *hOpsDev = nullptr; ZlOpRange *hRanges = nullptr, *hRangesDev = nullptr;
         size_t opsCap = 0, rangesCap = 0;
+        ZlClipEdit *hEdits = nullptr, *hEditsDev = nullptr; size_t editsCap = 0;   // the call's clip-parameter edits, same arrangement
         ZlReport *hReports = nullptr, *dReports = nullptr;
         float *hGain = nullptr;
         ZlBatchStats *hStats = nullptr, *dStats = nullptr;
@@ -158,6 +161,8 @@ struct zlhip_engine {
         bool active = false;                 // inside zlhip_bounce: every sub-batch plans on the planning stream
     } bnc;
 
+    bool failed = false;                 // the resident kernel stopped answering in the middle of a cycle: the voice table is undefined (zlhip_render)
+
     // profiling
     bool profiling = false; hipEvent_t evJoin = nullptr;
     hipEvent_t joins[2] = {nullptr, nullptr};   // events on caller streams the host still has to wait for (engine_wait)
@@ -202,6 +207,50 @@ static int engine_wait(zlhip_engine *e)
 }
 
 
+// ---- resident kernels and device-synchronising HIP calls -----------------------------------------------
+// hipFree, hipHostFree and hipDeviceSynchronize wait for every kernel on the device -- also for the resident real-time kernel of
+// ANY engine of the process: up to its idle timeout, or for ever while its host keeps posting cycles.  Engines whose resident
+// kernel may be on the device are registered here; a thread about to make such a call asks all of them (other than its own
+// engine, which it stops itself) to leave through their mailbox (ZlRtShared::yield), waits until they have, and holds the
+// request for the duration of the call.  The owners notice that their kernel has left at their next cycle (rt_render) and
+// render that cycle with launches while a request is held; afterwards they start their kernel again.
+namespace {
+struct RtRegistry {
+    std::mutex mu;
+    std::vector<zlhip_engine *> engines;
+    std::atomic<int> quiescing{0};
+} g_rt;
+
+void rt_unregister(zlhip_engine *e)
+{
+    std::lock_guard<std::mutex> lk(g_rt.mu);
+    g_rt.engines.erase(std::remove(g_rt.engines.begin(), g_rt.engines.end(), e), g_rt.engines.end());
+}
+
+struct ZlQuiesce {
+    explicit ZlQuiesce(const zlhip_engine *self)
+    {
+        g_rt.quiescing.fetch_add(1, std::memory_order_acq_rel);
+        std::lock_guard<std::mutex> lk(g_rt.mu);
+        for (zlhip_engine *o : g_rt.engines) if (o != self && o->rt.h) __atomic_store_n(&o->rt.h->yield, 1u, __ATOMIC_RELEASE);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (zlhip_engine *o : g_rt.engines) {
+            if (o == self || !o->rt.h) continue;
+            // (a kernel that was just launched reads the request at its first idle poll; one second: thousands of cycles)
+            while (__atomic_load_n(&o->rt.h->state, __ATOMIC_ACQUIRE) != 2u && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(1)) { }
+        }
+    }
+    ~ZlQuiesce()
+    {
+        std::lock_guard<std::mutex> lk(g_rt.mu);
+        if (g_rt.quiescing.fetch_sub(1, std::memory_order_acq_rel) == 1)
+            for (zlhip_engine *o : g_rt.engines) if (o->rt.h) __atomic_store_n(&o->rt.h->yield, 0u, __ATOMIC_RELEASE);
+    }
+    ZlQuiesce(const ZlQuiesce &) = delete;
+    ZlQuiesce &operator=(const ZlQuiesce &) = delete;
+};
+}  // namespace
+
 // ---- resident real-time kernel ------------------------------------------------------------------
 // Asks the resident kernel to leave and waits for it.  Called before anything else touches the voice table, the clip / sound
 // tables, the arena or the plan records from outside (batches, uploads, parameter changes, destruction): while the kernel is
@@ -213,6 +262,7 @@ static int rt_stop(zlhip_engine *e)
     ZL_HIP(e, hipStreamSynchronize(e->rt.stream));
     __atomic_store_n(&e->rt.h->stop, 0u, __ATOMIC_RELEASE);
     e->rt.running = false;
+    rt_unregister(e);
     return ZLHIP_OK;
 }
 
@@ -249,6 +299,7 @@ void zlhip_config_default(zlhip_config *cfg)
     cfg->playback_sample_rate = 48000.0;
     cfg->sound_arena_bytes = 256ull << 20;
     cfg->voices_per_task = 0;
+    cfg->rt_idle_timeout_us = 0;     // 200 ms
 }
 
 void zlhip_engine_destroy(zlhip_engine *e)
@@ -256,6 +307,8 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)rt_stop(e);
+    rt_unregister(e);
+    ZlQuiesce quiet(e);                 // the frees below wait for the device: no other engine's resident kernel may be on it
     if (e->rt.stampsOn && e->rt.stampN)
         std::fprintf(stderr, "zlhip resident kernel (workgroup 0), mean us per block over %llu blocks: K0 %.2f  K1 %.2f  K1c %.2f  K2 %.2f  reports + release %.2f\n", e->rt.stampN,
                      e->rt.stampSum[0] / e->rt.stampN, e->rt.stampSum[1] / e->rt.stampN, e->rt.stampSum[2] / e->rt.stampN, e->rt.stampSum[3] / e->rt.stampN,
@@ -281,7 +334,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     for (auto &c : e->slots) {
         void *cd[] = { c.dReports, c.dStats, c.dPass };
         for (void *p : cd) if (p) (void)hipFree(p);
-        void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats, c.hPass, c.hOps, c.hRanges };
+        void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats, c.hPass, c.hOps, c.hRanges, c.hEdits };
         for (void *p : ch) if (p) (void)hipHostFree(p);
         for (auto &x : c.evK2) if (x) (void)hipEventDestroy(x);
         hipEvent_t evs[] = { c.evBegin, c.evEnd, c.done };
@@ -304,10 +357,22 @@ void zlhip_engine_destroy(zlhip_engine *e)
     delete e;
 }
 
-int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
+int zlhip_engine_create(const zlhip_config *cfg_in, zlhip_engine **out)
 {
-    if (!cfg || !out) return ZLHIP_ERR_INVALID;
+    if (!cfg_in || !out) return ZLHIP_ERR_INVALID;
     *out = nullptr;
+    // struct_size: a caller built against an earlier header passes a shorter struct; the fields it does not know keep their defaults
+    zlhip_config cfg_full;
+    zlhip_config_default(&cfg_full);
+    {
+        const size_t minSize = offsetof(zlhip_config, plan_window_blocks) + sizeof(int32_t);     // ABI version 1
+        const size_t have = cfg_in->struct_size == 0 ? minSize : (size_t)cfg_in->struct_size;
+        if (have < minSize) return ZLHIP_ERR_INVALID;
+        std::memcpy(&cfg_full, cfg_in, std::min(have, sizeof cfg_full));
+        cfg_full.struct_size = sizeof cfg_full;
+    }
+    const zlhip_config *cfg = &cfg_full;
+    if (cfg->rt_idle_timeout_us < 0) return ZLHIP_ERR_INVALID;
     if (cfg->num_buses < 1 || cfg->voices_per_bus < 1 || cfg->max_frames < 64 || cfg->max_frames > 4096
         || (cfg->max_frames % 64) != 0 || cfg->max_batch_blocks < 1 || cfg->max_sounds < 1
         || !(cfg->playback_sample_rate > 0.0) || (cfg->mode & ~7u))
@@ -419,6 +484,10 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
             chk(hipHostMalloc((void **)&c.hReports, V * sizeof(ZlReport)), "hReports");
             chk(hipHostMalloc((void **)&c.hGain, V * sizeof(float)), "hGain");
             chk(hipHostMalloc((void **)&c.hStats, sizeof(ZlBatchStats)), "hStats");
+            // room for a cycle's clip-parameter edits without ever growing (growing frees pinned memory, which waits for the device)
+            c.editsCap = (size_t)std::min(cfg->max_sounds, 64);
+            chk(hipHostMalloc((void **)&c.hEdits, c.editsCap * sizeof(ZlClipEdit)), "hEdits");
+            if (rc == ZLHIP_OK) chk(hipHostGetDevicePointer((void **)&c.hEditsDev, c.hEdits, 0), "map hEdits");
             if (rc == ZLHIP_OK) {
                 chk(hipHostGetDevicePointer((void **)&c.hReportsDev, c.hReports, 0), "map hReports");
                 chk(hipHostGetDevicePointer((void **)&c.hGainDev, c.hGain, 0), "map hGain");
@@ -472,6 +541,7 @@ int zlhip_engine_create(const zlhip_config *cfg, zlhip_engine **out)
         const char *rw = std::getenv("ZL_RT_WIDE");
         e->rt.wide = rw && std::atoi(rw) == 1;
         e->rt.stampsOn = std::getenv("ZL_RT_STAMPS") != nullptr;
+        if (cfg->rt_idle_timeout_us > 0) e->rt.idleTicks = (unsigned long long)cfg->rt_idle_timeout_us * 100ull;   // 100 MHz counter
     }
     e->hc.init(cfg->num_buses, cfg->voices_per_bus, cfg->max_sounds, cfg->playback_sample_rate);
     e->soundFloats.assign((size_t)cfg->max_sounds, 0);
@@ -548,8 +618,23 @@ static int publish_sound(zlhip_engine *e, int id)
     return zlhip_clip_set(e, id, &p);
 }
 
+static int sound_upload_device(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length, double sample_rate,
+                               bool have_producer, hipStream_t producer, int32_t *out_id);
+
 int zlhip_sound_upload_device(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length,
                               double sample_rate, int32_t *out_id)
+{
+    return sound_upload_device(e, left_dev, right_dev, length, sample_rate, false, nullptr, out_id);
+}
+
+int zlhip_sound_upload_device_on(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length,
+                                 double sample_rate, void *producer_stream, int32_t *out_id)
+{
+    return sound_upload_device(e, left_dev, right_dev, length, sample_rate, true, (hipStream_t)producer_stream, out_id);
+}
+
+static int sound_upload_device(zlhip_engine *e, const float *left_dev, const float *right_dev, int32_t length, double sample_rate,
+                               bool have_producer, hipStream_t producer, int32_t *out_id)
 {
     if (!e || !left_dev) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
@@ -559,9 +644,18 @@ int zlhip_sound_upload_device(zlhip_engine *e, const float *left_dev, const floa
     if (e->outstanding) { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     int rc = alloc_sound_slot(e, length, right_dev ? 2 : 1, sample_rate, out_id, &dst);
     if (rc != ZLHIP_OK) return rc;
-    // left_dev / right_dev were produced on a stream this call knows nothing about (the engine's stream is
-    // non-blocking: not even the null stream orders it): a one-off upload can afford to wait for the whole device
-    hipError_t st = hipDeviceSynchronize();
+    hipError_t st;
+    if (have_producer) {
+        // the planes are complete when `producer` has run dry: an event there, waited for by the engine's stream -- no device-wide wait
+        st = hipEventRecord(e->evJoin, producer);
+        if (st == hipSuccess) st = hipStreamWaitEvent(e->stream, e->evJoin, 0);
+    } else {
+        // left_dev / right_dev were produced on a stream this call knows nothing about (the engine's stream is non-blocking: not
+        // even the null stream orders it): wait for the whole device -- with every other engine's resident kernel asked to leave
+        // for the duration (they would make this wait last until their idle timeout, or for ever)
+        ZlQuiesce quiet(e);
+        st = hipDeviceSynchronize();
+    }
     int krc = st == hipSuccess ? zl_launch_interleave(left_dev, right_dev, dst, length, 8, e->stream) : (int)st;
     if (krc != 0) {
         free_sound_slot(e, *out_id); *out_id = -1;
@@ -610,14 +704,11 @@ int zlhip_clip_set(zlhip_engine *e, int32_t id, const zlhip_clip_params *p)
 {
     if (!e || !p || id < 0 || id >= e->cfg.max_sounds || !e->hc.soundUsed[id]) return ZLHIP_ERR_INVALID;
     if (p->num_slice_positions < 0 || p->num_slice_positions > ZLHIP_MAX_SLICES) return fail(e, ZLHIP_ERR_INVALID, "too many slices");
-    ZL_HIP(e, hipSetDevice(e->device));
-    { int r_ = rt_stop(e); if (r_ != ZLHIP_OK) return r_; }         // (the resident real-time kernel does not see other engines' writes)
-    if (e->outstanding) { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }     // queued batches still read the parameters
-    e->hc.clipParams[id] = *p;
-    ZlClip c;
-    ZlHostControl::fill_clip(c, *p);
-    ZL_HIP(e, hipMemcpyAsync(e->dClips + id, &c, sizeof c, hipMemcpyHostToDevice, e->stream));
-    { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
+    // No HIP call, no wait: the edit is recorded on the host and the DEVICE applies it at the start of the next render call or
+    // real-time cycle (K0 / every workgroup of the resident kernel, in stream order behind the planning of every call already
+    // queued) -- the block boundary at which the reference's voices read the parameters (SamplerSynthVoice.cpp:189-196).  The
+    // resident kernel stays resident; a JACK thread is never made to wait behind a parameter change.
+    e->hc.set_clip_params(id, *p);
     return ZLHIP_OK;
 }
 
@@ -717,10 +808,21 @@ static int pick_group(const zlhip_engine *e, int K, int N)
 // no copy command and no staging.
 static int upload_ops(zlhip_engine *e, zlhip_engine::CallSlot &c, ZlBatch &A)
 {
-    A.n_op_ranges = 0; A.ops = nullptr; A.op_ranges = nullptr;
+    A.n_op_ranges = 0; A.ops = nullptr; A.op_ranges = nullptr; A.n_clip_edits = 0; A.clip_edits = nullptr;
+    const size_t ne = e->hc.pendingClipEdits.size();
+    if (ne > 0) {
+        if (ne > c.editsCap) { ZlQuiesce quiet(e); ZL_HIP(e, grow_mapped(&c.hEdits, &c.hEditsDev, &c.editsCap, ne)); }
+        std::memcpy(c.hEdits, e->hc.pendingClipEdits.data(), ne * sizeof(ZlClipEdit));
+        e->hc.pendingClipEdits.clear();
+        A.n_clip_edits = (int)ne; A.clip_edits = c.hEditsDev;
+    }
     const size_t n = e->hc.pendingOps.size();
     if (n == 0) return ZLHIP_OK;
-    ZL_HIP(e, grow_mapped(&c.hOps, &c.hOpsDev, &c.opsCap, n));
+    if (n > c.opsCap || n > c.rangesCap) {
+        ZlQuiesce quiet(e);                                        // growing frees pinned memory, which waits for the device
+        ZL_HIP(e, grow_mapped(&c.hOps, &c.hOpsDev, &c.opsCap, n));
+        ZL_HIP(e, grow_mapped(&c.hRanges, &c.hRangesDev, &c.rangesCap, n));
+    }
     e->hc.drain_ops_to(c.hOps, e->ranges);
     ZL_HIP(e, grow_mapped(&c.hRanges, &c.hRangesDev, &c.rangesCap, e->ranges.size()));
     std::memcpy(c.hRanges, e->ranges.data(), e->ranges.size() * sizeof(ZlOpRange));
@@ -774,6 +876,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     if (nblocks < 1 || nblocks > e->cfg.max_batch_blocks) return fail(e, ZLHIP_ERR_CAPACITY, "nblocks exceeds max_batch_blocks");
     if (nframes < 64 || nframes > e->cfg.max_frames || (nframes % 64) != 0 || (nframes > 256 && (nframes % 256) != 0))
         return fail(e, ZLHIP_ERR_INVALID, "nframes must be a multiple of 64 (of 256 above 256) and <= max_frames");
+    if (e->failed) return fail(e, ZLHIP_ERR_STATE, "engine failed (the resident kernel stopped answering in the middle of a cycle): destroy it");
     ZL_HIP(e, hipSetDevice(e->device));
     { int r_ = rt_stop(e); if (r_ != ZLHIP_OK) return r_; }         // a batch shares the voice table and the plan records with the resident kernel
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
@@ -816,6 +919,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     if (e->trace) {
         const size_t need = (size_t)nblocks * e->V * nframes;
         if (need > e->traceInts) {
+            ZlQuiesce quiet(e);
             if (e->dTrace) ZL_HIP(e, hipFree(e->dTrace));
             ZL_HIP(e, dalloc(&e->dTrace, need));
             e->traceInts = need;
@@ -904,7 +1008,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         // every (block, voice) of a window asks for at most one slot: the next window of this set counts from past that
         Aw.ctl_base = q.ctlBase;
         q.ctlBase += (unsigned long long)Aw.K * (unsigned long long)e->V + 1ull;
-        if (w > 0) { Aw.n_op_ranges = 0; Aw.ops = nullptr; Aw.op_ranges = nullptr; }     // commands apply before the first block only
+        if (w > 0) { Aw.n_op_ranges = 0; Aw.ops = nullptr; Aw.op_ranges = nullptr; Aw.n_clip_edits = 0; Aw.clip_edits = nullptr; }   // commands and parameter edits apply before the first block only
         // planning may not overwrite a record set while an earlier window (of this or the previous call) still renders from it
         if (ps != s && q.used) ZL_HIP(e, hipStreamWaitEvent(ps, q.renderedEv, 0));
         ZL_KERNEL(e, zl_launch_apply_ops(Aw, ps));
@@ -971,7 +1075,7 @@ int zlhip_host_alloc(size_t bytes, void **out)
     return hipHostMalloc(out, bytes) == hipSuccess ? ZLHIP_OK : ZLHIP_ERR_CAPACITY;
 }
 
-void zlhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+void zlhip_host_free(void *p) { if (p) { ZlQuiesce quiet(nullptr); (void)hipHostFree(p); } }
 
 static int bounce_body(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_clock *clocks, void *host_out, bool pcm, int64_t sub)
 {
@@ -1034,8 +1138,10 @@ int zlhip_bounce(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_
     }
     const size_t needFloats = (size_t)B * 2 * (size_t)sub * (size_t)nframes, needFrames = (size_t)B * (size_t)sub * (size_t)nframes;
     if (q.busFloats < needFloats || (pcm && q.pcmFrames < needFrames)) {
+        { int r_ = rt_stop(e); if (r_ != ZLHIP_OK) return r_; }
         { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
         ZL_HIP(e, hipStreamSynchronize(q.copyStream));
+        ZlQuiesce quiet(e);                                        // hipFree waits for the device
         for (int i = 0; i < NBUF; ++i) {
             if (q.busFloats < needFloats) {
                 if (q.bus[i]) { ZL_HIP(e, hipFree(q.bus[i])); q.bus[i] = nullptr; }
@@ -1095,8 +1201,11 @@ static bool rt_eligible(zlhip_engine *e, int nframes)
     return e->rt.vw > 0;
 }
 
+#define ZL_RT_BUSY 1     // rt_start / rt_render: a device-synchronising call is in progress somewhere in the process -- render this cycle with launches
+
 static int rt_start(zlhip_engine *e, int nframes)
 {
+    if (g_rt.quiescing.load(std::memory_order_acquire) > 0) return ZL_RT_BUSY;
     { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     for (auto &c : e->slots) if (c.inflight) { ZL_HIP(e, hipEventSynchronize(c.done)); c.inflight = false; int h_ = harvest_slot(e, c); if (h_ != ZLHIP_OK) return h_; }
     if (e->planStream) ZL_HIP(e, hipStreamSynchronize(e->planStream));
@@ -1129,9 +1238,15 @@ static int rt_start(zlhip_engine *e, int nframes)
     A.ctl_P = q.ctlP; A.ctl_env = q.ctlEnv; A.partials = q.partials; A.ctl_next = q.ctlNext; A.sim_const = q.simConst;
     A.ctl_slots = e->ctlSlotsOverride >= 0 ? std::min<int>(e->ctlSlotsOverride, (int)(e->ctlPoolFrames / (size_t)nframes)) : (int)std::min<size_t>(e->ctlPoolFrames / (size_t)nframes, 0x7fffffff);
     // (every cycle is a plan window of its own: its pool base travels in the mailbox)
-    e->rt.h->state = 0;
+    // registered and launched under the registry's lock: a thread that starts a device-synchronising call either sees this engine
+    // in the registry (and its kernel will read the request), or this thread sees its request and does not launch
+    std::lock_guard<std::mutex> lk(g_rt.mu);
+    if (g_rt.quiescing.load(std::memory_order_acquire) > 0) return ZL_RT_BUSY;
+    __atomic_store_n(&e->rt.h->state, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&e->rt.h->yield, 0u, __ATOMIC_RELEASE);
     ZL_KERNEL(e, zl_launch_rt_loop(A, e->rt.d, e->rt.dev, e->rt.seq, e->rt.idleTicks, e->dGain, c.hReportsDev, c.hGainDev, e->rt.devRanges, std::max(e->rt.vw, 1), std::min(256, nframes), e->rt.stream));
     e->rt.running = true; e->rt.nframes = nframes;
+    if (std::find(g_rt.engines.begin(), g_rt.engines.end(), e) == g_rt.engines.end()) g_rt.engines.push_back(e);
     return ZLHIP_OK;
 }
 
@@ -1145,15 +1260,25 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
         if (rc != ZLHIP_OK) return rc;
     }
     ZlBatch A; std::memset(&A, 0, sizeof A);
-    // the block's voice operations: mapped host memory, read in place by the kernel.  (Growing the buffers frees pinned memory,
-    // which waits for the device: stop the kernel first.)
-    if (e->hc.pendingOps.size() > c.opsCap || e->hc.pendingOps.size() > c.rangesCap) { int rc = rt_stop(e); if (rc != ZLHIP_OK) return rc; }
+    // the block's voice operations and clip edits: mapped host memory, read in place by the kernel.  (Growing the buffers frees
+    // pinned memory, which waits for the device: stop the kernel first, and grow them before it is started again.)
+    if (e->hc.pendingOps.size() > c.opsCap || e->hc.pendingOps.size() > c.rangesCap || e->hc.pendingClipEdits.size() > c.editsCap) {
+        int rc = rt_stop(e);
+        if (rc != ZLHIP_OK) return rc;
+        ZlQuiesce quiet(e);
+        ZL_HIP(e, grow_mapped(&c.hOps, &c.hOpsDev, &c.opsCap, e->hc.pendingOps.size()));
+        ZL_HIP(e, grow_mapped(&c.hRanges, &c.hRangesDev, &c.rangesCap, e->hc.pendingOps.size()));
+        ZL_HIP(e, grow_mapped(&c.hEdits, &c.hEditsDev, &c.editsCap, e->hc.pendingClipEdits.size()));
+    }
+    // (started before the operations are taken out of the host's pending list: when the start is refused, the cycle goes through
+    // the launched path with everything still pending)
+    if (!e->rt.running) { int rc = rt_start(e, nframes); if (rc != ZLHIP_OK) return rc; }
     int rc = upload_ops(e, c, A);
     if (rc != ZLHIP_OK) return rc;
-    if (!e->rt.running) { rc = rt_start(e, nframes); if (rc != ZLHIP_OK) return rc; }
     ZlRtShared *sh = e->rt.h;
     ZlHostControl::fill_clock(sh->clock, *clock, nframes);
     sh->nframes = nframes; sh->n_op_ranges = A.n_op_ranges; sh->ops = A.ops; sh->op_ranges = A.op_ranges;
+    sh->n_clip_edits = A.n_clip_edits; sh->clip_edits = A.clip_edits;
     sh->ctl_base = q.ctlBase; q.ctlBase += (unsigned long long)e->V + 1ull;
     const unsigned long long seq = ++e->rt.seq;
     __atomic_store_n(&sh->cmd_seq, seq, __ATOMIC_RELEASE);
@@ -1167,16 +1292,23 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
                 ZL_HIP(e, hipStreamSynchronize(e->rt.stream));
                 e->rt.running = false;
                 if (__atomic_load_n(&sh->done_seq, __ATOMIC_ACQUIRE) == seq) break;
+                rt_unregister(e);
                 e->rt.seq = seq - 1;                               // the restarted kernel must see `seq` as new
-                rc = rt_start(e, nframes);
+                // (a device-synchronising call somewhere in the process made the kernel leave with this cycle posted but not taken:
+                // wait for that call to end -- it is a one-off of some milliseconds -- the cycle's inputs are in the mailbox already)
+                while ((rc = rt_start(e, nframes)) == ZL_RT_BUSY && std::chrono::steady_clock::now() - spin0 < std::chrono::seconds(2)) { }
                 e->rt.seq = seq;
-                if (rc != ZLHIP_OK) return rc;
+                if (rc != ZLHIP_OK) return rc == ZL_RT_BUSY ? fail(e, ZLHIP_ERR_STATE, "resident real-time kernel kept out by a device-wide wait") : rc;
             }
-            // (two seconds: hundreds of block periods.  Stop asking the kernel for blocks and fall back to launches from now on)
+            // (two seconds: hundreds of block periods)
             if (std::chrono::steady_clock::now() - spin0 > std::chrono::seconds(2)) {
                 e->rt.enabled = false;
                 (void)rt_stop(e);
-                return fail(e, ZLHIP_ERR_STATE, "resident real-time kernel does not answer");
+                if (__atomic_load_n(&sh->done_seq, __ATOMIC_ACQUIRE) == seq) break;      // it did finish the cycle after all: deliver it; launches from now on
+                // The cycle was posted and its voice operations were taken: some buses may have applied and rendered it, others not.
+                // The voice table no longer matches the host's control state -- not recoverable: every later render call fails.
+                e->failed = true;
+                return fail(e, ZLHIP_ERR_STATE, "resident real-time kernel does not answer; the engine is unusable (destroy it)");
             }
         }
     }
@@ -1198,9 +1330,12 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
 int zlhip_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right)
 {
     if (!e || !clock || !out_left || !out_right) return ZLHIP_ERR_INVALID;
+    if (e->failed) return fail(e, ZLHIP_ERR_STATE, "engine failed (the resident kernel stopped answering in the middle of a cycle): destroy it");
     if (nframes >= 64 && nframes <= e->cfg.max_frames && (nframes % 64) == 0 && rt_eligible(e, nframes)) {
         ZL_HIP(e, hipSetDevice(e->device));
-        return rt_render(e, nframes, clock, out_left, out_right);
+        const int rc = rt_render(e, nframes, clock, out_left, out_right);
+        if (rc != ZL_RT_BUSY) return rc;
+        // a device-synchronising call is in progress in the process: this cycle is rendered with launches (same results)
     }
     // the block's mix is written by the kernels straight into mapped host memory (24 KB for 12 buses x 256 frames):
     // no copy command after the render, one wait for the call's completion event

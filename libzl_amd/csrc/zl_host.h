@@ -41,6 +41,11 @@ struct ZlHostControl {
     std::vector<ZlHostVoice> voices;
     std::vector<ZlVoiceOp> pendingOps;
     std::vector<uint32_t> opOrder;
+    // clip-parameter edits since the last render call, one per clip (a later edit of the same clip replaces the earlier one):
+    // the device applies them at the start of the next call / cycle, where the reference's voices read the parameters
+    // (SamplerSynthVoice.cpp:189-196).  The host mirror clipParams is updated at once: commands handled after an edit see it,
+    // as startNote does (SamplerSynthVoice.cpp:115-121).
+    std::vector<ZlClipEdit> pendingClipEdits;
 
     void init(int B, int VPB, int max_sounds, double fs)
     {
@@ -50,6 +55,17 @@ struct ZlHostControl {
         soundUsed.assign((size_t)max_sounds, 0);
         voices.assign((size_t)B * VPB, ZlHostVoice());
         pendingOps.clear();
+        pendingClipEdits.clear();
+    }
+
+    void set_clip_params(int id, const zlhip_clip_params &p)
+    {
+        clipParams[(size_t)id] = p;
+        ZlClipEdit *slot = nullptr;
+        for (ZlClipEdit &e : pendingClipEdits) if (e.clip == id) { slot = &e; break; }
+        if (!slot) { pendingClipEdits.emplace_back(); slot = &pendingClipEdits.back(); }
+        slot->clip = id; slot->pad = 0;
+        fill_clip(slot->c, p);
     }
 
     static float adsr_rate(float distance, float timeInSeconds, double sr)      // juce::ADSR::recalculateRates

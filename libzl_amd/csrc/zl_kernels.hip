@@ -16,14 +16,31 @@
 // sequence; see zl_render.h).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <algorithm>
 #include "zl_types.h"
 #include "zl_plan.h"
 #include "zl_render.h"
 #include "zl_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
+// One clip-parameter edit (zlhip_clip_set) -> the HBM clip table, by the 64 lanes of a wave, word by word.  The record sits in
+// mapped host memory; the table is read by the planner at the start of the plan window that follows (zl_plan.h, begin).
+static __device__ __forceinline__ void zl_apply_clip_edit(const ZlBatch &A, const ZlClipEdit *ed, int lane)
+{
+    const int clip = ed->clip;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&ed->c);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(const_cast<ZlClip *>(A.clips) + clip);
+    for (int w = lane; w < (int)(sizeof(ZlClip) / 4); w += 64) dst[w] = src[w];
+}
+
+// workgroups [0, ceil(n_op_ranges / 64)): one lane per voice with operations; the following n_clip_edits workgroups: one edit each
 __global__ void zl_k0_apply_ops(const ZlBatch A)
 {
+    const int opGroups = (A.n_op_ranges + 63) / 64;
+    if ((int)blockIdx.x >= opGroups) {
+        zl_apply_clip_edit(A, A.clip_edits + ((int)blockIdx.x - opGroups), (int)threadIdx.x);
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_op_ranges) return;
     const ZlOpRange rg = A.op_ranges[i];
@@ -1071,12 +1088,15 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
                 for (;;) {
                     const unsigned long long q = __hip_atomic_load(&sh->cmd_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (q != last) {
+                        // the host published the block's inputs with a release store of cmd_seq: acquire before reading them (the same
+                        // mailbox lines are read every cycle; without this a cycle may see the previous cycle's cached clock or pool base)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
                         // the block's inputs: out of host memory once, into HBM for everybody (words first, then the sequence number)
                         unsigned long long w[ZL_RT_CMD_WORDS];
                         w[0] = (unsigned long long)(uint32_t)sh->nframes | ((unsigned long long)(uint32_t)sh->n_op_ranges << 32);
                         w[1] = (unsigned long long)(uintptr_t)sh->ops; w[2] = (unsigned long long)(uintptr_t)sh->op_ranges; w[3] = sh->ctl_base;
                         w[4] = sh->clock.current_usecs; w[5] = sh->clock.next_usecs; w[6] = sh->clock.playhead; w[7] = sh->clock.playhead_usecs;
-                        w[8] = sh->clock.subbeat_usecs; w[9] = sh->clock.usecs_per_frame; w[10] = 0; w[11] = 0;
+                        w[8] = sh->clock.subbeat_usecs; w[9] = sh->clock.usecs_per_frame; w[10] = (unsigned long long)(uint32_t)sh->n_clip_edits; w[11] = (unsigned long long)(uintptr_t)sh->clip_edits;
 #pragma unroll
                         for (int i = 0; i < ZL_RT_CMD_WORDS; ++i) { s_cmd[1 + i] = w[i]; __hip_atomic_store(&dev->cmd[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1085,7 +1105,8 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
                         s_cmd[0] = q; go = 1;
                         break;
                     }
-                    if (__hip_atomic_load(&sh->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || __builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) {
+                    if (__hip_atomic_load(&sh->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || __hip_atomic_load(&sh->yield, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                        || __builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) {
                         __hip_atomic_store(&dev->pub_seq, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody leaves
                         break;
                     }
@@ -1116,6 +1137,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         A.ctl_base = s_cmd[4];
         A.clock0.current_usecs = s_cmd[5]; A.clock0.next_usecs = s_cmd[6]; A.clock0.playhead = s_cmd[7]; A.clock0.playhead_usecs = s_cmd[8];
         A.clock0.subbeat_usecs = s_cmd[9]; A.clock0.usecs_per_frame = s_cmd[10];
+        A.n_clip_edits = (int)(uint32_t)s_cmd[11]; A.clip_edits = reinterpret_cast<const ZlClipEdit *>((uintptr_t)s_cmd[12]);
         A.inline_clock = 1; A.fuse_assemble = 1;
         if (WIDE && z == 0) {
             // workgroup 0: the block's operation ranges host memory -> HBM (behind a system-scope acquire: the host reuses its buffers
@@ -1134,10 +1156,14 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         // ---- K0: the operations of this workgroup's voices (the ranges are sorted by voice).  Narrow buses read ranges and
         //      operations in host memory in place (system-scope acquire, as above); wide buses read the ranges from workgroup 0's
         //      copy in HBM (agent-scope acquire: it may sit in another XCD's L2) and only their own operations from host memory
-        if (A.n_op_ranges > 0) {
+        if (A.n_op_ranges > 0 || A.n_clip_edits > 0) {
             if (WIDE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         }
+        // ---- the cycle's clip-parameter edits: EVERY workgroup writes all of them into the HBM clip table (the same bytes; a few per
+        //      cycle at most).  A workgroup then plans from what it wrote itself -- its own XCD's L2 -- so no hand-off between
+        //      workgroups is needed, and the table is complete in HBM when the kernel leaves.
+        for (int i = tid >> 6; i < A.n_clip_edits; i += (int)(blockDim.x >> 6)) zl_apply_clip_edit(A, A.clip_edits + i, lane);
         const ZlOpRange *ranges = WIDE ? dev_ranges : A.op_ranges;
         for (int i = tid; i < A.n_op_ranges; i += (int)blockDim.x) {
             const ZlOpRange rg = ranges[i];
@@ -1491,8 +1517,8 @@ __global__ void zl_k_interleave(const float *L, const float *R, float *dst, int 
 
 int zl_launch_apply_ops(const ZlBatch &A, hipStream_t s)
 {
-    if (A.n_op_ranges <= 0) return 0;
-    hipLaunchKernelGGL(zl_k0_apply_ops, dim3((A.n_op_ranges + 63) / 64), dim3(64), 0, s, A);
+    if (A.n_op_ranges <= 0 && A.n_clip_edits <= 0) return 0;
+    hipLaunchKernelGGL(zl_k0_apply_ops, dim3((std::max(A.n_op_ranges, 0) + 63) / 64 + std::max(A.n_clip_edits, 0)), dim3(64), 0, s, A);
     ZL_LAUNCH_CHECK();
     return 0;
 }

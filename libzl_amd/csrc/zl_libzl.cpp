@@ -12,6 +12,7 @@
 // build keeps its own ClipAudioSource_* / JackPassthrough_* bodies, calling the engine from them.
 #ifndef ZLHIP_NO_LIBZL_NAMES
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -23,6 +24,7 @@
 
 #include "../../include/libzl_hotpath.h"
 #include "zl_render.h"       // zl_pcm16: the recorder's 16-bit sample format
+#include "zl_sched.h"        // the ClipCommand scheduling front-end (SyncTimer.cpp:452-702,1011-1048)
 
 namespace {
 
@@ -94,12 +96,26 @@ struct PassState { float dry = 1.0f, fx1 = 1.0f, fx2 = 1.0f, pan = 0.0f; bool mu
 
 }  // namespace
 
+// ---- what the real-time thread reads of a clip: published by the setters through a sequence lock ----------------------
+// The reference's setters run unlocked on the caller's thread and the voice reads the fields per block
+// (libzl.cpp:230-302, SamplerSynthVoice.cpp:189-196).  Here a setter (UI thread; setters of one clip are serialised among
+// themselves by the clip's setMu, which the real-time thread never takes) writes the clip's fields and publishes a snapshot:
+// sequence odd, copy, sequence even, dirty.  The cycle (libzl_hotpath_process / _cycle) picks dirty snapshots up at its top
+// and hands them to zlhip_clip_set, which makes no HIP call -- the device applies them at the cycle boundary.  A snapshot that
+// is being written at that instant is taken at the next cycle: the real-time thread never waits for a setter.
+struct ClipSnapshot {
+    std::atomic<uint32_t> seq{0};
+    std::atomic<bool> dirty{false};
+    zlhip_clip_params params;                                       // guarded by seq
+};
+
 struct ClipAudioSource {
     int id = 0;
     int engineClip = -1;
     std::string fileName, filePath;
     double sourceSampleRate = 0.0;
     int lengthFrames = 0;
+    std::mutex setMu;                                              // setters only
     // ClipAudioSource::Private (ClipAudioSource.cpp:63-82)
     float startPositionInSeconds = 0;
     float lengthInSeconds = -1;
@@ -112,17 +128,64 @@ struct ClipAudioSource {
     std::vector<double> slicePositions;
     int sliceBaseMidiNote = 60, keyZoneStart = 0, keyZoneEnd = 127, rootNote = 60;
     AdsrParams adsr;
+    ClipSnapshot snap;
+    // real-time side
     PositionsModel positions;
-    void (*progressCb)(float) = nullptr;
-    void (*levelCb)(float) = nullptr;
+    std::atomic<float> startPositionRt{0.0f};                      // startPositionInSeconds as the cycle reads it (syncProgress, :227)
+    std::atomic<void (*)(float)> progressCb{nullptr}, levelCb{nullptr};
+    std::atomic<float> peakGainOut{0.0f};                          // positionsModel->peakGain() / firstProgress() after the last cycle
+    std::atomic<double> firstProgressOut{-1.0};
     double currentLeveldB = -400.0, prevLeveldB = -400.0, firstPositionProgress = 0.0;
     int64_t nextGainUpdateTime = 0, nextPositionUpdateTime = 0;
 };
 
 namespace {
 
+// ---- requests from any thread to the cycle: a bounded lock-free multi-producer queue (per-cell sequence numbers) -------------
+// ClipAudioSource::play / stop call SyncTimer::scheduleClipCommand on the caller's thread in the reference (the step lists are
+// QLists touched without a lock); here the caller only posts the request and the cycle applies it -- in arrival order, before it
+// looks at the steps that are due -- so the scheduler's state belongs to one thread and the caller never holds a lock the
+// real-time thread wants.
+struct Request {
+    enum Kind : int32_t { Schedule, QueueStart, QueueStop, TimerStart, TimerStop, SetBpm, TimerTick } kind;
+    int32_t a, b;                                                  // QueueStart/Stop: clip, channel; TimerStart / SetBpm: bpm
+    uint64_t delay;
+    zlhip_clip_command cmd;
+};
+
+struct RequestQueue {
+    static constexpr size_t CAP = 4096;                            // FreshCommandStashSize, SyncTimer.cpp:252
+    struct Cell { std::atomic<size_t> seq; Request r; };
+    Cell cells[CAP];
+    std::atomic<size_t> head{0}, tail{0};
+    RequestQueue() { for (size_t i = 0; i < CAP; ++i) cells[i].seq.store(i, std::memory_order_relaxed); }
+    bool push(const Request &r)
+    {
+        size_t pos = tail.load(std::memory_order_relaxed);
+        for (;;) {
+            Cell &c = cells[pos % CAP];
+            const size_t sq = c.seq.load(std::memory_order_acquire);
+            const intptr_t d = (intptr_t)sq - (intptr_t)pos;
+            if (d == 0) { if (tail.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) { c.r = r; c.seq.store(pos + 1, std::memory_order_release); return true; } }
+            else if (d < 0) return false;                          // full
+            else pos = tail.load(std::memory_order_relaxed);
+        }
+    }
+    bool pop(Request &r)                                           // single consumer: the cycle
+    {
+        const size_t pos = head.load(std::memory_order_relaxed);
+        Cell &c = cells[pos % CAP];
+        if (c.seq.load(std::memory_order_acquire) != pos + 1) return false;
+        r = c.r;
+        c.seq.store(pos + CAP, std::memory_order_release);
+        head.store(pos + 1, std::memory_order_relaxed);
+        return true;
+    }
+    void clear() { Request r; while (pop(r)) { } }
+};
+
 struct Global {
-    std::mutex mu;
+    std::mutex mu;                             // the engine, the clip list, the scheduler: held by a cycle; by create / destroy / init / shutdown
     zlhip_config cfg;
     bool cfgSet = false;
     zlhip_engine *engine = nullptr;
@@ -132,13 +195,26 @@ struct Global {
     std::vector<int64_t> voicePositionId;      // per voice slot: row in its clip's positions model
     std::vector<ClipAudioSource *> voiceClip;  // per voice slot: clip being played (host view)
     std::vector<zlhip_voice_report> reports;
+    RequestQueue requests;
+    ZlStepSequencer seq;                       // SyncTimer's step ring (libzl_hotpath_cycle)
+    ZlHostTransportSchedule ext;               // the host's SyncTimer owns the transport (libzl_hotpath_process)
+    std::vector<ZlDispatch> due;               // commands of the steps due in this cycle
+    std::vector<zlhip_clip_command> dueBatch;
+    uint32_t lastNframes = 0;
+    std::atomic<uint64_t> dropped{0};          // requests lost to a full queue
     PassState pass[11];                        // [0] GlobalPlayback (channel -1), [1..10] channels 0..9 (MidiRouter.cpp:876-883)
 } G;
 
-void push_params(ClipAudioSource *c)
+struct PendingCallback { void (*fn)(float); float value; };
+
+// setters: the clip's fields -> its published snapshot (call with c->setMu held)
+void publish_params(ClipAudioSource *c)
 {
-    if (!G.engine || c->engineClip < 0) return;
-    zlhip_clip_params p;
+    ClipSnapshot &sn = c->snap;
+    const uint32_t s0 = sn.seq.load(std::memory_order_relaxed);
+    sn.seq.store(s0 + 1, std::memory_order_relaxed);
+    std::atomic_thread_fence(std::memory_order_release);
+    zlhip_clip_params &p = sn.params;
     std::memset(&p, 0, sizeof p);
     p.start_position_seconds = c->startPositionInSeconds;
     p.length_seconds = c->lengthInSeconds;
@@ -150,7 +226,26 @@ void push_params(ClipAudioSource *c)
     p.root_note = c->rootNote;
     p.num_slice_positions = (int32_t)std::min<size_t>(c->slicePositions.size(), ZLHIP_MAX_SLICES);
     for (int i = 0; i < p.num_slice_positions; ++i) p.slice_positions[i] = c->slicePositions[(size_t)i];
-    zlhip_clip_set(G.engine, c->engineClip, &p);
+    std::atomic_thread_fence(std::memory_order_release);
+    sn.seq.store(s0 + 2, std::memory_order_release);
+    c->startPositionRt.store(c->startPositionInSeconds, std::memory_order_relaxed);
+    sn.dirty.store(true, std::memory_order_release);
+}
+
+// the cycle: a dirty snapshot -> the engine.  Wait-free: a snapshot caught in the middle of a write stays dirty for the next cycle.
+void apply_params(ClipAudioSource *c)
+{
+    if (!G.engine || c->engineClip < 0) return;
+    ClipSnapshot &sn = c->snap;
+    if (!sn.dirty.exchange(false, std::memory_order_acq_rel)) return;
+    const uint32_t s1 = sn.seq.load(std::memory_order_acquire);
+    zlhip_clip_params p;
+    if (!(s1 & 1u)) {
+        std::memcpy(&p, &sn.params, sizeof p);
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (sn.seq.load(std::memory_order_relaxed) == s1) { zlhip_clip_set(G.engine, c->engineClip, &p); return; }
+    }
+    sn.dirty.store(true, std::memory_order_release);
 }
 
 void set_slices(ClipAudioSource *c, int slices)                    // ClipAudioSource.cpp:495-528
@@ -185,6 +280,7 @@ uint64_t f32_to_u64_sat(float f)
     return (uint64_t)f;
 }
 
+// call with G.mu held
 ClipAudioSource *make_clip(const float *L, const float *R, int length, double sr, const char *path)
 {
     ClipAudioSource *c = new ClipAudioSource();
@@ -211,15 +307,24 @@ ClipAudioSource *make_clip(const float *L, const float *R, int length, double sr
     }
     c->id = G.nextClipId++;                                        // libzl.cpp:122-124
     G.clips.push_back(c);
-    push_params(c);
+    { std::lock_guard<std::mutex> sl(c->setMu); publish_params(c); }
+    apply_params(c);
     return c;
 }
 
-void send_command(const zlhip_clip_command &cmd)
+void post(const Request &r)
 {
-    if (!G.engine) return;
-    // voice slots that take this command: remember which clip they play so reports can be routed back
-    zlhip_handle_command(G.engine, &cmd, 0);
+    if (!G.requests.push(r)) {
+        if (G.dropped.fetch_add(1, std::memory_order_relaxed) == 0) std::fprintf(stderr, "libzl hot path: request queue full (no cycle is draining it): requests are dropped\n");
+    }
+}
+
+// SyncTimer::scheduleClipCommand(command, delay) from any thread
+void schedule_command(const zlhip_clip_command &cmd, uint64_t delay)
+{
+    Request r; std::memset(&r, 0, sizeof r);
+    r.kind = Request::Schedule; r.delay = delay; r.cmd = cmd;
+    post(r);
 }
 
 zlhip_clip_command channel_command(ClipAudioSource *c, int midiChannel)   // ClipCommand::channelCommand, ClipCommand.h:66-72
@@ -240,7 +345,7 @@ void clip_play(ClipAudioSource *c, bool loop, int midiChannel)     // ClipAudioS
     cmd.looping = loop ? 1 : 0;
     if (loop) cmd.stop_playback = 1;                               // stops any current loop plays, then starts a new one
     cmd.start_playback = 1;
-    send_command(cmd);
+    schedule_command(cmd, 0);                                      // d->syncTimer->scheduleClipCommand(command, 0), :428
 }
 
 void clip_stop(ClipAudioSource *c, int midiChannel)                // ClipAudioSource::stop, ClipAudioSource.cpp:431-455
@@ -248,42 +353,44 @@ void clip_stop(ClipAudioSource *c, int midiChannel)                // ClipAudioS
     if (midiChannel > -3) {
         zlhip_clip_command cmd = channel_command(c, midiChannel);
         cmd.midi_note = 60; cmd.stop_playback = 1;
-        send_command(cmd);
+        schedule_command(cmd, 0);
     } else {
         zlhip_clip_command cmd = channel_command(c, -2);           // noEffectCommand: midi note 60 (ClipCommand.h:44-51)
         cmd.midi_note = 60; cmd.stop_playback = 1;
-        send_command(cmd);
+        schedule_command(cmd, 0);
         cmd = channel_command(c, -1);                              // effectedCommand
         cmd.midi_note = 60; cmd.stop_playback = 1;
-        send_command(cmd);
+        schedule_command(cmd, 0);
         for (int i = 0; i < 10; ++i) {
             cmd = channel_command(c, i);
             cmd.midi_note = 60; cmd.stop_playback = 1;
-            send_command(cmd);
+            schedule_command(cmd, 0);
         }
     }
 }
 
-void sync_audio_level(ClipAudioSource *c, int64_t now)             // ClipAudioSource::Private::syncAudioLevel, :88-113
+void sync_audio_level(ClipAudioSource *c, int64_t now, std::vector<PendingCallback> &cbs)   // ClipAudioSource::Private::syncAudioLevel, :88-113
 {
     if (c->nextGainUpdateTime < now) {
         c->prevLeveldB = c->currentLeveldB;
         c->currentLeveldB = gainToDecibels(c->positions.peakGain());   // the tracktion LevelMeasurer client stays silent here
         const double prevLevel = decibelsToGain(c->prevLeveldB);
         if (c->prevLeveldB > c->currentLeveldB) c->currentLeveldB = gainToDecibels(prevLevel * 0.94);   // double form, :100-101
-        if (std::fabs(c->currentLeveldB - c->prevLeveldB) > 0.1 && c->levelCb) c->levelCb((float)c->currentLeveldB);
+        void (*cb)(float) = c->levelCb.load(std::memory_order_acquire);
+        if (std::fabs(c->currentLeveldB - c->prevLeveldB) > 0.1 && cb) cbs.push_back(PendingCallback{ cb, (float)c->currentLeveldB });
         c->nextGainUpdateTime = now + 30;
     }
 }
 
-void sync_progress(ClipAudioSource *c, int64_t now)                // ClipAudioSource::syncProgress, :225-240
+void sync_progress(ClipAudioSource *c, int64_t now, std::vector<PendingCallback> &cbs)      // ClipAudioSource::syncProgress, :225-240
 {
     if (c->nextPositionUpdateTime < now) {
-        double newPosition = c->startPositionInSeconds / c->duration;
-        if (c->progressCb != nullptr && c->positions.firstProgress() > -1.0f) newPosition = c->positions.firstProgress();
+        void (*cb)(float) = c->progressCb.load(std::memory_order_acquire);
+        double newPosition = c->startPositionRt.load(std::memory_order_relaxed) / c->duration;
+        if (cb != nullptr && c->positions.firstProgress() > -1.0f) newPosition = c->positions.firstProgress();
         if (std::fabs(c->firstPositionProgress - newPosition) > 0.001) {
             c->firstPositionProgress = newPosition;
-            if (c->progressCb) c->progressCb((float)(c->firstPositionProgress * c->duration));
+            if (cb) cbs.push_back(PendingCallback{ cb, (float)(c->firstPositionProgress * c->duration) });
             c->nextPositionUpdateTime = now + 100;
         }
     }
@@ -300,6 +407,103 @@ PassState *pass_for(int channel)                                   // libzl.cpp:
     if (channel == -1) return &G.pass[0];
     if (channel > -1 && channel < 10) return &G.pass[channel + 1];
     return nullptr;
+}
+
+// the requests posted since the last cycle, in arrival order, into the scheduler that serves this cycle (call with G.mu held)
+void drain_requests(bool internalTransport)
+{
+    Request r;
+    while (G.requests.pop(r)) {
+        switch (r.kind) {
+        case Request::Schedule:
+            if (internalTransport) G.seq.scheduleClipCommand(r.cmd, r.delay); else G.ext.scheduleClipCommand(r.cmd, r.delay);
+            break;
+        case Request::QueueStart:
+            if (internalTransport) G.seq.queueClipToStartOnChannel(r.a, r.b);
+            else {                                                 // (a host-owned transport queues through its own SyncTimer; taken as "paused": now)
+                zlhip_clip_command c; ZlStepSequencer::zlhip_clip_command_clear_inline(c);
+                c.clip = r.a; c.midi_channel = r.b; c.midi_note = 60; c.change_volume = 1; c.volume = 1.0f; c.looping = 1; c.stop_playback = 1; c.start_playback = 1;
+                G.ext.scheduleClipCommand(c, 0);
+            }
+            break;
+        case Request::QueueStop:
+            if (internalTransport) G.seq.queueClipToStopOnChannel(r.a, r.b);
+            else {
+                for (auto &st : G.ext.steps)
+                    for (size_t i = 0; i < st.clipCommands.size(); ++i) if (st.clipCommands[i].clip == r.a) { st.clipCommands.erase(st.clipCommands.begin() + (long)i); break; }
+                zlhip_clip_command c; ZlStepSequencer::zlhip_clip_command_clear_inline(c);
+                c.clip = r.a; c.midi_channel = r.b; c.midi_note = 60; c.stop_playback = 1;
+                size_t i = 0;
+                while (i < G.ext.steps.size() && G.ext.steps[i].due < G.ext.lastPlayhead) ++i;
+                if (i == G.ext.steps.size() || G.ext.steps[i].due != G.ext.lastPlayhead) G.ext.steps.insert(G.ext.steps.begin() + (long)i, ZlHostTransportSchedule::Step{ G.ext.lastPlayhead, {} });
+                G.ext.steps[i].clipCommands.push_back(c);          // appended, not merged (SyncTimer.cpp:858-859)
+            }
+            break;
+        case Request::TimerStart: if (internalTransport) G.seq.start(r.a); break;
+        case Request::TimerStop:  if (internalTransport) G.seq.stop(); break;
+        case Request::SetBpm:     if (internalTransport) G.seq.setBpm((uint64_t)(uint32_t)r.a); break;
+        case Request::TimerTick:  if (internalTransport) G.seq.hi_res_timer_callback(); break;
+        }
+    }
+}
+
+// the commands that fell due -> the engine: one zlhip_handle_commands call per run of equal ticks (a step), i.e. one voice-table
+// update on the device however many commands the cycle carries (SamplerSynth::handleClipCommand per command, SyncTimer.cpp:553-558)
+int dispatch_due()
+{
+    size_t i = 0;
+    while (i < G.due.size()) {
+        size_t j = i;
+        G.dueBatch.clear();
+        while (j < G.due.size() && G.due[j].tick == G.due[i].tick) G.dueBatch.push_back(G.due[j++].cmd);
+        const int rc = zlhip_handle_commands(G.engine, G.dueBatch.data(), (int32_t)G.dueBatch.size(), G.due[i].tick, nullptr);
+        if (rc < 0) return rc;
+        i = j;
+    }
+    G.due.clear();
+    return ZLHIP_OK;
+}
+
+// everything of a cycle behind the command dispatch: render, positions models, level / progress chains (call with G.mu held)
+int render_and_report(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right, std::vector<PendingCallback> &cbs)
+{
+    int rc = zlhip_render(G.engine, (int32_t)nframes, clock, out_left, out_right);
+    if (rc != ZLHIP_OK) return rc;
+    const int V = (int)G.reports.size();
+    rc = zlhip_voice_reports(G.engine, G.reports.data(), V);
+    if (rc != ZLHIP_OK) return rc;
+    const int64_t now = now_ms();
+    // route the per-voice reports into the per-clip positions models (SamplerSynthVoice.cpp:126-129,154-158,265-267)
+    for (int v = 0; v < V; ++v) {
+        const zlhip_voice_report &r = G.reports[(size_t)v];
+        ClipAudioSource *cur = r.playing ? clip_by_engine_id(r.clip) : nullptr;
+        if (G.voiceClip[(size_t)v] != cur) {
+            if (G.voiceClip[(size_t)v]) G.voiceClip[(size_t)v]->positions.remove(G.voicePositionId[(size_t)v], now);
+            G.voiceClip[(size_t)v] = cur;
+            G.voicePositionId[(size_t)v] = cur ? cur->positions.create(0.0f, now) : -1;
+        }
+        if (cur && r.valid) cur->positions.set(G.voicePositionId[(size_t)v], r.gain, r.progress, now);
+    }
+    for (size_t i = 0; i < G.clips.size();) {
+        ClipAudioSource *c = G.clips[i];
+        if (c->id < 0) {            // destroyed by the host: release once no voice plays it any more
+            bool used = false;
+            for (int v = 0; v < V; ++v) used = used || (G.reports[(size_t)v].playing && G.reports[(size_t)v].clip == c->engineClip);
+            if (!used) {
+                if (c->engineClip >= 0) zlhip_sound_release(G.engine, c->engineClip);
+                delete c;
+                G.clips.erase(G.clips.begin() + (long)i);
+                continue;
+            }
+        } else {
+            sync_audio_level(c, now, cbs);
+            sync_progress(c, now, cbs);
+            c->peakGainOut.store(c->positions.peakGain(), std::memory_order_relaxed);
+            c->firstProgressOut.store(c->positions.firstProgress(), std::memory_order_relaxed);
+        }
+        ++i;
+    }
+    return ZLHIP_OK;
 }
 
 // ---- RIFF / WAVE --------------------------------------------------------------------------------
@@ -440,6 +644,7 @@ void initJuce(void)                                                 // libzl.cpp
     G.voicePositionId.assign(V, -1);
     G.voiceClip.assign(V, nullptr);
     G.reports.assign(V, zlhip_voice_report{});
+    G.requests.clear(); G.seq.reset(); G.ext.clear(); G.due.clear(); G.lastNframes = 0;
     for (ClipAudioSource *c : G.clips) c->engineClip = -1;
 }
 
@@ -449,11 +654,16 @@ void shutdownJuce(void)                                             // libzl.cpp
     for (ClipAudioSource *c : G.clips) delete c;
     G.clips.clear();
     if (G.engine) { zlhip_engine_destroy(G.engine); G.engine = nullptr; }
+    G.requests.clear(); G.seq.reset(); G.ext.clear(); G.due.clear();
     G.status = ZLHIP_ERR_STATE;
     G.nextClipId = 1;
 }
 
 // ---- ClipAudioSource bridge -------------------------------------------------------------------------
+// Which calls the real-time thread never waits for: every setter, play / stop / queue, the SyncTimer_* calls below (they post a
+// request or publish a snapshot), and the getters (plain fields or atomics).  Creating and destroying clips, init and shutdown
+// take the cycle's mutex -- the reference marshals them to its message thread and takes SamplerSynth's clip mutex
+// (libzl.cpp:118-128,258-267; SamplerSynth.cpp:287,299).
 ClipAudioSource *ClipAudioSource_byID(int id)                      // libzl.cpp:107-116
 {
     std::lock_guard<std::mutex> lk(G.mu);
@@ -493,20 +703,21 @@ void ClipAudioSource_destroy(ClipAudioSource *c)                   // libzl.cpp:
     G.clips.erase(std::remove(G.clips.begin(), G.clips.end(), c), G.clips.end());
     for (auto &vc : G.voiceClip) if (vc == c) vc = nullptr;
     // the engine keeps the sound until the voices that still play its release tail are done; the slot is
-    // released lazily by libzl_hotpath_process once no voice reports it
+    // released lazily by the cycle once no voice reports it
     c->id = -c->id - 1;
-    G.clips.push_back(c);   // parked (negative id) until its voices ended; see reap in libzl_hotpath_process
+    c->progressCb.store(nullptr); c->levelCb.store(nullptr);
+    G.clips.push_back(c);   // parked (negative id) until its voices ended; see the reap in render_and_report
 }
 
 int ClipAudioSource_id(ClipAudioSource *c) { return c->id; }
 int ClipAudioSource_engineClip(ClipAudioSource *c) { return c->engineClip; }
-void ClipAudioSource_setProgressCallback(ClipAudioSource *c, void (*functionPtr)(float)) { std::lock_guard<std::mutex> lk(G.mu); c->progressCb = functionPtr; }
-void ClipAudioSource_setAudioLevelChangedCallback(ClipAudioSource *c, void (*functionPtr)(float)) { std::lock_guard<std::mutex> lk(G.mu); c->levelCb = functionPtr; }
+void ClipAudioSource_setProgressCallback(ClipAudioSource *c, void (*functionPtr)(float)) { c->progressCb.store(functionPtr, std::memory_order_release); }
+void ClipAudioSource_setAudioLevelChangedCallback(ClipAudioSource *c, void (*functionPtr)(float)) { c->levelCb.store(functionPtr, std::memory_order_release); }
 
-void ClipAudioSource_play(ClipAudioSource *c, bool loop) { std::lock_guard<std::mutex> lk(G.mu); clip_play(c, loop, -2); }            // play(loop) default channel -2
-void ClipAudioSource_stop(ClipAudioSource *c) { std::lock_guard<std::mutex> lk(G.mu); clip_stop(c, -3); }                          // stop() default -3: everywhere
-void ClipAudioSource_playOnChannel(ClipAudioSource *c, bool loop, int midiChannel) { std::lock_guard<std::mutex> lk(G.mu); clip_play(c, loop, midiChannel); }
-void ClipAudioSource_stopOnChannel(ClipAudioSource *c, int midiChannel) { std::lock_guard<std::mutex> lk(G.mu); clip_stop(c, midiChannel); }
+void ClipAudioSource_play(ClipAudioSource *c, bool loop) { clip_play(c, loop, -2); }                                              // play(loop) default channel -2
+void ClipAudioSource_stop(ClipAudioSource *c) { clip_stop(c, -3); }                                                               // stop() default -3: everywhere
+void ClipAudioSource_playOnChannel(ClipAudioSource *c, bool loop, int midiChannel) { clip_play(c, loop, midiChannel); }
+void ClipAudioSource_stopOnChannel(ClipAudioSource *c, int midiChannel) { clip_stop(c, midiChannel); }
 void stopClips(int size, ClipAudioSource **clips) { for (int i = 0; i < size; ++i) ClipAudioSource_stop(clips[i]); }               // libzl.cpp:87-94
 
 float ClipAudioSource_getDuration(ClipAudioSource *c) { return c->duration; }
@@ -514,104 +725,143 @@ const char *ClipAudioSource_getFileName(ClipAudioSource *c) { return c->fileName
 
 void ClipAudioSource_setStartPosition(ClipAudioSource *c, float s)  // ClipAudioSource.cpp:255-259
 {
-    std::lock_guard<std::mutex> lk(G.mu);
+    std::lock_guard<std::mutex> sl(c->setMu);
     c->startPositionInSeconds = std::max(0.0f, s);
-    push_params(c);
+    publish_params(c);
 }
 
 void ClipAudioSource_setLength(ClipAudioSource *c, float beat, int bpm)   // ClipAudioSource.cpp:352-360
 {
-    std::lock_guard<std::mutex> lk(G.mu);
+    std::lock_guard<std::mutex> sl(c->setMu);
     c->lengthInSeconds = subbeat_count_to_seconds((uint64_t)bpm, f32_to_u64_sat(beat * ZLHIP_BEAT_SUBDIVISIONS));
     c->lengthInBeats = beat;
-    push_params(c);
+    publish_params(c);
 }
 
-void ClipAudioSource_setPan(ClipAudioSource *c, float pan) { std::lock_guard<std::mutex> lk(G.mu); if (c->pan != pan) { c->pan = pan; push_params(c); } }                // :623-629
+void ClipAudioSource_setPan(ClipAudioSource *c, float pan) { std::lock_guard<std::mutex> sl(c->setMu); if (c->pan != pan) { c->pan = pan; publish_params(c); } }          // :623-629
 void ClipAudioSource_setSpeedRatio(ClipAudioSource *c, float v) { c->speedRatio = v; }                                             // :292-303 (offline re-render, out of scope)
 void ClipAudioSource_setPitch(ClipAudioSource *c, float v) { c->pitchChange = v; }                                                 // :279-290
 void ClipAudioSource_setGain(ClipAudioSource *c, float db) { c->gainDb = db; }                                                     // :305-311
 
 void ClipAudioSource_setVolume(ClipAudioSource *c, float vol)      // ClipAudioSource.cpp:313-326
 {
-    std::lock_guard<std::mutex> lk(G.mu);
+    std::lock_guard<std::mutex> sl(c->setMu);
     c->volumeAbsolute = (vol <= -40.0f) ? 0.0f : decibelsToVolumeFaderPosition(vol);
-    push_params(c);
+    publish_params(c);
 }
 
 void ClipAudioSource_setVolumeAbsolute(ClipAudioSource *c, float vol)   // ClipAudioSource.cpp:328-336
 {
-    std::lock_guard<std::mutex> lk(G.mu);
+    std::lock_guard<std::mutex> sl(c->setMu);
     c->volumeAbsolute = std::max(0.0f, std::min(vol, 1.0f));
-    push_params(c);
+    publish_params(c);
 }
 
 float ClipAudioSource_volumeAbsolute(ClipAudioSource *c) { return c->volumeAbsolute; }
 float dBFromVolume(float vol) { return volumeFaderPositionToDB(vol); }                                                              // libzl.cpp:429
 
-void ClipAudioSource_setSlices(ClipAudioSource *c, int slices) { std::lock_guard<std::mutex> lk(G.mu); set_slices(c, slices); push_params(c); }
+void ClipAudioSource_setSlices(ClipAudioSource *c, int slices) { std::lock_guard<std::mutex> sl(c->setMu); set_slices(c, slices); publish_params(c); }
 int  ClipAudioSource_keyZoneStart(ClipAudioSource *c) { return c->keyZoneStart; }
 void ClipAudioSource_setKeyZoneStart(ClipAudioSource *c, int v) { c->keyZoneStart = v; }
 int  ClipAudioSource_keyZoneEnd(ClipAudioSource *c) { return c->keyZoneEnd; }
 void ClipAudioSource_setKeyZoneEnd(ClipAudioSource *c, int v) { c->keyZoneEnd = v; }
 int  ClipAudioSource_rootNote(ClipAudioSource *c) { return c->rootNote; }
-void ClipAudioSource_setRootNote(ClipAudioSource *c, int v) { std::lock_guard<std::mutex> lk(G.mu); if (c->rootNote != v) { c->rootNote = v; push_params(c); } }
+void ClipAudioSource_setRootNote(ClipAudioSource *c, int v) { std::lock_guard<std::mutex> sl(c->setMu); if (c->rootNote != v) { c->rootNote = v; publish_params(c); } }
 
 // quirk Q13: every ADSR setter starts from a fresh default Parameters (ClipAudioSource.cpp:636-685)
 float ClipAudioSource_adsrAttack(ClipAudioSource *c) { return c->adsr.attack; }
-void  ClipAudioSource_setADSRAttack(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> lk(G.mu); if (c->adsr.attack != v) { AdsrParams p; p.attack = v; c->adsr = p; push_params(c); } }
+void  ClipAudioSource_setADSRAttack(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> sl(c->setMu); if (c->adsr.attack != v) { AdsrParams p; p.attack = v; c->adsr = p; publish_params(c); } }
 float ClipAudioSource_adsrDecay(ClipAudioSource *c) { return c->adsr.decay; }
-void  ClipAudioSource_setADSRDecay(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> lk(G.mu); if (c->adsr.decay != v) { AdsrParams p; p.decay = v; c->adsr = p; push_params(c); } }
+void  ClipAudioSource_setADSRDecay(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> sl(c->setMu); if (c->adsr.decay != v) { AdsrParams p; p.decay = v; c->adsr = p; publish_params(c); } }
 float ClipAudioSource_adsrSustain(ClipAudioSource *c) { return c->adsr.sustain; }
-void  ClipAudioSource_setADSRSustain(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> lk(G.mu); if (c->adsr.sustain != v) { AdsrParams p; p.sustain = v; c->adsr = p; push_params(c); } }
+void  ClipAudioSource_setADSRSustain(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> sl(c->setMu); if (c->adsr.sustain != v) { AdsrParams p; p.sustain = v; c->adsr = p; publish_params(c); } }
 float ClipAudioSource_adsrRelease(ClipAudioSource *c) { return c->adsr.release; }
-void  ClipAudioSource_setADSRRelease(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> lk(G.mu); if (c->adsr.release != v) { AdsrParams p; p.release = v; c->adsr = p; push_params(c); } }
+void  ClipAudioSource_setADSRRelease(ClipAudioSource *c, float v) { std::lock_guard<std::mutex> sl(c->setMu); if (c->adsr.release != v) { AdsrParams p; p.release = v; c->adsr = p; publish_params(c); } }
 
-float ClipAudioSource_peakGain(ClipAudioSource *c) { std::lock_guard<std::mutex> lk(G.mu); return c->positions.peakGain(); }
-double ClipAudioSource_firstProgress(ClipAudioSource *c) { std::lock_guard<std::mutex> lk(G.mu); return c->positions.firstProgress(); }
+// positionsModel->peakGain() / firstProgress() as the last cycle left them (the cycle calls peakGain() itself, ClipAudioSource.cpp:92,
+// so a read between two cycles returns exactly this value)
+float ClipAudioSource_peakGain(ClipAudioSource *c) { return c->peakGainOut.load(std::memory_order_relaxed); }
+double ClipAudioSource_firstProgress(ClipAudioSource *c) { return c->firstProgressOut.load(std::memory_order_relaxed); }
 
-int SyncTimer_getMultiplier(void) { return ZLHIP_BEAT_SUBDIVISIONS; }   // SyncTimer.cpp:946-948
+// ---- SyncTimer bridge: the part that schedules ClipCommands (libzl.h:69-79, libzl.cpp:311-349) -------------------------------
+int  SyncTimer_getMultiplier(void) { return ZLHIP_BEAT_SUBDIVISIONS; }   // SyncTimer.cpp:946-948
+void SyncTimer_startTimer(int interval) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::TimerStart; r.a = interval; post(r); }   // syncTimer->start(interval): the argument is the bpm (SyncTimer.cpp:870-872)
+void SyncTimer_stopTimer(void) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::TimerStop; post(r); }
+void SyncTimer_setBpm(unsigned int bpm) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::SetBpm; r.a = (int32_t)bpm; post(r); }
+void SyncTimer_queueClipToStartOnChannel(ClipAudioSource *clip, int midiChannel) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::QueueStart; r.a = clip->engineClip; r.b = midiChannel; post(r); }
+void SyncTimer_queueClipToStopOnChannel(ClipAudioSource *clip, int midiChannel) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::QueueStop; r.a = clip->engineClip; r.b = midiChannel; post(r); }
+void SyncTimer_queueClipToStart(ClipAudioSource *clip) { SyncTimer_queueClipToStartOnChannel(clip, -1); }   // SyncTimer.cpp:862-864
+void SyncTimer_queueClipToStop(ClipAudioSource *clip) { SyncTimer_queueClipToStopOnChannel(clip, -1); }     // :866-868
+void libzl_hotpath_schedule_clip_command(const zlhip_clip_command *command, uint64_t delay) { if (command) schedule_command(*command, delay); }
+void libzl_hotpath_timer_tick(void) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::TimerTick; post(r); }
+
+int libzl_hotpath_transport(zlhip_clock *out)
+{
+    if (!out) return ZLHIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(G.mu);
+    std::memset(out, 0, sizeof *out);
+    out->jack_playhead = G.seq.jackPlayheadGetter();
+    out->jack_playhead_usecs = G.seq.jackPlayheadUsecsGetter();
+    out->jack_subbeat_length_usecs = G.seq.jackSubbeatLengthInMicroseconds;
+    return ZLHIP_OK;
+}
 
 // ---- the per-cycle seam -------------------------------------------------------------------------------
+static void fire(std::vector<PendingCallback> &cbs)
+{
+    // outside the cycle's mutex: a callback may call back into this API (peakGain, byID, a setter)
+    for (const PendingCallback &cb : cbs) cb.fn(cb.value);
+    cbs.clear();
+}
+
+// host-owned transport: the host's SyncTimer getters arrive in `clock`
 int libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right)
 {
-    std::lock_guard<std::mutex> lk(G.mu);
-    if (!G.engine) return G.status;
-    int rc = zlhip_render(G.engine, (int32_t)nframes, clock, out_left, out_right);
-    if (rc != ZLHIP_OK) return rc;
-    const int V = (int)G.reports.size();
-    rc = zlhip_voice_reports(G.engine, G.reports.data(), V);
-    if (rc != ZLHIP_OK) return rc;
-    const int64_t now = now_ms();
-    // route the per-voice reports into the per-clip positions models (SamplerSynthVoice.cpp:126-129,154-158,265-267)
-    for (int v = 0; v < V; ++v) {
-        const zlhip_voice_report &r = G.reports[(size_t)v];
-        ClipAudioSource *cur = r.playing ? clip_by_engine_id(r.clip) : nullptr;
-        if (G.voiceClip[(size_t)v] != cur) {
-            if (G.voiceClip[(size_t)v]) G.voiceClip[(size_t)v]->positions.remove(G.voicePositionId[(size_t)v], now);
-            G.voiceClip[(size_t)v] = cur;
-            G.voicePositionId[(size_t)v] = cur ? cur->positions.create(0.0f, now) : -1;
-        }
-        if (cur && r.valid) cur->positions.set(G.voicePositionId[(size_t)v], r.gain, r.progress, now);
+    static thread_local std::vector<PendingCallback> cbs;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        if (!G.engine) return G.status;
+        if (!clock) return ZLHIP_ERR_INVALID;
+        G.ext.lastPlayhead = clock->jack_playhead;                  // a delay counts from the playhead of the cycle that takes the request
+        drain_requests(false);
+        for (ClipAudioSource *c : G.clips) if (c->id >= 0) apply_params(c);
+        G.ext.process(clock->jack_playhead, G.due);                 // currentTick = the host's jackPlayhead (SyncTimer.cpp:553-558)
+        rc = dispatch_due();
+        if (rc == ZLHIP_OK) rc = render_and_report(nframes, clock, out_left, out_right, cbs);
     }
-    for (size_t i = 0; i < G.clips.size();) {
-        ClipAudioSource *c = G.clips[i];
-        if (c->id < 0) {            // destroyed by the host: release once no voice plays it any more
-            bool used = false;
-            for (int v = 0; v < V; ++v) used = used || (G.reports[(size_t)v].playing && G.reports[(size_t)v].clip == c->engineClip);
-            if (!used) {
-                if (c->engineClip >= 0) zlhip_sound_release(G.engine, c->engineClip);
-                delete c;
-                G.clips.erase(G.clips.begin() + (long)i);
-                continue;
-            }
-        } else {
-            sync_audio_level(c, now);
-            sync_progress(c, now);
+    fire(cbs);
+    return rc;
+}
+
+// the library's own transport: SyncTimerPrivate::process for this JACK cycle, then every SamplerChannel (the order in which the two
+// JACK clients run inside a cycle is not defined in the reference; here the commands of a cycle reach the channels in the same cycle)
+int libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, float *out_left, float *out_right)
+{
+    static thread_local std::vector<PendingCallback> cbs;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        if (!G.engine) return G.status;
+        if (nframes == 0 || next_usecs < current_usecs) return ZLHIP_ERR_INVALID;
+        if (nframes != G.lastNframes) { G.seq.set_jack_latency(nframes, G.cfgSet ? G.cfg.playback_sample_rate : 48000.0); G.lastNframes = nframes; }
+        drain_requests(true);
+        for (ClipAudioSource *c : G.clips) if (c->id >= 0) apply_params(c);
+        G.seq.process(nframes, current_usecs, next_usecs, period_usecs, G.due);
+        rc = dispatch_due();
+        if (rc == ZLHIP_OK) {
+            zlhip_clock clk;
+            clk.current_usecs = current_usecs; clk.next_usecs = next_usecs;
+            clk.jack_playhead = G.seq.jackPlayheadGetter();                         // SamplerSynthVoice.cpp:179-182,232-237 read these getters
+            clk.jack_playhead_usecs = G.seq.jackPlayheadUsecsGetter();
+            clk.jack_subbeat_length_usecs = G.seq.jackSubbeatLengthInMicroseconds;
+            rc = render_and_report(nframes, &clk, out_left, out_right, cbs);
         }
-        ++i;
+        // the timer thread ticks once per subbeat while it runs (SyncTimer.cpp:117-163): modelled as one tick between two cycles
+        if (!G.seq.threadPaused) G.seq.hi_res_timer_callback();
     }
-    return ZLHIP_OK;
+    fire(cbs);
+    return rc;
 }
 
 // ---- JackPassthrough bridge (libzl.cpp:476-575) ------------------------------------------------------------

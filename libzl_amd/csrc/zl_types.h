@@ -42,6 +42,14 @@ struct ZlClip {
     double  slice_pos[ZL_MAX_SLICES];
 };
 
+// A parameter edit of one clip (zlhip_clip_set): the whole record, applied to the HBM clip table by the device at the
+// start of the next render call / real-time cycle (K0, or every workgroup of the resident kernel) -- the boundary at which
+// the reference's voices read the parameters (SamplerSynthVoice.cpp:189-196), and no HIP call on the host.
+struct ZlClipEdit {
+    int32_t clip, pad;
+    ZlClip  c;
+};
+
 // SamplerSynthVoicePrivate + juce::ADSR state (SamplerSynthVoice.cpp:20-39), device resident.
 struct ZlVoiceState {
     double   P;                   // sourceSamplePosition
@@ -205,6 +213,10 @@ struct ZlRtShared {
     unsigned long long ctl_base;  // base of this cycle's control-slot pool (zl_plan.h zl_ctl_alloc)
     ZlClock  clock;
     unsigned long long stamps[8]; // s_memrealtime (100 MHz) at the kernel's stages of the last block (diagnostic)
+    const ZlClipEdit  *clip_edits;// the cycle's clip-parameter edits (mapped host memory), applied before the cycle is planned
+    int32_t  n_clip_edits;
+    uint32_t yield;               // another thread of the process is about to make a device-synchronising HIP call (hipFree, ...):
+                                  // leave after the cycle in flight (zl_engine.cpp, ZlQuiesce)
 };
 
 // Device side of the resident kernel: workgroup 0 watches the mailbox and republishes every block in HBM for the other
@@ -214,7 +226,7 @@ struct ZlRtShared {
 #define ZL_RT_MAX_BUSES 256
 struct ZlRtDev {
     unsigned long long pub_seq;                  // the block being rendered (~0ull: leave)
-    unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words)
+    unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words), n_clip_edits, clip_edits
     unsigned int arrive, pad;
     unsigned int bus_arrive[ZL_RT_MAX_BUSES];    // wide buses (one workgroup per voice): the voices of a bus that have written their partial mix
 };
@@ -242,6 +254,8 @@ struct ZlBatch {
     ZlVoiceState       *voices;   // [V]
     const ZlVoiceOp    *ops;
     const ZlOpRange    *op_ranges;
+    const ZlClipEdit   *clip_edits; // [n_clip_edits] clip-parameter edits of the call (mapped host memory), applied by K0
+    int32_t             n_clip_edits, pad_edits;
     ZlVoiceConst       *vconst;   // [V]
     ZlRunList          *runs;     // [V]
     ZlTSeg             *tsegs;    // [V][ZL_MAXTSEG] segment stream of the window

@@ -47,6 +47,17 @@ SIGNATURES = {
     "ClipAudioSource_adsrRelease": (C.c_float, [_P]),
     "ClipAudioSource_setADSRRelease": (None, [_P, C.c_float]),
     "SyncTimer_getMultiplier": (C.c_int, []),
+    "SyncTimer_startTimer": (None, [C.c_int]),
+    "SyncTimer_setBpm": (None, [C.c_uint]),
+    "SyncTimer_stopTimer": (None, []),
+    "SyncTimer_queueClipToStart": (None, [_P]),
+    "SyncTimer_queueClipToStartOnChannel": (None, [_P, C.c_int]),
+    "SyncTimer_queueClipToStop": (None, [_P]),
+    "SyncTimer_queueClipToStopOnChannel": (None, [_P, C.c_int]),
+    "libzl_hotpath_cycle": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
+    "libzl_hotpath_schedule_clip_command": (None, [C.POINTER(_abi.ClipCommand), C.c_uint64]),
+    "libzl_hotpath_timer_tick": (None, []),
+    "libzl_hotpath_transport": (C.c_int, [C.POINTER(Clock)]),
     "initJuce": (None, []),
     "shutdownJuce": (None, []),
     "stopClips": (None, [C.c_int, C.POINTER(_P)]),

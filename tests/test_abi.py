@@ -68,7 +68,7 @@ def test_struct_sizes_match_the_c_layout(lib):
 
 def test_defaults_and_plain_helpers_work_without_a_gpu(lib):
     _abi.bind(lib)
-    assert lib.zlhip_abi_version() == 1
+    assert lib.zlhip_abi_version() == 2
     cfg = _abi.Config()
     lib.zlhip_config_default(C.byref(cfg))
     assert (cfg.num_buses, cfg.voices_per_bus) == (12, 8)      # SamplerSynth.cpp:23,258

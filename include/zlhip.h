@@ -303,6 +303,9 @@ int zlhip_last_timings(zlhip_engine *e, zlhip_timings *out);
  * and read the kernel times once at the end.  Waits for outstanding calls. */
 int zlhip_profile_totals(zlhip_engine *e, zlhip_timings *totals, int32_t *calls, int reset);
 float *zlhip_bus_device_ptr(zlhip_engine *e);                   /* internal [B][2][Kmax*Nmax] buffer */
+/* the resident real-time kernel behind zlhip_render: how many times it was launched, how many cycles it rendered (a parameter edit,
+ * a command or a quiet spell shorter than the idle timeout do not relaunch it; a batch, an upload or a block-size change do) */
+int zlhip_rt_stats(zlhip_engine *e, uint64_t *kernel_starts, uint64_t *cycles_rendered);
 /* HBM the engine allocated at creation: everything (source arena, voice / plan records, control pool, bus, levels) and the
  * arena's share of it */
 int zlhip_memory_bytes(zlhip_engine *e, uint64_t *total_device_bytes, uint64_t *arena_bytes);

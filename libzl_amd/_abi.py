@@ -142,6 +142,7 @@ SIGNATURES = {
     "zlhip_profile_totals": (C.c_int, [_E, C.POINTER(Timings), C.POINTER(C.c_int32), C.c_int]),
     "zlhip_bus_device_ptr": (C.c_void_p, [_E]),
     "zlhip_device_name": (C.c_int, [_E, C.c_char_p, C.c_size_t]),
+    "zlhip_rt_stats": (C.c_int, [_E, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 
 # ZLHIP_LIBRARY selects another build of the same library (A/B measurements of kernel variants); never a fallback

@@ -147,6 +147,16 @@ def build_cpu_harness(force: bool = False) -> str:
         if res.returncode != 0:
             sys.stderr.write(res.stdout + res.stderr)
             raise RuntimeError("building the CPU test harness failed")
+    # the product's ClipCommand scheduler (zl_sched.h), host build
+    t2 = os.path.join(hdir, "_build", "libzl_sched_host.so")
+    src2 = os.path.join(hdir, "sched_host.cpp")
+    if force or _stale(t2, [src2, os.path.join(CSRC, "zl_sched.h"), os.path.join(ROOT, "include", "zlhip.h")]):
+        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall",
+               "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", t2, src2]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError("building the CPU scheduler harness failed")
     return target
 
 

@@ -147,6 +147,7 @@ struct zlhip_engine {
         hipStream_t stream = nullptr;
         int nframes = 0;
         unsigned long long seq = 0;
+        unsigned long long starts = 0, cycles = 0;        // launches of the resident kernel, cycles it rendered (zlhip_rt_stats)
         unsigned long long idleTicks = 20000000ull;       // 200 ms of the 100 MHz counter without a block: the kernel leaves
         bool stampsOn = false; double stampSum[6] = {0, 0, 0, 0, 0, 0}; unsigned long long stampN = 0;   // ZL_RT_STAMPS=1: stage times (us)
     } rt;
@@ -1245,7 +1246,7 @@ static int rt_start(zlhip_engine *e, int nframes)
     __atomic_store_n(&e->rt.h->state, 0u, __ATOMIC_RELEASE);
     __atomic_store_n(&e->rt.h->yield, 0u, __ATOMIC_RELEASE);
     ZL_KERNEL(e, zl_launch_rt_loop(A, e->rt.d, e->rt.dev, e->rt.seq, e->rt.idleTicks, e->dGain, c.hReportsDev, c.hGainDev, e->rt.devRanges, std::max(e->rt.vw, 1), std::min(256, nframes), e->rt.stream));
-    e->rt.running = true; e->rt.nframes = nframes;
+    e->rt.running = true; e->rt.nframes = nframes; e->rt.starts += 1;
     if (std::find(g_rt.engines.begin(), g_rt.engines.end(), e) == g_rt.engines.end()) g_rt.engines.push_back(e);
     return ZLHIP_OK;
 }
@@ -1324,6 +1325,7 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
     e->latest = &c;
     e->lastK = 1; e->lastN = nframes; e->lastBus = e->hBusDev; e->lastWindows = 1;
     e->outstanding = false; e->reportsFresh = true;
+    e->rt.cycles += 1;
     return ZLHIP_OK;
 }
 
@@ -1575,6 +1577,14 @@ int zlhip_profile_totals(zlhip_engine *e, zlhip_timings *totals, int32_t *calls,
 }
 
 float *zlhip_bus_device_ptr(zlhip_engine *e) { return e ? e->dBus : nullptr; }
+
+int zlhip_rt_stats(zlhip_engine *e, uint64_t *kernel_starts, uint64_t *cycles_rendered)
+{
+    if (!e) return ZLHIP_ERR_INVALID;
+    if (kernel_starts) *kernel_starts = e->rt.starts;
+    if (cycles_rendered) *cycles_rendered = e->rt.cycles;
+    return ZLHIP_OK;
+}
 
 int zlhip_memory_bytes(zlhip_engine *e, uint64_t *total_device_bytes, uint64_t *arena_bytes)
 {

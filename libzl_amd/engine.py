@@ -18,7 +18,7 @@ from ._abi import (Clock, ClipCommand, ClipParams, Config, Levels, PassthroughPa
                    MODE_FAITHFUL, MODE_FIX_DELAY, MODE_FIX_GAIN, MODE_HERMITE, ZlHipError)
 
 __all__ = ["SamplerSynth", "Clock", "ClipCommand", "ClipParams", "Levels", "PassthroughParams", "VoiceReport",
-           "MODE_FAITHFUL", "MODE_FIX_GAIN", "MODE_FIX_DELAY", "MODE_HERMITE", "ZlHipError", "clip_command", "synthetic_clocks"]
+           "MODE_FAITHFUL", "MODE_FIX_GAIN", "MODE_FIX_DELAY", "MODE_HERMITE", "ZlHipError", "clip_command", "synthetic_clocks", "running_playhead"]
 
 
 def clip_command(lib=None, **fields) -> ClipCommand:
@@ -35,10 +35,32 @@ def clip_command(lib=None, **fields) -> ClipCommand:
     return c
 
 
-def synthetic_clocks(nblocks: int, nframes: int, sample_rate: float, start_block: int = 0, bpm: int = 120) -> "C.Array[Clock]":
+_running_playheads: dict = {}
+
+
+def running_playhead(block: int, period: int, bpm: int):
+    """(jackPlayhead, jackPlayheadUsecs) as a SyncTimer that was started at time 0 leaves them after its process call for the
+    JACK cycle [block * period, (block + 1) * period): one step per subbeat while its time lies before the cycle's end, the step
+    time accumulated as `quint64 += double` (SyncTimer.cpp:484,512,660-667,990-1004)."""
+    key = (period, bpm)
+    rows = _running_playheads.setdefault(key, [])
+    sub = float((60000000000 // (bpm * 96))) / 1000.0
+    # jackNextPlaybackPosition = current_usecs of the first cycle = 0; the step clock runs in parallel from 0 as well
+    n, pos = rows[-1] if rows else (0, 0)
+    while len(rows) <= block:
+        nxt = (len(rows) + 1) * period
+        while pos < nxt:
+            n += 1
+            pos = int(float(pos) + sub)
+        rows.append((n, pos))
+    return rows[block]
+
+
+def synthetic_clocks(nblocks: int, nframes: int, sample_rate: float, start_block: int = 0, bpm: int = 120,
+                     moving_playhead: bool = False) -> "C.Array[Clock]":
     """Monotone JACK-like cycle times: current_usecs = k * round(1e6 * nframes / fs).
-    The SyncTimer playhead is held at tick 0 / usec 0 with the subbeat length of `bpm`
-    (SyncTimer.cpp:180-183,959)."""
+    The SyncTimer playhead is held at tick 0 / usec 0 with the subbeat length of `bpm` (SyncTimer.cpp:180-183,959) -- a
+    stopped timer before its first cycle -- or, with moving_playhead, advances as a running timer's does (running_playhead)."""
     period = int(round(1e6 * nframes / sample_rate))
     subbeat = ((1 * 60000000000) // (bpm * 96)) // 1000
     arr = (Clock * nblocks)()
@@ -46,8 +68,11 @@ def synthetic_clocks(nblocks: int, nframes: int, sample_rate: float, start_block
         kk = start_block + k
         arr[k].current_usecs = kk * period
         arr[k].next_usecs = (kk + 1) * period
-        arr[k].jack_playhead = 0
-        arr[k].jack_playhead_usecs = 0
+        if moving_playhead:
+            arr[k].jack_playhead, arr[k].jack_playhead_usecs = running_playhead(kk, period, bpm)
+        else:
+            arr[k].jack_playhead = 0
+            arr[k].jack_playhead_usecs = 0
         arr[k].jack_subbeat_length_usecs = subbeat
     return arr
 
@@ -74,7 +99,7 @@ class SamplerSynth:
     def __init__(self, num_buses: int = 12, voices_per_bus: int = 8, *, max_frames: int = 1024,
                  max_batch_blocks: int = 64, max_sounds: int = 1024, mode: int = MODE_FAITHFUL,
                  playback_sample_rate: float = 48000.0, sound_arena_bytes: int = 256 << 20,
-                 voices_per_task: int = 0, plan_window_blocks: int = 0, device: int = 0):
+                 voices_per_task: int = 0, plan_window_blocks: int = 0, device: int = 0, rt_idle_timeout_us: int = 0):
         self._lib = _abi.load()
         cfg = Config()
         self._lib.zlhip_config_default(C.byref(cfg))
@@ -89,6 +114,7 @@ class SamplerSynth:
         cfg.sound_arena_bytes = sound_arena_bytes
         cfg.voices_per_task = voices_per_task
         cfg.plan_window_blocks = plan_window_blocks
+        cfg.rt_idle_timeout_us = rt_idle_timeout_us
         self.cfg = cfg
         self._e = C.c_void_p()
         rc = self._lib.zlhip_engine_create(C.byref(cfg), C.byref(self._e))
@@ -297,6 +323,12 @@ class SamplerSynth:
         t, a = C.c_uint64(0), C.c_uint64(0)
         self._ck(self._lib.zlhip_memory_bytes(self._e, C.byref(t), C.byref(a)), "memory_bytes")
         return t.value, a.value
+
+    def rt_stats(self):
+        """(launches of the resident real-time kernel, cycles it rendered)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._lib.zlhip_rt_stats(self._e, C.byref(a), C.byref(b)), "rt_stats")
+        return a.value, b.value
 
     def bus_device_ptr(self) -> int:
         return self._lib.zlhip_bus_device_ptr(self._e)

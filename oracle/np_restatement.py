@@ -204,6 +204,12 @@ class Command:
     change_looping: bool = False
     change_volume: bool = False
     volume: np.float32 = f32(0.0)
+    change_pitch: bool = False
+    pitch_change: np.float32 = f32(0.0)
+    change_speed: bool = False
+    speed_ratio: np.float32 = f32(0.0)
+    change_gain_db: bool = False
+    gain_db: np.float32 = f32(0.0)
 
     def equivalent(self, o):                                      # ClipCommand.h:33-39
         return self.clip == o.clip and (
@@ -414,6 +420,181 @@ class Synth:
                 if v.is_playing:
                     reports[(b, i)] = v.process(L[b], R[b], nframes, clk, self.mode)
         return L, R, reports
+
+
+# ---------------------------------------------------------------- SyncTimer: ClipCommands on the step ring
+# Written from /root/reference/lib/SyncTimer.cpp, independently of oracle/zl_oracle.c's zlo_sync_timer_*: the ring is a sparse
+# dict here (a step that was never touched is "played" and empty, SyncTimer.cpp:78), integers are Python ints, the two
+# `quint64 += double` accumulations (:665,671) go through float().
+STEP_RING_COUNT = 32768           # SyncTimer.cpp:253
+
+
+def schedule_into_step(step_commands: list, command: Command) -> bool:
+    """SyncTimer::scheduleClipCommand once the step is known (:1014-1047).  True when the command was appended."""
+    found = False
+    for existing in step_commands:
+        if existing.equivalent(command):
+            if command.change_looping:
+                existing.looping = command.looping; existing.change_looping = True
+            if command.change_pitch:
+                existing.pitch_change = command.pitch_change; existing.change_pitch = True
+            if command.change_speed:
+                existing.speed_ratio = command.speed_ratio; existing.change_speed = True
+            if command.change_gain_db:
+                existing.gain_db = command.gain_db; existing.change_gain_db = True
+            if command.change_volume:
+                existing.volume = command.volume; existing.change_volume = True
+            if command.start:
+                existing.start = True
+            found = True
+    if not found:
+        step_commands.append(Command(**command.__dict__))
+    return not found
+
+
+class _Step:
+    __slots__ = ("clips", "bpms", "played")
+
+    def __init__(self):
+        self.clips, self.bpms, self.played = [], [], True
+
+
+class SyncTimerModel:
+    def __init__(self):
+        self.ring = {}                      # index -> _Step
+        self.read_head = 0
+        self.step_next_usecs = 0            # stepNextPlaybackPosition
+        self.bpm = 120                      # SyncTimerThread::bpm
+        self.paused = True                  # SyncTimerThread::paused == SyncTimerPrivate::isPaused (:750-752)
+        self.playhead = 0                   # jackPlayhead
+        self.playhead_bpm = 120.0           # jackPlayheadBpm (double)
+        self.jack_next_usecs = 0            # jackNextPlaybackPosition
+        self.subbeat_usecs = self.subbeat_ns(self.bpm, 1) // 1000          # :749
+        self.latency_ms = 0
+        self.cumulative_beat = 0
+        self.beat = 0
+        self.read_head_on_start = 0
+        self._update_ahead()
+
+    @staticmethod
+    def subbeat_ns(bpm: int, count: int) -> int:                          # :180-183
+        return (count * 60000000000) // (bpm * BEAT_SUBDIVISIONS)
+
+    def _update_ahead(self):                                              # :704-707, :184-187
+        ns = int(f32(f32(self.latency_ms) * f32(1000000)))
+        self.ahead = int(f32(f32(ns // (60000000000 // (self.bpm * BEAT_SUBDIVISIONS))) + f32(1)))
+
+    def set_latency(self, buffer_size: int, sample_rate: float):          # :730-741
+        new = int((1000 * float(buffer_size)) / float(sample_rate))
+        if new != self.latency_ms:
+            self.latency_ms = new
+            self._update_ahead()
+
+    def _step(self, index: int) -> _Step:
+        return self.ring.setdefault(index % STEP_RING_COUNT, _Step())
+
+    def delayed_step(self, delay: int) -> _Step:                          # :364-378
+        if self.paused:
+            idx = self.read_head + delay + 1
+        else:
+            idx = self.read_head_on_start + max(self.cumulative_beat + delay, self.playhead + 1)
+        st = self._step(idx)
+        if st.played:                                                     # ensureFresh, :50-62
+            st.played = False
+            st.clips, st.bpms = [], []
+        return st
+
+    def schedule(self, command: Command, delay: int = 0):                 # :1011-1048
+        schedule_into_step(self.delayed_step(delay).clips, command)
+
+    def set_bpm(self, bpm: int):                                          # :954-975
+        if self.bpm != bpm:
+            self.bpm = bpm
+            self.subbeat_usecs = self.subbeat_ns(bpm, 1) // 1000
+            self._update_ahead()
+            self.delayed_step(0).bpms.append(bpm)
+
+    def start(self, bpm: int):                                            # :870-879
+        self.set_bpm(bpm)
+        self.read_head_on_start = self.read_head
+        self.paused = False
+
+    def stop(self):                                                       # :881-925
+        self.paused = True
+        self.beat = 0; self.cumulative_beat = 0; self.playhead = 0
+        target = (self.read_head + 1) % STEP_RING_COUNT
+        for off in range(STEP_RING_COUNT):      # ring order from the read head (a step created on the way is visited in its turn)
+            idx = (self.read_head + off) % STEP_RING_COUNT
+            st = self.ring.get(idx)
+            if st is not None and not st.played:
+                if idx != target:             # (a command re-scheduled into its own step folds into itself)
+                    for c in list(st.clips):
+                        c2 = Command(**c.__dict__)
+                        c2.change_volume = True; c2.volume = f32(0.0)
+                        self.schedule(c2, 0)
+                st.played = True
+
+    def timer_callback(self):                                             # :391-418
+        while self.cumulative_beat < self.playhead + self.ahead * 2:
+            self.beat = (self.beat + 1) % (BEAT_SUBDIVISIONS * 4)
+            self.cumulative_beat += 1
+
+    def queue_start(self, clip: int, channel: int):                       # :815-832
+        c = Command(clip=clip, midi_channel=channel, midi_note=60, change_volume=True, volume=f32(1.0), looping=True, stop=True, start=True)
+        bar = BEAT_SUBDIVISIONS * 4
+        nzb = 0 if self.paused else bar - (self.cumulative_beat % bar)
+        self.schedule(c, nzb + bar if self.cumulative_beat + nzb < self.playhead else nzb)
+
+    def queue_stop(self, clip: int, channel: int):                        # :834-860
+        for st in self.ring.values():
+            if not st.played:
+                for i, c in enumerate(st.clips):
+                    if c.clip == clip:
+                        del st.clips[i]
+                        break
+        self.delayed_step(0).clips.append(Command(clip=clip, midi_channel=channel, midi_note=60, stop=True))
+
+    def process(self, nframes: int, current_usecs: int, next_usecs: int):  # :452-702 -> [(Command, tick)]
+        out = []
+        usecs_per_frame = (next_usecs - current_usecs) // nframes
+        this_bpm = self.playhead_bpm
+        this_len = float(self.subbeat_ns(int(self.playhead_bpm), 1)) / 1000.0                 # :484
+        if not self.paused and self.playhead == 0:
+            self.jack_next_usecs = current_usecs                                              # :490-497
+        if self.step_next_usecs == 0:
+            self.step_next_usecs = current_usecs                                              # :500-502
+        first_free = 0
+        while self.step_next_usecs < next_usecs and first_free < nframes:                     # :512
+            st = self._step(self.read_head)
+            self.read_head = (self.read_head + 1) % STEP_RING_COUNT
+            if self.step_next_usecs <= current_usecs:                                         # :517-523
+                first_free += 1
+            else:
+                rel = ((self.step_next_usecs - current_usecs) // usecs_per_frame) & 0xffffffff if usecs_per_frame else 0
+                first_free = min(max(rel, first_free), nframes - 1)
+            if not st.played:
+                for c in st.clips:
+                    out.append((Command(**c.__dict__), self.playhead))                        # :553-558
+                i = 0
+                while i < len(st.bpms):                                                       # SetBpmOperation, :606-612
+                    nb = min(max(int(st.bpms[i]), 50), 200)
+                    self.set_bpm(nb)
+                    this_bpm = float(nb)
+                    i += 1
+                st.played = True
+            if self.playhead_bpm != this_bpm:                                                 # :634-639
+                self.playhead_bpm = this_bpm
+                this_len = float(self.subbeat_ns(int(self.playhead_bpm), 1) // 1000)
+            if not self.paused:                                                               # :660-667
+                self.playhead += 1
+                self.jack_next_usecs = int(float(self.jack_next_usecs) + this_len)
+            self.step_next_usecs = int(float(self.step_next_usecs) + this_len)                # :671
+        return out
+
+    def clock(self, current_usecs: int, next_usecs: int) -> Clock:        # the getters, :990-1009
+        if self.paused:
+            return Clock(current_usecs, next_usecs, self.read_head, self.step_next_usecs, self.subbeat_usecs)
+        return Clock(current_usecs, next_usecs, self.playhead, self.jack_next_usecs, self.subbeat_usecs)
 
 
 # ---------------------------------------------------------------- AudioLevels (AudioLevels.cpp:330-412)

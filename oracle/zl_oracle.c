@@ -390,6 +390,260 @@ int zlo_clip_command_equivalent(const zlo_clip_command *a, const zlo_clip_comman
 
 /* =============================== SamplerSynthVoice =========================================== */
 
+
+/* ================================================================================================
+ * SyncTimer: the step ring that carries ClipCommands (SyncTimer.cpp; header comment in zl_oracle.h)
+ * ============================================================================================== */
+#define ZLO_BEAT_SUBDIV_U64 ((uint64_t)ZLO_BEAT_SUBDIVISIONS)
+
+static uint64_t st_subbeat_count_to_nanoseconds(uint64_t bpm, uint64_t subBeatCount)   /* :180-183 */
+{
+    return (subBeatCount * 60000000000ULL) / (bpm * ZLO_BEAT_SUBDIV_U64);
+}
+static float st_nanoseconds_to_subbeat_count(uint64_t bpm, uint64_t nanoseconds)        /* :184-187 */
+{
+    return (float)(nanoseconds / (60000000000ULL / (bpm * ZLO_BEAT_SUBDIV_U64)));
+}
+
+static void st_update_schedule_ahead(zlo_sync_timer *t)                                  /* :704-707 */
+{
+    /* nanosecondsToSubbeatCount(bpm, jackLatency * (float)1000000) + 1 : quint64 * float -> float -> quint64 argument */
+    const float ns = (float)t->jackLatency * (float)1000000;
+    t->scheduleAheadAmount = (uint64_t)(st_nanoseconds_to_subbeat_count(t->bpm, (uint64_t)ns) + 1);
+}
+
+static void st_step_ensure_fresh(zlo_step *s)                                            /* :50-62 */
+{
+    if (s->played) { s->played = 0; s->nClipCommands = 0; s->nBpmCommands = 0; }
+}
+
+static void st_step_reserve_clip(zlo_step *s, int32_t need)
+{
+    if (need > s->capClipCommands) {
+        int32_t cap = s->capClipCommands ? s->capClipCommands * 2 : 4;
+        while (cap < need) cap *= 2;
+        s->clipCommands = (zlo_clip_command *)realloc(s->clipCommands, (size_t)cap * sizeof(zlo_clip_command));
+        s->capClipCommands = cap;
+    }
+}
+static void st_step_push_bpm(zlo_step *s, int32_t bpm)
+{
+    if (s->nBpmCommands + 1 > s->capBpmCommands) {
+        const int32_t cap = s->capBpmCommands ? s->capBpmCommands * 2 : 4;
+        s->bpmCommands = (int32_t *)realloc(s->bpmCommands, (size_t)cap * sizeof(int32_t));
+        s->capBpmCommands = cap;
+    }
+    s->bpmCommands[s->nBpmCommands++] = bpm;
+}
+
+zlo_sync_timer *zlo_sync_timer_new(void)
+{
+    zlo_sync_timer *t = (zlo_sync_timer *)calloc(1, sizeof *t);
+    t->stepRing = (zlo_step *)calloc(ZLO_STEP_RING_COUNT, sizeof(zlo_step));
+    for (int i = 0; i < ZLO_STEP_RING_COUNT; ++i) t->stepRing[i].played = 1;            /* :78 */
+    t->bpm = 120; t->threadPaused = 1; t->isPaused = 1;                                   /* :236,250,440 */
+    t->jackPlayheadBpm = 120;                                                             /* :423 */
+    t->jackSubbeatLengthInMicroseconds = st_subbeat_count_to_nanoseconds(t->bpm, 1) / 1000;   /* ctor, :749 */
+    st_update_schedule_ahead(t);                                                          /* ctor, :771 */
+    return t;
+}
+
+void zlo_sync_timer_free(zlo_sync_timer *t)
+{
+    if (!t) return;
+    for (int i = 0; i < ZLO_STEP_RING_COUNT; ++i) { free(t->stepRing[i].clipCommands); free(t->stepRing[i].bpmCommands); }
+    free(t->stepRing);
+    free(t);
+}
+
+void zlo_sync_timer_set_latency(zlo_sync_timer *t, uint32_t bufferSize, double sampleRate)   /* :730-741 */
+{
+    const uint64_t newLatency = (uint64_t)((1000 * (double)bufferSize) / (double)sampleRate);
+    if (newLatency != t->jackLatency) { t->jackLatency = newLatency; st_update_schedule_ahead(t); }
+}
+
+static zlo_step *st_delayed_step(zlo_sync_timer *t, uint64_t delay)                      /* :364-378 */
+{
+    uint64_t step;
+    if (t->isPaused) {
+        step = (t->stepReadHead + delay + 1) % ZLO_STEP_RING_COUNT;
+    } else {
+        const uint64_t a = t->cumulativeBeat + delay, b = t->jackPlayhead + 1;
+        step = (t->stepReadHeadOnStart + (a > b ? a : b)) % ZLO_STEP_RING_COUNT;
+    }
+    zlo_step *s = &t->stepRing[step];
+    st_step_ensure_fresh(s);
+    return s;
+}
+
+int zlo_step_schedule(zlo_clip_command *list, int32_t *n, const zlo_clip_command *command)   /* :1014-1047 */
+{
+    int foundExisting = 0;
+    for (int32_t i = 0; i < *n; ++i) {
+        zlo_clip_command *existingCommand = &list[i];
+        if (zlo_clip_command_equivalent(existingCommand, command)) {
+            if (command->changeLooping) { existingCommand->looping = command->looping; existingCommand->changeLooping = 1; }
+            if (command->changePitch)   { existingCommand->pitchChange = command->pitchChange; existingCommand->changePitch = 1; }
+            if (command->changeSpeed)   { existingCommand->speedRatio = command->speedRatio; existingCommand->changeSpeed = 1; }
+            if (command->changeGainDb)  { existingCommand->gainDb = command->gainDb; existingCommand->changeGainDb = 1; }
+            if (command->changeVolume)  { existingCommand->volume = command->volume; existingCommand->changeVolume = 1; }
+            if (command->startPlayback) { existingCommand->startPlayback = 1; }
+            foundExisting = 1;
+        }
+    }
+    if (foundExisting) return 0;                 /* deleteClipCommand(command) */
+    list[(*n)++] = *command;                     /* stepData->clipCommands << command */
+    return 1;
+}
+
+void zlo_schedule_clip_command(zlo_sync_timer *t, const zlo_clip_command *command, uint64_t delay)   /* :1011-1048 */
+{
+    zlo_step *s = st_delayed_step(t, delay);
+    st_step_reserve_clip(s, s->nClipCommands + 1);
+    zlo_step_schedule(s->clipCommands, &s->nClipCommands, command);
+}
+
+void zlo_sync_timer_set_bpm(zlo_sync_timer *t, uint64_t bpm)                             /* :954-975 */
+{
+    if (t->bpm != bpm) {
+        t->bpm = bpm;                                                                     /* timerThread->setBPM */
+        t->jackSubbeatLengthInMicroseconds = st_subbeat_count_to_nanoseconds(t->bpm, 1) / 1000;
+        st_update_schedule_ahead(t);
+        st_step_push_bpm(st_delayed_step(t, 0), (int32_t)bpm);                            /* scheduleTimerCommand(0, SetBpmOperation) */
+    }
+}
+
+void zlo_sync_timer_start(zlo_sync_timer *t, int bpm)                                    /* :870-879 */
+{
+    zlo_sync_timer_set_bpm(t, (uint64_t)bpm);
+    t->stepReadHeadOnStart = t->stepReadHead;
+    t->threadPaused = 0; t->isPaused = 0;                                                 /* resume() -> pausedChanged (:750-752) */
+}
+
+void zlo_sync_timer_stop(zlo_sync_timer *t)                                              /* :881-925 */
+{
+    t->threadPaused = 1; t->isPaused = 1;                                                 /* pause() */
+    t->beat = 0; t->cumulativeBeat = 0; t->jackPlayhead = 0;                              /* :888-890 */
+    for (uint64_t step = 0; step < ZLO_STEP_RING_COUNT; ++step) {                         /* :893-916 */
+        const uint64_t index = (step + t->stepReadHead) % ZLO_STEP_RING_COUNT;
+        zlo_step *stepData = &t->stepRing[index];
+        if (!stepData->played) {
+            /* scheduleClipCommand(clipCommand, 0) addresses the step behind the read head.  When that is the step being
+             * walked, every command is equivalent to itself: it folds into the list it is in, nothing is appended; the
+             * step is then marked played and its commands never reach the sampler. */
+            if (index != (t->stepReadHead + 1) % ZLO_STEP_RING_COUNT) {
+                for (int32_t i = 0; i < stepData->nClipCommands; ++i) {
+                    zlo_clip_command c = stepData->clipCommands[i];
+                    c.changeVolume = 1; c.volume = 0;                                     /* :908-909 */
+                    zlo_schedule_clip_command(t, &c, 0);
+                }
+            }
+            stepData->played = 1;
+        }
+    }
+}
+
+void zlo_sync_timer_callback(zlo_sync_timer *t)                                          /* :391-418 */
+{
+    while (t->cumulativeBeat < (t->jackPlayhead + (t->scheduleAheadAmount * 2))) {
+        t->beat = (t->beat + 1) % (ZLO_BEAT_SUBDIVISIONS * 4);
+        ++t->cumulativeBeat;
+    }
+}
+
+void zlo_sync_timer_queue_clip_to_start_on_channel(zlo_sync_timer *t, int32_t clip, int midiChannel)   /* :815-832 */
+{
+    zlo_clip_command command;
+    zlo_clip_command_clear(&command);
+    command.clip = clip; command.midiChannel = midiChannel; command.midiNote = 60;
+    command.changeVolume = 1; command.volume = 1.0f; command.looping = 1;
+    command.stopPlayback = 1; command.startPlayback = 1;
+    const uint64_t bar = ZLO_BEAT_SUBDIV_U64 * 4;
+    const uint64_t nextZeroBeat = t->threadPaused ? 0 : bar - (t->cumulativeBeat % bar);
+    zlo_schedule_clip_command(t, &command, t->cumulativeBeat + nextZeroBeat < t->jackPlayhead ? nextZeroBeat + bar : nextZeroBeat);
+}
+
+void zlo_sync_timer_queue_clip_to_stop_on_channel(zlo_sync_timer *t, int32_t clip, int midiChannel)    /* :834-860 */
+{
+    for (uint64_t step = 0; step < ZLO_STEP_RING_COUNT; ++step) {                         /* :837-850: the first reference per unplayed step */
+        zlo_step *stepData = &t->stepRing[step];
+        if (!stepData->played) {
+            for (int32_t i = 0; i < stepData->nClipCommands; ++i) {
+                if (stepData->clipCommands[i].clip == clip) {
+                    memmove(&stepData->clipCommands[i], &stepData->clipCommands[i + 1], (size_t)(stepData->nClipCommands - i - 1) * sizeof(zlo_clip_command));
+                    stepData->nClipCommands -= 1;
+                    break;
+                }
+            }
+        }
+    }
+    zlo_clip_command command;
+    zlo_clip_command_clear(&command);
+    command.clip = clip; command.midiChannel = midiChannel; command.midiNote = 60; command.stopPlayback = 1;
+    zlo_step *s = st_delayed_step(t, 0);                                                  /* appended without the merge, :858-859 */
+    st_step_reserve_clip(s, s->nClipCommands + 1);
+    s->clipCommands[s->nClipCommands++] = command;
+}
+
+int32_t zlo_sync_timer_process(zlo_sync_timer *t, uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs,
+                               zlo_dispatch *out, int32_t max_out)                       /* :452-702 */
+{
+    (void)period_usecs;                                                                   /* (only the transport's bpm average uses it) */
+    int32_t nout = 0;
+    const uint64_t microsecondsPerFrame = (next_usecs - current_usecs) / nframes;         /* :482 */
+    double thisStepBpm = t->jackPlayheadBpm;
+    /* subbeatCountToNanoseconds takes const quint64 &bpm: the double playhead bpm is truncated on the way in (:484) */
+    double thisStepSubbeatLengthInMicroseconds = (double)st_subbeat_count_to_nanoseconds((uint64_t)t->jackPlayheadBpm, 1) / 1000.0;
+    if (!t->isPaused) {
+        if (t->jackPlayhead == 0) t->jackNextPlaybackPosition = current_usecs;            /* :490-497 */
+    }
+    if (t->stepNextPlaybackPosition == 0) t->stepNextPlaybackPosition = current_usecs;    /* :500-502 */
+    uint32_t firstAvailableFrame = 0, relativePosition = 0;
+    while (t->stepNextPlaybackPosition < next_usecs && firstAvailableFrame < nframes) {   /* :512 */
+        zlo_step *stepData = &t->stepRing[t->stepReadHead];
+        t->stepReadHead = (t->stepReadHead + 1) % ZLO_STEP_RING_COUNT;                    /* stepReadHead->next */
+        if (t->stepNextPlaybackPosition <= current_usecs) {                               /* :517-523 */
+            relativePosition = firstAvailableFrame;
+            ++firstAvailableFrame;
+        } else {
+            uint32_t p = microsecondsPerFrame ? (uint32_t)((t->stepNextPlaybackPosition - current_usecs) / microsecondsPerFrame) : 0;
+            if (p < firstAvailableFrame) p = firstAvailableFrame;
+            if (p > nframes - 1) p = nframes - 1;
+            relativePosition = p;
+            firstAvailableFrame = relativePosition;
+        }
+        (void)relativePosition;                /* where MIDI events of the step land; clip commands carry no frame offset */
+        if (!stepData->played) {
+            for (int32_t i = 0; i < stepData->nClipCommands; ++i) {                       /* :553-558 */
+                if (nout < max_out) { out[nout].cmd = stepData->clipCommands[i]; out[nout].tick = t->jackPlayhead; }
+                ++nout;
+            }
+            for (int32_t i = 0; i < stepData->nBpmCommands; ++i) {                        /* SetBpmOperation, :606-612 */
+                uint64_t newBpm = (uint64_t)stepData->bpmCommands[i];
+                if (newBpm < 50) newBpm = 50;
+                if (newBpm > 200) newBpm = 200;
+                zlo_sync_timer_set_bpm(t, newBpm);                                        /* q->setBpm(newBpm) */
+                thisStepBpm = (double)newBpm;
+            }
+            stepData->played = 1;
+        }
+        if (t->jackPlayheadBpm != thisStepBpm) {                                          /* :634-639 */
+            t->jackPlayheadBpm = thisStepBpm;
+            thisStepSubbeatLengthInMicroseconds = (double)(st_subbeat_count_to_nanoseconds((uint64_t)t->jackPlayheadBpm, 1) / 1000);
+        }
+        if (!t->isPaused) {                                                               /* :660-667 */
+            ++t->jackPlayhead;
+            t->jackNextPlaybackPosition = (uint64_t)((double)t->jackNextPlaybackPosition + thisStepSubbeatLengthInMicroseconds);   /* quint64 += double */
+        }
+        t->stepNextPlaybackPosition = (uint64_t)((double)t->stepNextPlaybackPosition + thisStepSubbeatLengthInMicroseconds);       /* :671 */
+    }
+    return nout;
+}
+
+uint64_t zlo_sync_timer_jack_playhead(const zlo_sync_timer *t) { return t->threadPaused ? t->stepReadHead : t->jackPlayhead; }                           /* :990-996 */
+uint64_t zlo_sync_timer_jack_playhead_usecs(const zlo_sync_timer *t) { return t->threadPaused ? t->stepNextPlaybackPosition : t->jackNextPlaybackPosition; }   /* :998-1004 */
+uint64_t zlo_sync_timer_jack_subbeat_length_usecs(const zlo_sync_timer *t) { return t->jackSubbeatLengthInMicroseconds; }                               /* :1006-1009 */
+
 static float velocity_to_gain(float velocity) { return velocity; }    /* SamplerSynthVoice.cpp:11-18 */
 
 void zlo_voice_init(zlo_voice *v)

@@ -152,6 +152,57 @@ typedef struct zlo_clip_command {
 void zlo_clip_command_clear(zlo_clip_command *c);                                   /* ClipCommand.h:74-91 + ctor defaults */
 int  zlo_clip_command_equivalent(const zlo_clip_command *a, const zlo_clip_command *b); /* :33-39 */
 
+/* ---- SyncTimer: the step ring that carries ClipCommands to SamplerSynth -------
+ * SyncTimer.cpp:43-79 (StepData), :364-378 (delayedStep), :391-418 (hiResTimerCallback), :452-702 (process),
+ * :815-860 (queueClipToStart/StopOnChannel), :870-925 (start / stop), :954-975 (setBpm), :990-1009 (getters),
+ * :1011-1048 (scheduleClipCommand).  MIDI buffers, the jack transport position, timer commands other than SetBpm and
+ * the timer thread itself (its tick is zlo_sync_timer_callback) are outside the path. */
+#define ZLO_STEP_RING_COUNT 32768        /* SyncTimer.cpp:253 */
+typedef struct zlo_step {                /* StepData, :43-79 */
+    zlo_clip_command *clipCommands; int32_t nClipCommands, capClipCommands;
+    int32_t *bpmCommands;           int32_t nBpmCommands, capBpmCommands;    /* TimerCommand::SetBpmOperation parameters */
+    int32_t played;                      /* starts true (:78) */
+} zlo_step;
+typedef struct zlo_dispatch { zlo_clip_command cmd; uint64_t tick; } zlo_dispatch;   /* samplerSynth->handleClipCommand(cmd, jackPlayhead), :553-558 */
+typedef struct zlo_sync_timer {
+    zlo_step *stepRing;                  /* [ZLO_STEP_RING_COUNT] */
+    uint64_t stepReadHead;               /* index of *stepReadHead */
+    uint64_t stepNextPlaybackPosition;
+    uint64_t bpm;                        /* SyncTimerThread::bpm, :250 */
+    int32_t  threadPaused;               /* SyncTimerThread::paused, :236 */
+    int32_t  isPaused;                   /* SyncTimerPrivate::isPaused, :440,750-752 */
+    uint64_t jackPlayhead;
+    double   jackPlayheadBpm;
+    uint64_t jackNextPlaybackPosition;
+    uint64_t jackSubbeatLengthInMicroseconds;
+    uint64_t jackLatency;
+    uint64_t scheduleAheadAmount;
+    uint64_t cumulativeBeat;
+    int32_t  beat;
+    uint64_t stepReadHeadOnStart;
+} zlo_sync_timer;
+
+zlo_sync_timer *zlo_sync_timer_new(void);
+void     zlo_sync_timer_free(zlo_sync_timer *t);
+/* the merge of scheduleClipCommand on one step's list (:1014-1047): returns 1 if `command` was appended, 0 if folded into
+ * an equivalent command of the step.  list must have room for one more entry. */
+int      zlo_step_schedule(zlo_clip_command *list, int32_t *n, const zlo_clip_command *command);
+void     zlo_schedule_clip_command(zlo_sync_timer *t, const zlo_clip_command *command, uint64_t delay);   /* :1011-1048 */
+void     zlo_sync_timer_set_latency(zlo_sync_timer *t, uint32_t bufferSize, double sampleRate);           /* :730-741,770-771 */
+void     zlo_sync_timer_set_bpm(zlo_sync_timer *t, uint64_t bpm);                                         /* :954-975 */
+void     zlo_sync_timer_start(zlo_sync_timer *t, int bpm);                                                /* :870-879 */
+void     zlo_sync_timer_stop(zlo_sync_timer *t);                                                          /* :881-925 */
+void     zlo_sync_timer_callback(zlo_sync_timer *t);                                                      /* hiResTimerCallback, :391-418 */
+void     zlo_sync_timer_queue_clip_to_start_on_channel(zlo_sync_timer *t, int32_t clip, int midiChannel); /* :815-832 */
+void     zlo_sync_timer_queue_clip_to_stop_on_channel(zlo_sync_timer *t, int32_t clip, int midiChannel);  /* :834-860 */
+/* process (:452-702): plays the steps due in [current_usecs, next_usecs); their ClipCommands go to out[0 .. return value)
+ * (at most max_out) with the playhead they are dispatched with */
+int32_t  zlo_sync_timer_process(zlo_sync_timer *t, uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs,
+                                zlo_dispatch *out, int32_t max_out);
+uint64_t zlo_sync_timer_jack_playhead(const zlo_sync_timer *t);            /* :990-996 */
+uint64_t zlo_sync_timer_jack_playhead_usecs(const zlo_sync_timer *t);      /* :998-1004 */
+uint64_t zlo_sync_timer_jack_subbeat_length_usecs(const zlo_sync_timer *t);/* :1006-1009 */
+
 /* ---- clock inputs: JACK cycle times + SyncTimer playhead getters -------------------------- */
 typedef struct zlo_clock {
     uint64_t current_usecs, next_usecs;          /* jack_get_cycle_times, SamplerSynth.cpp:128 */

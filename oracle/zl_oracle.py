@@ -75,6 +75,23 @@ class Clock(C.Structure):
                 ("jackPlayheadUsecs", C.c_uint64), ("jackSubbeatLengthInMicroseconds", C.c_uint64)]
 
 
+class Step(C.Structure):
+    _fields_ = [("clipCommands", C.POINTER(ClipCommand)), ("nClipCommands", C.c_int32), ("capClipCommands", C.c_int32),
+                ("bpmCommands", C.POINTER(C.c_int32)), ("nBpmCommands", C.c_int32), ("capBpmCommands", C.c_int32), ("played", C.c_int32)]
+
+
+class Dispatch(C.Structure):
+    _fields_ = [("cmd", ClipCommand), ("tick", C.c_uint64)]
+
+
+class SyncTimer(C.Structure):
+    _fields_ = [("stepRing", C.POINTER(Step)), ("stepReadHead", C.c_uint64), ("stepNextPlaybackPosition", C.c_uint64),
+                ("bpm", C.c_uint64), ("threadPaused", C.c_int32), ("isPaused", C.c_int32), ("jackPlayhead", C.c_uint64),
+                ("jackPlayheadBpm", C.c_double), ("jackNextPlaybackPosition", C.c_uint64),
+                ("jackSubbeatLengthInMicroseconds", C.c_uint64), ("jackLatency", C.c_uint64), ("scheduleAheadAmount", C.c_uint64),
+                ("cumulativeBeat", C.c_uint64), ("beat", C.c_int32), ("stepReadHeadOnStart", C.c_uint64)]
+
+
 class Voice(C.Structure):
     _fields_ = [
         ("hasCommand", C.c_int32), ("cmd", ClipCommand), ("clip", C.c_int32), ("clipPositionId", C.c_int64),
@@ -139,6 +156,21 @@ _SIGS = {
     "zlo_sync_progress": (C.c_int, [C.POINTER(ClipMeter), C.POINTER(Clip), C.c_int, C.c_int64, C.POINTER(C.c_float)]),
     "zlo_clip_command_clear": (None, [C.POINTER(ClipCommand)]),
     "zlo_clip_command_equivalent": (C.c_int, [C.POINTER(ClipCommand), C.POINTER(ClipCommand)]),
+    "zlo_sync_timer_new": (C.POINTER(SyncTimer), []),
+    "zlo_sync_timer_free": (None, [C.POINTER(SyncTimer)]),
+    "zlo_step_schedule": (C.c_int, [C.POINTER(ClipCommand), C.POINTER(C.c_int32), C.POINTER(ClipCommand)]),
+    "zlo_schedule_clip_command": (None, [C.POINTER(SyncTimer), C.POINTER(ClipCommand), C.c_uint64]),
+    "zlo_sync_timer_set_latency": (None, [C.POINTER(SyncTimer), C.c_uint32, C.c_double]),
+    "zlo_sync_timer_set_bpm": (None, [C.POINTER(SyncTimer), C.c_uint64]),
+    "zlo_sync_timer_start": (None, [C.POINTER(SyncTimer), C.c_int]),
+    "zlo_sync_timer_stop": (None, [C.POINTER(SyncTimer)]),
+    "zlo_sync_timer_callback": (None, [C.POINTER(SyncTimer)]),
+    "zlo_sync_timer_queue_clip_to_start_on_channel": (None, [C.POINTER(SyncTimer), C.c_int32, C.c_int]),
+    "zlo_sync_timer_queue_clip_to_stop_on_channel": (None, [C.POINTER(SyncTimer), C.c_int32, C.c_int]),
+    "zlo_sync_timer_process": (C.c_int32, [C.POINTER(SyncTimer), C.c_uint32, C.c_uint64, C.c_uint64, C.c_float, C.POINTER(Dispatch), C.c_int32]),
+    "zlo_sync_timer_jack_playhead": (C.c_uint64, [C.POINTER(SyncTimer)]),
+    "zlo_sync_timer_jack_playhead_usecs": (C.c_uint64, [C.POINTER(SyncTimer)]),
+    "zlo_sync_timer_jack_subbeat_length_usecs": (C.c_uint64, [C.POINTER(SyncTimer)]),
     "zlo_voice_init": (None, [C.POINTER(Voice)]),
     "zlo_voice_set_current_command": (C.c_int, [C.POINTER(Voice), C.POINTER(ClipCommand), C.POINTER(Clip), C.POINTER(Sound)]),
     "zlo_voice_start_note": (None, [C.POINTER(Voice), C.c_int, C.c_float, C.c_int, C.POINTER(Sound), C.POINTER(Clip), C.c_double, C.c_int64]),
@@ -323,3 +355,59 @@ def clip_command(**fields) -> ClipCommand:
             raise AttributeError(k)
         setattr(c, k, v)
     return c
+
+
+CMD_FIELDS = [f for f, _ in ClipCommand._fields_]
+
+
+def cmd_tuple(c: ClipCommand):
+    return tuple(getattr(c, f) for f in CMD_FIELDS)
+
+
+class OracleSyncTimer:
+    """SyncTimer's ClipCommand step ring (zlo_sync_timer_*), driven like libzl_hotpath_cycle drives the product's."""
+
+    def __init__(self, fast: bool = False):
+        self.lib = load(fast=fast)
+        self.t = self.lib.zlo_sync_timer_new()
+        self._out = (Dispatch * 4096)()
+
+    def close(self):
+        if self.t:
+            self.lib.zlo_sync_timer_free(self.t)
+            self.t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def schedule(self, cmd: ClipCommand, delay: int = 0):
+        self.lib.zlo_schedule_clip_command(self.t, C.byref(cmd), delay)
+
+    def set_latency(self, buffer_size, sample_rate): self.lib.zlo_sync_timer_set_latency(self.t, buffer_size, sample_rate)
+    def set_bpm(self, bpm): self.lib.zlo_sync_timer_set_bpm(self.t, bpm)
+    def start(self, bpm): self.lib.zlo_sync_timer_start(self.t, bpm)
+    def stop(self): self.lib.zlo_sync_timer_stop(self.t)
+    def timer_callback(self): self.lib.zlo_sync_timer_callback(self.t)
+    def queue_start(self, clip, channel): self.lib.zlo_sync_timer_queue_clip_to_start_on_channel(self.t, clip, channel)
+    def queue_stop(self, clip, channel): self.lib.zlo_sync_timer_queue_clip_to_stop_on_channel(self.t, clip, channel)
+
+    def process(self, nframes, current_usecs, next_usecs, period_usecs=None):
+        """-> [(ClipCommand copy, tick)] of the steps that fell due in this cycle"""
+        if period_usecs is None:
+            period_usecs = float(next_usecs - current_usecs)
+        n = self.lib.zlo_sync_timer_process(self.t, nframes, current_usecs, next_usecs, C.c_float(period_usecs), self._out, len(self._out))
+        assert n <= len(self._out)
+        res = []
+        for i in range(n):
+            c = ClipCommand()
+            C.memmove(C.byref(c), C.byref(self._out[i].cmd), C.sizeof(ClipCommand))
+            res.append((c, int(self._out[i].tick)))
+        return res
+
+    def clock(self, current_usecs, next_usecs) -> Clock:
+        """the clock a voice reads in this cycle: JACK cycle times + SyncTimer's getters (SyncTimer.cpp:990-1009)"""
+        return Clock(current_usecs, next_usecs, self.lib.zlo_sync_timer_jack_playhead(self.t),
+                     self.lib.zlo_sync_timer_jack_playhead_usecs(self.t), self.lib.zlo_sync_timer_jack_subbeat_length_usecs(self.t))

@@ -145,6 +145,42 @@ def beat_locked_long_regular():
     return sc
 
 
+def beat_locked_moving_playhead():
+    """Beat-locked loops against a MOVING SyncTimer playhead (a timer that has been running for 9000 cycles: playhead ~ 7700):
+    commands carry the tick they are dispatched with, a retrigger lands while the loop plays, one command carries a tick 150
+    ticks in the past -- nextLoopTick behind the playhead: the u64 wrap of SamplerSynthVoice.cpp:180-181,236-237 and restarts in
+    consecutive frames -- and one a tick in the future (a start that SamplerSynth's ring delayed)."""
+    sc = _base(11, nblocks=260, length=9000)
+    sc.bpm = 200; sc.moving_playhead = True; sc.block0 = 9000
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = float(1 + (i % 2))
+            clip.lengthInSeconds = float(np.float32(0.04 + 0.01 * i))
+        sc.clip_setup[i] = setup
+    t = sc.tick_at
+    sc.events[0] = [("cmd", play_cmd(0, midi_channel=-2, note=60, volume=0.8), t(0)), ("cmd", play_cmd(1, midi_channel=-1, note=64, volume=0.7), t(0))]
+    sc.events[9] = [("cmd", play_cmd(2, midi_channel=-2, note=57, volume=0.6), t(9) - 150)]
+    sc.events[31] = [("cmd", play_cmd(3, midi_channel=-1, note=67, volume=0.9), t(31) + 40)]
+    sc.events[140] = [("cmd", play_cmd(0, midi_channel=-2, note=60, volume=0.5), t(140))]            # restart over the playing loop
+    sc.events[200] = [("cmd", stop_cmd(1, midi_channel=-1, note=64), t(200))]
+    return sc
+
+
+def beat_locked_moving_playhead_long():
+    """The same against windows: 2600 blocks of 64 frames in one batch (several plan windows with plan_window_blocks small),
+    restarts found by bisection over blocks whose clocks carry a different playhead each."""
+    sc = _base(12, nframes=64, nblocks=2600, length=30000)
+    sc.bpm = 140; sc.moving_playhead = True; sc.block0 = 5000
+    _play_all(sc, [60, 64, 55, 67])
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = float(1 + i)
+            clip.lengthInSeconds = float(np.float32(0.3 + 0.05 * i))
+        sc.clip_setup[i] = setup
+    sc.events[0] = [("cmd", ev[1], sc.tick_at(0) + j) for j, ev in enumerate(sc.events[0])]
+    return sc
+
+
 def random_envelopes(seed):
     """A mixed random scene whose clips get random ADSR times (zero, tiny, short, longer than the scene) and sustain
     levels (0, 1, in between), with the scene's own commands (note-offs, restarts, volume changes) on top."""
@@ -248,7 +284,7 @@ def loop_edits_while_playing():
     return sc
 
 
-SCENES = {f.__name__: f for f in (unit_step_loops_many_passes, positions_beyond_2_to_24, loop_edits_while_playing, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
+SCENES = {f.__name__: f for f in (beat_locked_moving_playhead, beat_locked_moving_playhead_long, unit_step_loops_many_passes, positions_beyond_2_to_24, loop_edits_while_playing, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
                                   envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}
 for _seed in range(8):
     SCENES[f"random_envelopes_{_seed}"] = (lambda _seed=_seed: random_envelopes(9100 + _seed))

@@ -22,16 +22,16 @@ f32 = np.float32
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def clocks_for(k, nframes, fs, bpm=120, playhead_fn=None):
+def clocks_for(k, nframes, fs, bpm=120, playhead_fn=None, block0=0):
     period = int(round(1e6 * nframes / fs))
     sub = ((60000000000) // (bpm * 96)) // 1000
-    c = nr.Clock(k * period, (k + 1) * period, 0, 0, sub)
+    c = nr.Clock((block0 + k) * period, (block0 + k + 1) * period, 0, 0, sub)
     if playhead_fn:
         c.playhead, c.playhead_usecs = playhead_fn(k, period, sub)
     return c
 
 
-def run_scene(name, *, B, VPB, fs, mode, nframes, nblocks, sounds, clips, events, bpm=120, playhead=None):
+def run_scene(name, *, B, VPB, fs, mode, nframes, nblocks, sounds, clips, events, bpm=120, playhead=None, block0=0):
     """sounds: list of (L, R|None, sr); clips: list of dict of Clip field overrides; events: {block: [cmd dict + 'tick']}"""
     syn = nr.Synth(B, VPB, fs, mode)
     for (L, R, sr), cf in zip(sounds, clips):
@@ -60,7 +60,7 @@ def run_scene(name, *, B, VPB, fs, mode, nframes, nblocks, sounds, clips, events
             ev = dict(ev)
             tick = ev.pop("tick", 0)
             syn.handle(nr.Command(**{kk: (f32(vv) if kk == "volume" else vv) for kk, vv in ev.items()}), tick)
-        clk = clocks_for(k, nframes, fs, bpm, playhead)
+        clk = clocks_for(k, nframes, fs, bpm, playhead, block0)
         clock_rows.append([clk.current_usecs, clk.next_usecs, clk.playhead, clk.playhead_usecs, clk.subbeat_usecs])
         L, R, reports = syn.process(nframes, clk)
         busL[:, k * nframes:(k + 1) * nframes] = L
@@ -150,9 +150,120 @@ def config1_full_shape():
     print(f"c1_config1_shape: restarts {restarts}, {len(keep)} blocks kept -> {os.path.relpath(path, ROOT)} ({os.path.getsize(path)} bytes)")
 
 
+CMD_ORDER = ["clip", "midi_note", "midi_channel", "start", "stop", "change_slice", "slice", "change_looping", "looping", "change_pitch",
+             "pitch_change", "change_speed", "speed_ratio", "change_gain_db", "gain_db", "change_volume", "volume"]     # ClipCommand.h:13-32
+OP_KINDS = ["schedule", "start", "stop", "bpm", "qstart", "qstop", "tick"]
+
+
+def scheduler_golden():
+    """s1_scheduler.npz: a seeded session of SyncTimer calls (scheduleClipCommand with delays, start / stop / setBpm,
+    queueClipToStart/Stop, timer ticks) through the numpy twin of the step ring (np_restatement.SyncTimerModel): every command
+    dispatched per JACK cycle with all its fields and its tick, and the clock triple the voices read in that cycle."""
+    rng = np.random.default_rng(0x5C4ED)
+    N, fs, t0, ncycles = 256, 48000.0, 7_000_003, 700
+    per = int(round(1e6 * N / fs))
+    m = nr.SyncTimerModel()
+    m.set_latency(N, fs)
+
+    def rand_cmd():
+        k = int(rng.integers(0, 5))
+        c = nr.Command(clip=int(rng.integers(0, 4)), midi_channel=int(rng.integers(-2, 3)), midi_note=int(rng.choice([60, 60, 60, 64])))
+        if k == 0:
+            c.start = True; c.change_volume = True; c.volume = f32(1.0); c.looping = bool(rng.integers(0, 2)); c.stop = c.looping
+        elif k == 1:
+            c.stop = True
+        elif k == 2:
+            c.change_volume = True; c.volume = f32(rng.uniform(0, 1))
+        elif k == 3:
+            c.change_slice = True; c.slice = int(rng.integers(0, 4)); c.start = True; c.change_looping = True; c.looping = bool(rng.integers(0, 2))
+        else:
+            c.change_pitch = True; c.pitch_change = f32(rng.uniform(-2, 2)); c.change_gain_db = bool(rng.integers(0, 2)); c.gain_db = f32(-6.0)
+            c.change_speed = bool(rng.integers(0, 2)); c.speed_ratio = f32(0.75)
+        return c
+
+    def row(c):
+        return [float(getattr(c, f)) for f in CMD_ORDER]
+
+    ops, disp, disp_cycle, clocks, running = [], [], [], [], []
+    for k in range(ncycles):
+        for _ in range(int(rng.integers(1, 5)) if rng.random() < 0.35 else 0):
+            a = int(rng.integers(0, 14))
+            if a < 7:
+                c, d = rand_cmd(), int(rng.choice([0, 0, 0, 0, 1, 3, 24, 96, 400]))
+                m.schedule(c, d); ops.append([k, 0, 0, d] + row(c))
+            elif a == 7:
+                b = int(rng.choice([60, 90, 120, 174, 230, 45])); m.start(b); ops.append([k, 1, b, 0] + [0.0] * 17)
+            elif a == 8:
+                m.stop(); ops.append([k, 2, 0, 0] + [0.0] * 17)
+            elif a == 9:
+                b = int(rng.choice([50, 100, 120, 140, 250])); m.set_bpm(b); ops.append([k, 3, b, 0] + [0.0] * 17)
+            elif a in (10, 11):
+                cl, ch = int(rng.integers(0, 4)), int(rng.integers(-2, 3)); m.queue_start(cl, ch); ops.append([k, 4, cl, ch] + [0.0] * 17)
+            elif a == 12:
+                cl, ch = int(rng.integers(0, 4)), int(rng.integers(-2, 3)); m.queue_stop(cl, ch); ops.append([k, 5, cl, ch] + [0.0] * 17)
+            else:
+                m.timer_callback(); ops.append([k, 6, 0, 0] + [0.0] * 17)
+        cu, nx = t0 + k * per, t0 + (k + 1) * per
+        for c, tick in m.process(N, cu, nx):
+            disp.append(row(c) + [float(tick)]); disp_cycle.append(k)
+        ck = m.clock(cu, nx)
+        clocks.append([ck.playhead, ck.playhead_usecs, ck.subbeat_usecs])
+        running.append(0 if m.paused else 1)
+        if not m.paused:
+            m.timer_callback()               # the timer thread's tick between two cycles, as libzl_hotpath_cycle models it
+    meta = dict(name="s1_scheduler", N=N, fs=fs, t0=t0, ncycles=ncycles, cmd_order=CMD_ORDER, op_kinds=OP_KINDS)
+    path = os.path.join(HERE, "s1_scheduler.npz")
+    np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), ops=np.array(ops, dtype=np.float64),
+                        dispatch=np.array(disp, dtype=np.float64).reshape(-1, 18), dispatch_cycle=np.array(disp_cycle, dtype=np.int64),
+                        clocks=np.array(clocks, dtype=np.uint64), running=np.array(running, dtype=np.uint8))
+    print(f"s1_scheduler: {len(ops)} calls, {len(disp)} commands dispatched over {ncycles} cycles -> {os.path.relpath(path, ROOT)} ({os.path.getsize(path)} bytes)")
+
+
+def moving_playhead_goldens():
+    """g4b: beat-locked loops against a MOVING SyncTimer playhead (the other goldens freeze it at (0, 0)).  The playhead and
+    its time come from the numpy twin of SyncTimer itself: a timer started at time 0 with 200 bpm that has been running for
+    12 000 JACK cycles when the scene begins (playhead > 10 000).  Commands carry the tick SyncTimer dispatches them with (the
+    playhead before the cycle's first step); one carries a tick 200 ticks in the past, so that nextLoopTick lies BEHIND the
+    playhead when the voice first renders: the unsigned wrap of SamplerSynthVoice.cpp:180-181,236-237 and a restart in three
+    consecutive frames."""
+    rng = np.random.default_rng(0x64B)
+
+    def src(n, stereo=True):
+        L = rng.uniform(-1, 1, n).astype(np.float32)
+        return (L, rng.uniform(-1, 1, n).astype(np.float32) if stereo else None)
+
+    play = lambda clip, ch=-2, loop=True, note=60, vol=1.0, **kw: dict(clip=clip, midi_channel=ch, midi_note=note, start=True, stop=loop,
+                                                                      looping=loop, change_volume=True, volume=vol, **kw)
+    N, fs, bpm, block0, nblocks = 128, 48000.0, 200, 12_000, 260
+    per = int(round(1e6 * N / fs))
+    m = nr.SyncTimerModel()
+    m.set_latency(N, fs)
+    m.start(bpm)
+    rows = []
+    for k in range(block0 + nblocks):
+        m.process(N, k * per, (k + 1) * per)
+        ck = m.clock(k * per, (k + 1) * per)
+        rows.append((ck.playhead, ck.playhead_usecs))
+        m.timer_callback()
+    tick_of = lambda k: rows[block0 + k - 1][0]          # the playhead SyncTimer dispatches the cycle's first step with
+    a, b, c, d = src(2600), src(2200, stereo=False), src(3100), src(2000)
+    run_scene("g4b_beat_locked_moving_playhead", B=1, VPB=4, fs=fs, mode=0, nframes=N, nblocks=nblocks, bpm=bpm, block0=block0,
+              sounds=[(a[0], a[1], 48000.0), (b[0], None, 44100.0), (c[0], c[1], 48000.0), (d[0], d[1], 48000.0)],
+              clips=[dict(length_beats=1.0, length_sec=0.04, volume_abs=0.7, pan=0.2), dict(length_beats=1.0, length_sec=0.035, volume_abs=0.9, pan=-0.4),
+                     dict(length_beats=1.0, length_sec=0.05, volume_abs=0.8, pan=0.0), dict(length_beats=2.0, length_sec=0.03, volume_abs=0.6, pan=0.5)],
+              events={0: [dict(play(0, note=60, vol=0.9), tick=tick_of(0)), dict(play(3, note=64, vol=0.5), tick=tick_of(0))],
+                      7: [dict(play(1, note=62, vol=0.8), tick=tick_of(7))],
+                      20: [dict(play(2, note=57, vol=0.7), tick=tick_of(20) - 200)]},
+              playhead=lambda k, period, sub: rows[block0 + k])
+
+
 def main():
     if "--config1" in sys.argv:
         return config1_full_shape()
+    if "--scheduler" in sys.argv:
+        return scheduler_golden()
+    if "--moving-playhead" in sys.argv:
+        return moving_playhead_goldens()
     rng = np.random.default_rng(0x5A17)
 
     def src(n, stereo=True):

@@ -105,3 +105,27 @@ def check_config1(bus, trace, expect, N=256):
     assert hashlib.sha256(np.ascontiguousarray(bus).tobytes()).hexdigest() == expect["bus_sha256"], "whole-bus digest differs"
     if trace is not None:
         assert hashlib.sha256(np.ascontiguousarray(trace).tobytes()).hexdigest() == expect["trace_sha256"], "whole-trace digest differs"
+
+
+def scheduler_session_from_golden(g):
+    """tests/golden/s1_scheduler.npz -> (N, fs, t0, ops per cycle) in the form tests/test_scheduler.py runs a session from."""
+    from oracle import np_restatement as npr
+    meta = json.loads(bytes(g["meta"]).decode())
+    order, kinds = meta["cmd_order"], meta["op_kinds"]
+    ops = [[] for _ in range(meta["ncycles"])]
+    bools = {"start", "stop", "change_slice", "change_looping", "looping", "change_pitch", "change_speed", "change_gain_db", "change_volume"}
+    ints = {"clip", "midi_note", "midi_channel", "slice"}
+    for row in g["ops"]:
+        k, kind, a, b = int(row[0]), kinds[int(row[1])], int(row[2]), int(row[3])
+        if kind == "schedule":
+            f = {}
+            for name, v in zip(order, row[4:]):
+                f[name] = bool(v) if name in bools else int(v) if name in ints else np.float32(v)
+            ops[k].append(("schedule", npr.Command(**f), b))
+        elif kind in ("start", "bpm"):
+            ops[k].append((kind, a))
+        elif kind in ("qstart", "qstop"):
+            ops[k].append((kind, a, b))
+        else:
+            ops[k].append((kind,))
+    return meta["N"], meta["fs"], meta["t0"], ops

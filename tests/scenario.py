@@ -87,11 +87,21 @@ class Scene:
     events: Dict[int, list] = field(default_factory=dict)
     clocks: Optional[Callable[[int, int], "C.Array"]] = None     # (start_block, n) -> Clock array
     bpm: int = 120
+    moving_playhead: bool = False           # SyncTimer's playhead advances as a running timer's does (else frozen at tick 0 / usec 0)
+    block0: int = 0                         # JACK cycle number of the scene's first block (a timer that has been running for a while)
 
     def make_clocks(self, start, n):
         if self.clocks is not None:
             return self.clocks(start, n)
-        return synthetic_clocks(n, self.nframes, self.fs, start_block=start, bpm=self.bpm)
+        return synthetic_clocks(n, self.nframes, self.fs, start_block=self.block0 + start, bpm=self.bpm, moving_playhead=self.moving_playhead)
+
+    def tick_at(self, block):
+        """the playhead SyncTimer dispatches the first step of cycle `block` with (the playhead after the previous cycle)"""
+        if not self.moving_playhead:
+            return 0
+        from libzl_amd.engine import running_playhead
+        k = self.block0 + block
+        return running_playhead(k - 1, int(round(1e6 * self.nframes / self.fs)), self.bpm)[0] if k > 0 else 0
 
 
 def _segments(scene: Scene, batch: int):

@@ -219,3 +219,85 @@ def test_wide_resident_equals_launched_with_a_command_storm(built, rt_wide_env):
                 os.environ["ZL_RT_PERSISTENT"] = old
     assert np.array_equal(outs[0][0].view(np.int32), outs[1][0].view(np.int32)) and np.abs(outs[0][0]).max() > 1.0
     assert outs[0][1] == outs[1][1]
+
+
+def test_parameter_edits_and_commands_keep_the_kernel_resident(built, rt_env):
+    """zlhip_clip_set records the edit on the host and the resident kernel applies it at the next cycle boundary
+    (SamplerSynthVoice.cpp:189-196 reads the parameters per block): a mixed scene with clip edits and commands between cycles
+    is rendered by ONE launch of the kernel, bit-exact."""
+    sc = random_scene(331, num_buses=12, voices_per_bus=8, nclips=20, mode=0, nframes=128, nblocks=60)
+    assert any(ev[0] == "clip" for evs in sc.events.values() for ev in evs)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn = _play_blockwise(sc, edit_at=(5, 6, 7, 30))
+    assert np.array_equal(bus.view(np.int32), ref_bus.view(np.int32)), f"max diff {np.abs(bus - ref_bus).max()}"
+    starts, cycles = syn.rt_stats()
+    assert (starts, cycles) == (1, sc.nblocks)
+    syn.close()
+
+
+def test_an_idle_engine_sees_every_cycles_clock(built, rt_env):
+    """one beat-locked voice, no commands for hundreds of cycles, a clock (and SyncTimer playhead) that changes every
+    cycle: the resident kernel reads the mailbox behind a system-scope acquire, so a quiet cycle cannot render with the previous
+    cycle's cached clock.  Against the launched path and the oracle."""
+    from edge_scenes import _base
+    from scenario import play_cmd
+    sc = _base(55, nframes=64, nblocks=500, nsounds=1, length=20000)
+    sc.num_buses, sc.voices_per_bus = 12, 8
+    sc.bpm = 200; sc.moving_playhead = True; sc.block0 = 7000
+
+    def setup(lib, clip):
+        clip.lengthInBeats = 1.0
+        clip.lengthInSeconds = float(np.float32(0.2))
+    sc.clip_setup[0] = setup
+    sc.events[0] = [("cmd", play_cmd(0, midi_channel=3, note=60, volume=0.9), sc.tick_at(0))]
+    ref_bus, _, _ = run_oracle(sc)
+    bus, rep, syn = _play_blockwise(sc)
+    assert np.array_equal(bus.view(np.int32), ref_bus.view(np.int32))
+    assert syn.rt_stats() == (1, 500)
+    syn.close()
+    os.environ["ZL_RT_PERSISTENT"] = "0"
+    bus2, _, syn2 = _play_blockwise(sc)
+    assert np.array_equal(bus2.view(np.int32), ref_bus.view(np.int32)) and syn2.rt_stats() == (0, 0)
+    syn2.close()
+
+
+def test_two_engines_device_wide_waits_do_not_wait_for_a_resident_kernel(built, rt_env):
+    """engine A renders real-time cycles through its resident kernel while the same process creates, grows and destroys
+    engine B (hipFree / hipHostFree / hipDeviceSynchronize inside: device-wide waits).  Those calls ask A's kernel to leave for
+    their duration instead of waiting out its idle timeout (set to 2 s here), A renders the cycles in between with launches or a
+    fresh residency, and its stream stays bit-exact."""
+    import torch
+    from libzl_amd import SamplerSynth
+    sc = random_scene(340, num_buses=12, voices_per_bus=8, nclips=16, nframes=128, nblocks=40, events=False)
+    ref_bus, _, _ = run_oracle(sc)
+    from oracle import zl_oracle as zo
+    ref = zo.OracleSynth(1, 1, sc.fs, sc.mode, max_sounds=32)
+    A = SamplerSynth(num_buses=12, voices_per_bus=8, max_frames=128, max_batch_blocks=4, max_sounds=32, sound_arena_bytes=1 << 22, rt_idle_timeout_us=2_000_000)
+    for i, (L, R, sr) in enumerate(sc.sounds):
+        ref.register_clip(L, R, sr); A.register_clip(L, R, sr)
+        sc.clip_setup[i](ref.lib, ref.clips[i])
+        A.set_clip_params(i, snapshot_clip(ref.clips[i]))
+    for ev in sc.events[0]:
+        A.handle_clip_command(engine_cmd(**ev[1]), ev[2])
+    N = 128
+    out = np.zeros((12, 2, 40 * N), dtype=np.float32)
+    t_foreign = 0.0
+    for k in range(40):
+        L, R = A.process(N, sc.make_clocks(k, 1)[0])
+        out[:, 0, k * N:(k + 1) * N] = L; out[:, 1, k * N:(k + 1) * N] = R
+        if k in (5, 15, 25):
+            t0 = time.perf_counter()
+            Bsyn = SamplerSynth(num_buses=2, voices_per_bus=8, max_frames=128, max_batch_blocks=4, max_sounds=8, sound_arena_bytes=1 << 20)
+            src = torch.rand(4000, device="cuda")
+            cid = Bsyn.register_clip_device(src.data_ptr(), None, 4000, 48000.0)      # hipDeviceSynchronize inside
+            Bsyn.enable_trace(True)
+            Bsyn.render_batch(2, N, sc.make_clocks(0, 2))                              # the trace buffer is allocated, then grown (hipFree)
+            Bsyn.render_batch(4, N, sc.make_clocks(0, 4))
+            Bsyn.synchronize()
+            Bsyn.close()                                                               # hipFree / hipHostFree of everything
+            t_foreign += time.perf_counter() - t0
+    assert np.array_equal(out.view(np.int32), ref_bus.view(np.int32))
+    starts, cycles = A.rt_stats()
+    assert starts >= 2 and cycles >= 30, (starts, cycles)         # it was asked to leave and came back
+    assert t_foreign < 3 * 1.5, t_foreign                         # three rounds; each would wait >= 2 s (often several times) behind A's kernel
+    A.close()

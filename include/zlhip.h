@@ -278,9 +278,10 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
 
 /* ---- offline bounce (BASELINE configs[4]; the recorder side of the bus, AudioLevels.cpp:35-119) ----------------------------
  * Renders nblocks consecutive blocks exactly like consecutive zlhip_render_batch calls (voice state, levels and reports carry on;
- * afterwards zlhip_levels_tick / zlhip_block_peaks / zlhip_voice_reports see the last sub-batch) and delivers every bus to HOST
- * memory: the bounce is cut into sub-batches of sub_blocks blocks (0 = a sixth of the bounce, at least 256 blocks; at most max_batch_blocks) that
- * render into three device buffers in turn while the previous ones cross PCIe on a copy stream.  Synchronous.
+ * afterwards zlhip_levels_tick / zlhip_block_peaks / zlhip_voice_reports see the last chunk) and delivers every bus to HOST memory.
+ * The bounce is cut into chunks of sub_blocks blocks (0 = max_batch_blocks, the longest call the engine takes), each ONE render call
+ * whose plan windows pipeline as in a device-resident batch; every window is handed to the copy engine as soon as its render kernel
+ * has finished (16-bit: converted first), so PCIe runs next to the rendering of the following windows.  Synchronous.
  *   clocks    host [nblocks]
  *   host_out  ZLHIP_BOUNCE_F32_PLANAR:  float   [num_buses][2][nblocks*nframes]     (the layout of zlhip_render_batch)
  *             ZLHIP_BOUNCE_PCM16_STEREO: int16_t [num_buses][nblocks*nframes][2]     (the data chunk of one 16-bit stereo WAV per

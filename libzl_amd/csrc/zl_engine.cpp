@@ -152,14 +152,25 @@ struct zlhip_engine {
         bool stampsOn = false; double stampSum[6] = {0, 0, 0, 0, 0, 0}; unsigned long long stampN = 0;   // ZL_RT_STAMPS=1: stage times (us)
     } rt;
 
-    // offline bounce (zlhip_bounce): two device bus buffers rendered into in turn, their 16-bit versions, the copy stream
+    // offline bounce (zlhip_bounce): the device bus buffers of two chunks rendered into in turn, their 16-bit versions, the copy stream.
+    // A chunk is ONE zlhip_render_batch call; every plan window of it is delivered as soon as its render kernel has finished
+    // (the sink below, called from the window loop), while the following windows render.
     struct Bounce {
-        static constexpr int NBUF = 3;       // one renders, one is delivered, one is spare: the "delivered" wait of a render is always long over
-        float *bus[NBUF] = {nullptr, nullptr, nullptr}; int16_t *pcm[NBUF] = {nullptr, nullptr, nullptr};
+        static constexpr int NBUF = 2, NEV = 16;
+        float *bus[NBUF] = {nullptr, nullptr}; int16_t *pcm[NBUF] = {nullptr, nullptr};
         size_t busFloats = 0, pcmFrames = 0;
         hipStream_t copyStream = nullptr;
-        hipEvent_t rendered[NBUF] = {nullptr, nullptr, nullptr}, copied[NBUF] = {nullptr, nullptr, nullptr};
-        bool active = false;                 // inside zlhip_bounce: every sub-batch plans on the planning stream
+        hipEvent_t copied[NBUF] = {nullptr, nullptr};      // the last delivery out of a chunk buffer
+        hipEvent_t winEv[NEV] = {};                        // "window rendered (and converted)": waited for by the copy stream
+        unsigned winNext = 0;
+        bool active = false;                 // inside zlhip_bounce: every chunk plans on the planning stream
+        struct Sink {
+            bool on = false, pcm = false;
+            char *hostBase = nullptr;        // the chunk's first frame in the caller's buffer
+            void *hostDev = nullptr;         // direct delivery: the device view of hostBase (page-locked memory only), else nullptr
+            size_t totalFrames = 0;          // frames per row of the caller's buffer (the whole bounce)
+            int16_t *pcmDev = nullptr;       // the chunk's 16-bit staging buffer [B][chunk frames][2]
+        } sink;
     } bnc;
 
     bool failed = false;                 // the resident kernel stopped answering in the middle of a cycle: the voice table is undefined (zlhip_render)
@@ -345,9 +356,9 @@ void zlhip_engine_destroy(zlhip_engine *e)
     for (int i = 0; i < zlhip_engine::Bounce::NBUF; ++i) {
         if (e->bnc.bus[i]) (void)hipFree(e->bnc.bus[i]);
         if (e->bnc.pcm[i]) (void)hipFree(e->bnc.pcm[i]);
-        if (e->bnc.rendered[i]) (void)hipEventDestroy(e->bnc.rendered[i]);
         if (e->bnc.copied[i]) (void)hipEventDestroy(e->bnc.copied[i]);
     }
+    for (hipEvent_t ev : e->bnc.winEv) if (ev) (void)hipEventDestroy(ev);
     if (e->planStream) (void)hipStreamDestroy(e->planStream);
     if (e->asmStream) (void)hipStreamDestroy(e->asmStream);
     void *host[] = { e->hBus, e->hLevelState };
@@ -489,6 +500,9 @@ int zlhip_engine_create(const zlhip_config *cfg_in, zlhip_engine **out)
             c.editsCap = (size_t)std::min(cfg->max_sounds, 64);
             chk(hipHostMalloc((void **)&c.hEdits, c.editsCap * sizeof(ZlClipEdit)), "hEdits");
             if (rc == ZLHIP_OK) chk(hipHostGetDevicePointer((void **)&c.hEditsDev, c.hEdits, 0), "map hEdits");
+            // ... and for its voice operations: two per voice (a stop and a start of every voice in one cycle) before anything grows
+            if (rc == ZLHIP_OK) chk(grow_mapped(&c.hOps, &c.hOpsDev, &c.opsCap, V + 32), "hOps");
+            if (rc == ZLHIP_OK) chk(grow_mapped(&c.hRanges, &c.hRangesDev, &c.rangesCap, V + 32), "hRanges");
             if (rc == ZLHIP_OK) {
                 chk(hipHostGetDevicePointer((void **)&c.hReportsDev, c.hReports, 0), "map hReports");
                 chk(hipHostGetDevicePointer((void **)&c.hGainDev, c.hGain, 0), "map hGain");
@@ -616,6 +630,7 @@ static int publish_sound(zlhip_engine *e, int id)
     zlhip_clip_params p;
     zlhip_clip_params_default(&p, (float)(e->hc.sounds[id].length / e->hc.sounds[id].sample_rate));
     { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
+    e->hc.forget_clip_params(id);                                  // (the first edit of a slot carries the whole record)
     return zlhip_clip_set(e, id, &p);
 }
 
@@ -865,6 +880,28 @@ static ZlPassParams pass_params(const zlhip_passthrough_params &p)
     return ZlPassParams{ p.dry_amount, p.wet_fx1_amount, p.wet_fx2_amount, p.pan_amount, p.muted };
 }
 
+// Offline bounce, one plan window: blocks [k0, k0 + K) of the chunk being rendered into busDev ([B][2][Ktot * N]) are final on
+// stream s -- converted there to 16 bit if asked (a small kernel between two render kernels; on the copy stream it would get no
+// compute units while the next window's render kernel fills the chip) and handed to the copy engine as ONE strided copy.
+static int bounce_deliver_window(zlhip_engine *e, const float *busDev, int b0, int b1, int k0, int K, int Ktot, int nframes, hipStream_t s)
+{
+    zlhip_engine::Bounce &q = e->bnc;
+    const size_t rowFrames = (size_t)Ktot * (size_t)nframes, off = (size_t)k0 * (size_t)nframes, frames = (size_t)K * (size_t)nframes;
+    const size_t nb = (size_t)(b1 - b0), total = q.sink.totalFrames;
+    if (nb == 0) return ZLHIP_OK;
+    if (q.sink.pcm) ZL_KERNEL(e, zl_launch_deliver(busDev + (size_t)b0 * 2 * rowFrames, q.sink.pcmDev + (size_t)b0 * rowFrames * 2, 1, (int)nb,
+                                                   (long long)rowFrames, (long long)off, (long long)frames, (long long)rowFrames, s));
+    hipEvent_t ev = q.winEv[q.winNext++ % zlhip_engine::Bounce::NEV];
+    ZL_HIP(e, hipEventRecord(ev, s));
+    ZL_HIP(e, hipStreamWaitEvent(q.copyStream, ev, 0));
+    // rows of 4 bytes per frame in both formats: [B][total][2] 16-bit = one row per bus, [B][2][total] fp32 = one per bus channel
+    const size_t rows = q.sink.pcm ? nb : nb * 2, row0 = q.sink.pcm ? (size_t)b0 : (size_t)b0 * 2;
+    const char *src = q.sink.pcm ? (const char *)q.sink.pcmDev : (const char *)busDev;
+    ZL_HIP(e, hipMemcpy2DAsync(q.sink.hostBase + (row0 * total + off) * 4, total * 4, src + (row0 * rowFrames + off) * 4, rowFrames * 4, frames * 4, rows,
+                               hipMemcpyDeviceToHost, q.copyStream));
+    return ZLHIP_OK;
+}
+
 int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks, float *bus_out_dev, void *stream)
 {
     return zlhip_render_batch_fanout(e, nblocks, nframes, clocks, bus_out_dev, nullptr, nullptr, stream);
@@ -1028,12 +1065,17 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
                 ZL_HIP(e, hipStreamWaitEvent(s, q.planned, 0));
             }
         }
+        // K2 scans the block for AudioLevels itself when one workgroup holds the whole block of the final mix
+        const bool k3 = !(Aw.groups == 1 && nframes <= 256);
+        // offline bounce, direct delivery: K2 itself also stores the finished bus into the caller's page-locked host buffer
+        const bool direct = e->bnc.sink.on && e->bnc.sink.hostDev && Aw.groups == 1;
+        if (direct) { Aw.host_out = e->bnc.sink.hostDev; Aw.host_fmt = e->bnc.sink.pcm ? 1 : 0; Aw.host_total = (long long)e->bnc.sink.totalFrames; Aw.host_k0 = 0; }
         // profiling: the K2 dispatch carries its own start / stop events (hipExtLaunchKernel)
         if (e->profiling) ZL_KERNEL(e, zl_launch_render(Aw, s, c.evK2[2 * (size_t)w], c.evK2[2 * (size_t)w + 1]));
         else ZL_KERNEL(e, zl_launch_render(Aw, s));
-        // K2 scans the block for AudioLevels itself when one workgroup holds the whole block of the final mix
-        const bool k3 = !(Aw.groups == 1 && nframes <= 256);
         if (k3) ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
+        // ... or through the copy engine, window by window: the window's columns of the bus are final now
+        if (e->bnc.sink.on && !direct) { int d_ = bounce_deliver_window(e, A.bus, 0, Aw.B, Aw.k0, Aw.K, nblocks, nframes, s); if (d_ != ZLHIP_OK) return d_; }
         // (every event record is a packet the command processor handles between two K2 launches: when profiling, the
         // event that closes the K2 timing doubles as the set's "rendered" event)
         // (an engine with a single record set never plans on another stream: nobody waits for "rendered")
@@ -1078,37 +1120,39 @@ int zlhip_host_alloc(size_t bytes, void **out)
 
 void zlhip_host_free(void *p) { if (p) { ZlQuiesce quiet(nullptr); (void)hipHostFree(p); } }
 
-static int bounce_body(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_clock *clocks, void *host_out, bool pcm, int64_t sub)
+static int bounce_body(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_clock *clocks, void *host_out, bool pcm, int64_t chunk)
 {
     constexpr int NBUF = zlhip_engine::Bounce::NBUF;
     zlhip_engine::Bounce &q = e->bnc;
-    const int B = e->cfg.num_buses;
     const size_t total = (size_t)nblocks * (size_t)nframes;          // frames per bus channel in host_out
     static const bool stamps = std::getenv("ZL_BOUNCE_STAMPS") != nullptr;     // diagnostics: host time of every step (stderr)
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t00 = stamps ? now_us() : 0.0;
+    // Direct delivery: the render kernel itself stores the finished bus into the caller's buffer over PCIe, in the requested format
+    // (page-locked memory only: it needs a device view).  Measured on the per-GPU share of BASELINE configs[4] (profiles/round3_bounce.txt):
+    // 16 bit 4.6 ms = 98 % of the device-resident rate (27 GB/s of stores next to the rendering: half the link) against 5.7 ms through the
+    // copy engine; fp32 6.05 ms (the stores run at 40 GB/s) against 7.0 ms.  ZL_BOUNCE_DIRECT: 0 = always through the copy engine, window
+    // by window; 1 = only the 16-bit format directly; 2 (default) = both.
+    static const int directMode = [] { const char *v = std::getenv("ZL_BOUNCE_DIRECT"); return v ? std::atoi(v) : 2; }();
+    void *hostDev = nullptr;
+    if (directMode >= (pcm ? 1 : 2)) {
+        if (hipHostGetDevicePointer(&hostDev, host_out, 0) != hipSuccess) { hostDev = nullptr; (void)hipGetLastError(); }   // pageable memory: copies
+    }
     int j = 0;
-    for (int64_t k0 = 0; k0 < nblocks; k0 += sub, ++j) {
-        const int nb = (int)std::min<int64_t>(sub, nblocks - k0);
+    for (int64_t k0 = 0; k0 < nblocks; k0 += chunk, ++j) {
+        const int nb = (int)std::min<int64_t>(chunk, nblocks - k0);
         const int i = j % NBUF;
-        const size_t frames = (size_t)nb * (size_t)nframes;
-        // the buffer is free again when the sub-batch rendered into it three sub-batches ago has left it
+        // the buffer is free again when the chunk rendered into it two chunks ago has left it
         if (j >= NBUF) ZL_HIP(e, hipStreamWaitEvent(e->stream, q.copied[i], 0));
         const double t0 = stamps ? now_us() : 0.0;
-        int rc = zlhip_render_batch_fanout(e, nb, nframes, clocks + k0, q.bus[i], nullptr, nullptr, nullptr);
+        q.sink.on = true; q.sink.pcm = pcm; q.sink.pcmDev = q.pcm[i]; q.sink.totalFrames = total;
+        q.sink.hostBase = (char *)host_out + (size_t)k0 * (size_t)nframes * 4;      // 4 bytes per frame and row in both formats
+        q.sink.hostDev = hostDev ? (void *)((char *)hostDev + (size_t)k0 * (size_t)nframes * 4) : nullptr;
+        const int rc = zlhip_render_batch_fanout(e, nb, nframes, clocks + k0, q.bus[i], nullptr, nullptr, nullptr);
+        q.sink.on = false;
         if (rc != ZLHIP_OK) return rc;
-        const double t1 = stamps ? now_us() : 0.0;
-        const size_t off = (size_t)k0 * (size_t)nframes * 4;         // byte offset of block k0 in a row of host_out (4 bytes per frame and row in both formats)
-        // delivery by the copy engine (SDMA), not by a kernel storing to mapped host memory: measured, a kernel on the copy stream gets no
-        // compute units while the next sub-batch's render kernel fills the chip (5.5 ms against 4.1 ms for the bench shape)
-        if (pcm) ZL_KERNEL(e, zl_launch_deliver(q.bus[i], q.pcm[i], 1, B, (long long)frames, (long long)frames, e->stream));
-        ZL_HIP(e, hipEventRecord(q.rendered[i], e->stream));
-        ZL_HIP(e, hipStreamWaitEvent(q.copyStream, q.rendered[i], 0));
-        // rows of frames * 4 bytes: [B][total][2] 16-bit = one per bus, [B][2][total] fp32 = one per bus channel
-        ZL_HIP(e, hipMemcpy2DAsync((char *)host_out + off, total * 4, pcm ? (const void *)q.pcm[i] : (const void *)q.bus[i], frames * 4, frames * 4,
-                                   pcm ? (size_t)B : (size_t)B * 2, hipMemcpyDeviceToHost, q.copyStream));
         ZL_HIP(e, hipEventRecord(q.copied[i], q.copyStream));
-        if (stamps) std::fprintf(stderr, "zlhip_bounce sub-batch %d: at %.0f us, render_batch %.0f us, delivery commands %.0f us\n", j, t0 - t00, t1 - t0, now_us() - t1);
+        if (stamps) std::fprintf(stderr, "zlhip_bounce chunk %d: at %.0f us, render + delivery commands %.0f us (%d windows)\n", j, t0 - t00, now_us() - t0, e->lastWindows);
     }
     const double t2 = stamps ? now_us() : 0.0;
     ZL_HIP(e, hipStreamSynchronize(q.copyStream));
@@ -1124,41 +1168,46 @@ int zlhip_bounce(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_
     ZL_HIP(e, hipSetDevice(e->device));
     constexpr int NBUF = zlhip_engine::Bounce::NBUF;
     const int B = e->cfg.num_buses;
-    // sub-batches: long enough that a K2 launch is efficient and its planning hides behind the previous one, short enough that the
-    // first delivery starts early and the last one is short (a sixth of the bounce)
-    int64_t sub = sub_blocks > 0 ? sub_blocks : std::max<int64_t>(256, (nblocks + 5) / 6);
-    sub = std::min<int64_t>(std::min<int64_t>(sub, e->cfg.max_batch_blocks), nblocks);
+    // chunks = the render calls of the bounce: as long as the engine takes (max_batch_blocks), so that its plan windows pipeline
+    // as in a device-resident batch and a loop's sources are re-read from the Infinity Cache inside a window; the DELIVERY is per
+    // plan window (bounce_deliver_window), so the first bytes cross PCIe after the first window, not after the first chunk
+    int64_t chunk = sub_blocks > 0 ? sub_blocks : e->cfg.max_batch_blocks;
+    chunk = std::min<int64_t>(std::min<int64_t>(chunk, e->cfg.max_batch_blocks), nblocks);
     const bool pcm = format == ZLHIP_BOUNCE_PCM16_STEREO;
     zlhip_engine::Bounce &q = e->bnc;
     if (!q.copyStream) {
         ZL_HIP(e, hipStreamCreateWithFlags(&q.copyStream, hipStreamNonBlocking));
-        for (int i = 0; i < NBUF; ++i) {
-            ZL_HIP(e, hipEventCreateWithFlags(&q.rendered[i], hipEventDisableTiming));
-            ZL_HIP(e, hipEventCreateWithFlags(&q.copied[i], hipEventDisableTiming));
-        }
+        for (int i = 0; i < NBUF; ++i) ZL_HIP(e, hipEventCreateWithFlags(&q.copied[i], hipEventDisableTiming));
+        for (hipEvent_t &ev : q.winEv) ZL_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    const size_t needFloats = (size_t)B * 2 * (size_t)sub * (size_t)nframes, needFrames = (size_t)B * (size_t)sub * (size_t)nframes;
-    if (q.busFloats < needFloats || (pcm && q.pcmFrames < needFrames)) {
+    const int nbuf = nblocks > chunk ? NBUF : 1;
+    const size_t needFloats = (size_t)B * 2 * (size_t)chunk * (size_t)nframes, needFrames = (size_t)B * (size_t)chunk * (size_t)nframes;
+    if (q.busFloats < needFloats || (pcm && q.pcmFrames < needFrames) || (nbuf > 1 && (!q.bus[1] || (pcm && !q.pcm[1])))) {
         { int r_ = rt_stop(e); if (r_ != ZLHIP_OK) return r_; }
         { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
         ZL_HIP(e, hipStreamSynchronize(q.copyStream));
         ZlQuiesce quiet(e);                                        // hipFree waits for the device
-        for (int i = 0; i < NBUF; ++i) {
-            if (q.busFloats < needFloats) {
+        const size_t nf = std::max(q.busFloats, needFloats), np = pcm ? std::max(q.pcmFrames, needFrames) : q.pcmFrames;
+        for (int i = 0; i < nbuf; ++i) {
+            if (!q.bus[i] || q.busFloats < nf) {
                 if (q.bus[i]) { ZL_HIP(e, hipFree(q.bus[i])); q.bus[i] = nullptr; }
-                ZL_HIP(e, hipMalloc((void **)&q.bus[i], needFloats * sizeof(float)));
+                ZL_HIP(e, hipMalloc((void **)&q.bus[i], nf * sizeof(float)));
             }
-            if (pcm && q.pcmFrames < needFrames) {
+            if (pcm && (!q.pcm[i] || q.pcmFrames < np)) {
                 if (q.pcm[i]) { ZL_HIP(e, hipFree(q.pcm[i])); q.pcm[i] = nullptr; }
-                ZL_HIP(e, hipMalloc((void **)&q.pcm[i], needFrames * 2 * sizeof(int16_t)));
+                ZL_HIP(e, hipMalloc((void **)&q.pcm[i], np * 2 * sizeof(int16_t)));
             }
         }
-        q.busFloats = std::max(q.busFloats, needFloats);
-        if (pcm) q.pcmFrames = std::max(q.pcmFrames, needFrames);
+        // (a second buffer allocated earlier at a smaller size is dropped: it is allocated again when a bounce needs it)
+        for (int i = nbuf; i < NBUF; ++i) {
+            if (q.bus[i] && q.busFloats < nf) { ZL_HIP(e, hipFree(q.bus[i])); q.bus[i] = nullptr; }
+            if (q.pcm[i] && q.pcmFrames < np) { ZL_HIP(e, hipFree(q.pcm[i])); q.pcm[i] = nullptr; }
+        }
+        q.busFloats = nf; q.pcmFrames = np;
     }
     q.active = true;
-    const int rc = bounce_body(e, nblocks, nframes, clocks, host_out, pcm, sub);
-    q.active = false;
+    const int rc = bounce_body(e, nblocks, nframes, clocks, host_out, pcm, chunk);
+    q.active = false; q.sink.on = false;
     // (also after an error: nothing of this call may still be writing the caller's buffer when it returns)
     const hipError_t cs = hipStreamSynchronize(q.copyStream);
     const int w = engine_wait(e);
@@ -1274,9 +1323,22 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
     // (started before the operations are taken out of the host's pending list: when the start is refused, the cycle goes through
     // the launched path with everything still pending)
     if (!e->rt.running) { int rc = rt_start(e, nframes); if (rc != ZLHIP_OK) return rc; }
+    ZlRtShared *sh = e->rt.h;
+    {
+        // knob edits (no slice table) ride in the mailbox, the first ZL_RT_INLINE_EDITS of them; the rest go through the edit buffer
+        int ni = 0;
+        auto &pe = e->hc.pendingClipEdits;
+        for (size_t i = 0; i < pe.size() && ni < ZL_RT_INLINE_EDITS;) {
+            if (pe[i].full) { ++i; continue; }
+            sh->inline_edits[ni].clip = pe[i].clip; sh->inline_edits[ni].pad = 0;
+            std::memcpy(sh->inline_edits[ni].head, &pe[i].c, ZL_CLIP_HEAD_BYTES);
+            ++ni;
+            pe.erase(pe.begin() + (long)i);
+        }
+        for (; ni < ZL_RT_INLINE_EDITS; ++ni) sh->inline_edits[ni].clip = -1;
+    }
     int rc = upload_ops(e, c, A);
     if (rc != ZLHIP_OK) return rc;
-    ZlRtShared *sh = e->rt.h;
     ZlHostControl::fill_clock(sh->clock, *clock, nframes);
     sh->nframes = nframes; sh->n_op_ranges = A.n_op_ranges; sh->ops = A.ops; sh->op_ranges = A.op_ranges;
     sh->n_clip_edits = A.n_clip_edits; sh->clip_edits = A.clip_edits;

@@ -60,12 +60,23 @@ struct ZlHostControl {
 
     void set_clip_params(int id, const zlhip_clip_params &p)
     {
+        // the slice table travels only when it changed (a kilobyte; the knobs in front of it are 32 bytes)
+        const zlhip_clip_params &old = clipParams[(size_t)id];
+        const bool slices = old.num_slice_positions != p.num_slice_positions
+            || std::memcmp(old.slice_positions, p.slice_positions, sizeof(double) * (size_t)std::max(p.num_slice_positions, 0)) != 0;
         clipParams[(size_t)id] = p;
         ZlClipEdit *slot = nullptr;
         for (ZlClipEdit &e : pendingClipEdits) if (e.clip == id) { slot = &e; break; }
-        if (!slot) { pendingClipEdits.emplace_back(); slot = &pendingClipEdits.back(); }
-        slot->clip = id; slot->pad = 0;
+        if (!slot) { pendingClipEdits.emplace_back(); slot = &pendingClipEdits.back(); slot->full = 0; }
+        slot->clip = id;
+        if (slices) slot->full = 1;
         fill_clip(slot->c, p);
+    }
+    // a sound slot that is (re)used: whatever the table held for it is unknown -- the next edit carries everything
+    void forget_clip_params(int id)
+    {
+        clipParams[(size_t)id] = zlhip_clip_params{};
+        clipParams[(size_t)id].num_slice_positions = -1;
     }
 
     static float adsr_rate(float distance, float timeInSeconds, double sr)      // juce::ADSR::recalculateRates

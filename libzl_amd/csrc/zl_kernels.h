@@ -12,7 +12,7 @@ int zl_launch_reports(const ZlReport *reports, int V, float *gain_out, ZlReport 
                       const ZlBatchStats *stats, ZlBatchStats *host_stats, hipStream_t s, hipEvent_t ev_done = nullptr);
 int zl_launch_levels_tick(ZlLevelsState *state, const ZlBlockLevels *levels, int B, int N, int with_hold_bus, hipStream_t s);
 int zl_launch_passthrough(const void *params_dev, const float *in, float *out, int B, long long frames, hipStream_t s);
-int zl_launch_deliver(const float *bus, void *out, int pcm16, int B, long long frames, long long total, hipStream_t s);
+int zl_launch_deliver(const float *bus, void *out, int pcm16, int B, long long in_stride, long long off, long long frames, long long total, hipStream_t s);
 int zl_launch_interleave(const float *L, const float *R, float *dst, int length, int pad, hipStream_t s);
 int zl_launch_reduce_scan(const float *pieces, int npieces, long long stride, long long units, int N, int off, float *out, ZlUnitLevels *lv, hipStream_t s);
 int zl_launch_levels_import(const ZlUnitLevels *units, ZlBlockLevels *levels, int B, int K, hipStream_t s);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <cstddef>
 #include "zl_types.h"
 #include "zl_plan.h"
 #include "zl_render.h"
@@ -27,10 +28,12 @@
 // mapped host memory; the table is read by the planner at the start of the plan window that follows (zl_plan.h, begin).
 static __device__ __forceinline__ void zl_apply_clip_edit(const ZlBatch &A, const ZlClipEdit *ed, int lane)
 {
+    static_assert(offsetof(ZlClip, slice_pos) == ZL_CLIP_HEAD_BYTES && sizeof(ZlClip) % 16 == 0 && offsetof(ZlClipEdit, c) % 16 == 0, "clip record layout");
     const int clip = ed->clip;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&ed->c);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(const_cast<ZlClip *>(A.clips) + clip);
-    for (int w = lane; w < (int)(sizeof(ZlClip) / 4); w += 64) dst[w] = src[w];
+    const int n16 = ed->full ? (int)(sizeof(ZlClip) / 16) : ZL_CLIP_HEAD_BYTES / 16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(&ed->c);
+    uint4 *dst = reinterpret_cast<uint4 *>(const_cast<ZlClip *>(A.clips) + clip);
+    for (int w = lane; w < n16; w += 64) dst[w] = src[w];
 }
 
 // workgroups [0, ceil(n_op_ranges / 64)): one lane per voice with operations; the following n_clip_edits workgroups: one edit each
@@ -405,6 +408,97 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
     if (PK) { accL = acc.x; accR = acc.y; }
 }
 
+// UNIT + INT chunks with SHARED taps (ZL_K2_UNIT_SHARE=1): at the playback rate inside an exact run, lane f + 1's first tap IS lane
+// f's second (pos = ipos + f), so every lane gathers only its OWN frame -- 8 bytes instead of 16 (16 instead of 32 with four
+// taps) -- and takes its neighbours' from their registers: v_mov_b32_dpp wave_shl:1 / wave_shr:1 (lane i reads lane i + 1 / i - 1;
+// the lane at the end of the wave keeps the `old` operand).  The taps a wave does not hold (frame + 1 of lane 63; frame - 1 of
+// lane 0 and frames + 1, + 2 of lane 63 with four taps) come from ONE extra load executed by those lanes only.  Half (a quarter)
+// of the bytes through the texture addresser, the same operands in the same order: bit-identical results.
+#ifndef ZL_K2_UNIT_SHARE
+#define ZL_K2_UNIT_SHARE 0
+#endif
+#define ZL_DPP_WAVE_SHL1 0x130
+#define ZL_DPP_WAVE_SHR1 0x138
+static __device__ __forceinline__ float zl_dpp_next(float old, float v)    // lane i <- lane i + 1; lane 63 <- old
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), ZL_DPP_WAVE_SHL1, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ float zl_dpp_prev(float old, float v)    // lane i <- lane i - 1; lane 0 <- old
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), ZL_DPP_WAVE_SHR1, 0xf, 0xf, false));
+}
+
+template <uint32_t MODE, int U>
+static __device__ __forceinline__ void zl_k2_chunk_unit_shared(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
+                                                                int c0, int vfirst, int f, bool wantPeak, float &accL, float &accR)
+{
+    constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
+    const int lane = (int)(threadIdx.x & 63u);
+    zl_f2a4b b[U];                                                // the lane's own frame (L, R) of every voice
+    zl_f2a4b ex2[HERM ? 1 : U];                                   // linear: frame + 1 of lane 63
+    zl_f4a4  ex4[HERM ? U : 1];                                   // four taps: frames - 1, 0 of lane 0; frames + 1, + 2 of lane 63
+    const char *src[U];
+    uint32_t ob[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = c0 + u;
+        const int pos = s_unit[i].ipos + f;
+        const uint64_t so = s_vc[i].src_offset;
+        src[u] = reinterpret_cast<const char *>(A.arena + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(so >> 32)) << 32)
+                                                            | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)so)));
+        ob[u] = (uint32_t)pos << 3;
+        b[u] = *reinterpret_cast<const zl_f2a4b *>(src[u] + ob[u]);
+    }
+    if (HERM) {
+        if (lane == 0 || lane == 63) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ex4[u] = *reinterpret_cast<const zl_f4a4 *>(src[u] + (lane == 0 ? ob[u] - 8u : ob[u] + 8u));
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ex4[u] = (zl_f4a4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    } else {
+        if (lane == 63) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ex2[u] = *reinterpret_cast<const zl_f2a4b *>(src[u] + ob[u] + 8u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ex2[u] = (zl_f2a4b){0.0f, 0.0f};
+        }
+    }
+    zl_f2 acc = {accL, accR};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = c0 + u;
+        const float alpha = s_unit[i].alpha;
+        float l, r;
+        if (HERM) {
+            const zl_f2 x0 = {b[u].x, b[u].y};
+            const zl_f2 xm = {zl_dpp_prev(ex4[u].x, b[u].x), zl_dpp_prev(ex4[u].y, b[u].y)};
+            const zl_f2 x1 = {zl_dpp_next(ex4[u].x, b[u].x), zl_dpp_next(ex4[u].y, b[u].y)};
+            const zl_f2 x2 = {zl_dpp_next(ex4[u].z, x1.x), zl_dpp_next(ex4[u].w, x1.y)};
+            const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, alpha, true, true, (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
+                                                  (zl_f2){s_vc[i].lpan, s_vc[i].rpan}, (zl_f2){s_unit[i].gpl, s_unit[i].gpr});
+            acc += o;
+            l = o.x; r = o.y;
+        } else {
+            ZlTaps t;
+            t.x0l = b[u].x; t.x0r = b[u].y;
+            t.x1l = zl_dpp_next(ex2[u].x, b[u].x); t.x1r = zl_dpp_next(ex2[u].y, b[u].y);
+            t.xml = t.xmr = t.x2l = t.x2r = 0.0f;
+            zl_mix_frame<MODE>(t, alpha, true, true, true, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env, s_vc[i].clip_volume, s_vc[i].lpan, s_vc[i].rpan, l, r);
+            acc.x += l; acc.y += r;
+        }
+        if (wantPeak) {                                           // :213-216, signed peak from 0 (Q6)
+            const float ng = l + r;
+            float pk = ng > 0.0f ? ng : 0.0f;
+            pk = zl_wave_max(pk);
+            if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(&A.reports[vfirst + i].peak_bits, __float_as_uint(pk));
+        }
+    }
+    accL = acc.x; accR = acc.y;
+}
+
 // The same for chunks of mono sources: an 8-byte gather [x0 x1] (16 bytes [x-1 x0 x1 x2] for Hermite), r = l (:205, Q4).
 template <uint32_t MODE, bool SEG2, bool UNIT, bool INT, int U>
 static __device__ __forceinline__ void zl_k2_chunk_simple_mono(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
@@ -768,6 +862,21 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
                 if (written) { outL[f + 1] = accL; outR[f + 1] = accR; }
                 if (f == 0)  { outL[0] = 0.0f;    outR[0] = 0.0f; }
             }
+            if (A.host_out && A.groups == 1) {
+                // offline bounce: the same samples once more, into the caller's page-locked host buffer (stores over PCIe; a wave's
+                // 64 frames are 256 contiguous bytes per row), in the recorder's 16-bit format if asked (zl_pcm16)
+                const size_t fo = (size_t)(A.host_k0 + A.k0 + k) * N;
+                const int at = (MODE & ZL_MODE_FIX_DELAY) ? f : f + 1;
+                if (A.host_fmt == 1) {
+                    uint32_t *o = static_cast<uint32_t *>(A.host_out) + (size_t)bus * (size_t)A.host_total + fo;
+                    if (at < N) __builtin_nontemporal_store((uint32_t)(uint16_t)zl_pcm16(accL) | ((uint32_t)(uint16_t)zl_pcm16(accR) << 16), o + at);
+                    if (!(MODE & ZL_MODE_FIX_DELAY) && f == 0) __builtin_nontemporal_store(0u, o);
+                } else {
+                    float *oL = static_cast<float *>(A.host_out) + ((size_t)bus * 2) * (size_t)A.host_total + fo, *oR = oL + A.host_total;
+                    if (at < N) { __builtin_nontemporal_store(accL, oL + at); __builtin_nontemporal_store(accR, oR + at); }
+                    if (!(MODE & ZL_MODE_FIX_DELAY) && f == 0) { __builtin_nontemporal_store(0.0f, oL); __builtin_nontemporal_store(0.0f, oR); }
+                }
+            }
             if (A.fan && A.groups == 1) {
                 // fused JackPassthrough fan-out of the finished bus (JackPassthrough.cpp:45-115): three more stereo pairs
                 // written from the registers that hold the mix -- no second pass over the bus
@@ -1003,7 +1112,12 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
             if (cc) zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
 #endif
             if (cc == 0) {                                        // nobody in this chunk plays (SamplerSynth.cpp:137)
-            } else if ((cc & 124) == 100) zl_k2_chunk_simple<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            } else if ((cc & 124) == 100) {
+                // (the shared-tap form needs a wave's lanes to be consecutive frames of one block: true for every launch shape --
+                // a wave is a 64-frame tile of its block)
+                if (ZL_K2_UNIT_SHARE) zl_k2_chunk_unit_shared<MODE, U>(A, s_plan, s_vc, s_unit, c0, vb, f, wantPeak, accL, accR);
+                else zl_k2_chunk_simple<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            }
             else if ((cc & 92) == 68)   zl_k2_chunk_simple<MODE, false, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
             else if ((cc & 28) == 4)    zl_k2_chunk_simple<MODE, false, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
             else if ((cc & 20) == 4)    zl_k2_chunk_simple<MODE, true, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
@@ -1097,6 +1211,12 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
                         w[1] = (unsigned long long)(uintptr_t)sh->ops; w[2] = (unsigned long long)(uintptr_t)sh->op_ranges; w[3] = sh->ctl_base;
                         w[4] = sh->clock.current_usecs; w[5] = sh->clock.next_usecs; w[6] = sh->clock.playhead; w[7] = sh->clock.playhead_usecs;
                         w[8] = sh->clock.subbeat_usecs; w[9] = sh->clock.usecs_per_frame; w[10] = (unsigned long long)(uint32_t)sh->n_clip_edits; w[11] = (unsigned long long)(uintptr_t)sh->clip_edits;
+                        {
+                            static_assert(sizeof(sh->inline_edits) == ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS * 8, "inline edits are whole words");
+                            const unsigned long long *ie = reinterpret_cast<const unsigned long long *>(&sh->inline_edits[0]);
+#pragma unroll
+                            for (int i = 0; i < ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS; ++i) w[12 + i] = ie[i];
+                        }
 #pragma unroll
                         for (int i = 0; i < ZL_RT_CMD_WORDS; ++i) { s_cmd[1 + i] = w[i]; __hip_atomic_store(&dev->cmd[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1164,6 +1284,13 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         //      cycle at most).  A workgroup then plans from what it wrote itself -- its own XCD's L2 -- so no hand-off between
         //      workgroups is needed, and the table is complete in HBM when the kernel leaves.
         for (int i = tid >> 6; i < A.n_clip_edits; i += (int)(blockDim.x >> 6)) zl_apply_clip_edit(A, A.clip_edits + i, lane);
+        // (the knob edits that came with the command: 8 words each, from LDS)
+        if (tid < ZL_RT_INLINE_EDITS * (ZL_CLIP_HEAD_BYTES / 4)) {
+            const int ei = tid / (ZL_CLIP_HEAD_BYTES / 4), wi = tid % (ZL_CLIP_HEAD_BYTES / 4);
+            const unsigned long long *ew = &s_cmd[1 + 12 + ei * ZL_RT_EDIT_WORDS];
+            const int clip = (int)(uint32_t)ew[0];
+            if (clip >= 0) reinterpret_cast<uint32_t *>(const_cast<ZlClip *>(A.clips) + clip)[wi] = reinterpret_cast<const uint32_t *>(ew + 1)[wi];
+        }
         const ZlOpRange *ranges = WIDE ? dev_ranges : A.op_ranges;
         for (int i = tid; i < A.n_op_ranges; i += (int)blockDim.x) {
             const ZlOpRange rg = ranges[i];
@@ -1483,18 +1610,19 @@ __global__ void __launch_bounds__(256) zl_k_passthrough(const ZlPassParams *para
 // the floats as they are, [B][2][total].  Four frames per lane: 16-byte loads, one (PCM) or two 16-byte stores.  The engine uses it
 // for the 16-bit conversion into a device staging buffer (total = frames); the copy engine moves the rows to the host.
 template <bool PCM>
-__global__ void __launch_bounds__(256) zl_k_deliver(const float *bus, void *out, long long frames, long long total)
+__global__ void __launch_bounds__(256) zl_k_deliver(const float *bus, void *out, long long in_stride, long long off, long long frames, long long total)
 {
+    // frames [off, off + frames) of every bus row (rows are in_stride floats apart) -> the same frames of the output (rows of `total` frames)
     const int b = blockIdx.y;
-    const float4 *L = reinterpret_cast<const float4 *>(bus + (size_t)b * 2 * frames), *R = reinterpret_cast<const float4 *>(bus + ((size_t)b * 2 + 1) * frames);
+    const float4 *L = reinterpret_cast<const float4 *>(bus + (size_t)b * 2 * in_stride + off), *R = reinterpret_cast<const float4 *>(bus + ((size_t)b * 2 + 1) * in_stride + off);
     const long long nvec = frames / 4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         const float4 l = L[i], r = R[i];
         if (PCM) {
             auto pair = [](float a, float c) { return (uint32_t)(uint16_t)zl_pcm16(a) | ((uint32_t)(uint16_t)zl_pcm16(c) << 16); };
-            reinterpret_cast<uint4 *>(static_cast<int16_t *>(out) + (size_t)b * 2 * total)[i] = make_uint4(pair(l.x, r.x), pair(l.y, r.y), pair(l.z, r.z), pair(l.w, r.w));
+            reinterpret_cast<uint4 *>(static_cast<int16_t *>(out) + ((size_t)b * total + off) * 2)[i] = make_uint4(pair(l.x, r.x), pair(l.y, r.y), pair(l.z, r.z), pair(l.w, r.w));
         } else {
-            float *o = static_cast<float *>(out) + (size_t)b * 2 * total;
+            float *o = static_cast<float *>(out) + (size_t)b * 2 * total + off;
             reinterpret_cast<float4 *>(o)[i] = l;
             reinterpret_cast<float4 *>(o + total)[i] = r;
         }
@@ -1667,13 +1795,13 @@ int zl_launch_passthrough(const void *params_dev, const float *in, float *out, i
     return 0;
 }
 
-int zl_launch_deliver(const float *bus, void *out, int pcm16, int B, long long frames, long long total, hipStream_t s)
+int zl_launch_deliver(const float *bus, void *out, int pcm16, int B, long long in_stride, long long off, long long frames, long long total, hipStream_t s)
 {
     long long nb = (frames / 4 + 255) / 256;
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
-    if (pcm16) hipLaunchKernelGGL(zl_k_deliver<true>, dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, frames, total);
-    else       hipLaunchKernelGGL(zl_k_deliver<false>, dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, frames, total);
+    if (pcm16) hipLaunchKernelGGL(zl_k_deliver<true>, dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, in_stride, off, frames, total);
+    else       hipLaunchKernelGGL(zl_k_deliver<false>, dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, in_stride, off, frames, total);
     ZL_LAUNCH_CHECK();
     return 0;
 }

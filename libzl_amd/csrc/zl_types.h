@@ -46,9 +46,12 @@ struct ZlClip {
 // start of the next render call / real-time cycle (K0, or every workgroup of the resident kernel) -- the boundary at which
 // the reference's voices read the parameters (SamplerSynthVoice.cpp:189-196), and no HIP call on the host.
 struct ZlClipEdit {
-    int32_t clip, pad;
+    int32_t clip, pad0, pad1;     // (the record below starts on a 16-byte boundary: it is copied with 16-byte accesses)
+    int32_t full;                 // 1: the slice table changed too; 0: only the 32 bytes in front of it (a pan / volume / length knob: one
+                                  // 16-byte load per lane for two lanes instead of a kilobyte over PCIe)
     ZlClip  c;
 };
+#define ZL_CLIP_HEAD_BYTES 32     // offsetof(ZlClip, slice_pos)
 
 // SamplerSynthVoicePrivate + juce::ADSR state (SamplerSynthVoice.cpp:20-39), device resident.
 struct ZlVoiceState {
@@ -214,6 +217,9 @@ struct ZlRtShared {
     ZlClock  clock;
     unsigned long long stamps[8]; // s_memrealtime (100 MHz) at the kernel's stages of the last block (diagnostic)
     const ZlClipEdit  *clip_edits;// the cycle's clip-parameter edits (mapped host memory), applied before the cycle is planned
+    // up to ZL_RT_INLINE_EDITS knob edits (the 32 bytes in front of the slice table) travel in the mailbox itself: workgroup 0
+    // reads them with the rest of the command -- no extra trip over PCIe for a pan or volume knob turned while playing
+    struct { int32_t clip, pad; uint32_t head[ZL_CLIP_HEAD_BYTES / 4]; } inline_edits[2];
     int32_t  n_clip_edits;
     uint32_t yield;               // another thread of the process is about to make a device-synchronising HIP call (hipFree, ...):
                                   // leave after the cycle in flight (zl_engine.cpp, ZlQuiesce)
@@ -222,11 +228,13 @@ struct ZlRtShared {
 // Device side of the resident kernel: workgroup 0 watches the mailbox and republishes every block in HBM for the other
 // workgroups (agent-scope atomics: eight-byte words, visible across XCDs without cache fences); `arrive` counts the workgroups
 // that have finished the block.
-#define ZL_RT_CMD_WORDS 12
+#define ZL_RT_INLINE_EDITS 2
+#define ZL_RT_EDIT_WORDS (1 + ZL_CLIP_HEAD_BYTES / 8)      // clip id + the head, in 8-byte words
+#define ZL_RT_CMD_WORDS (12 + ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS)
 #define ZL_RT_MAX_BUSES 256
 struct ZlRtDev {
     unsigned long long pub_seq;                  // the block being rendered (~0ull: leave)
-    unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words), n_clip_edits, clip_edits
+    unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words), n_clip_edits, clip_edits, the inline knob edits
     unsigned int arrive, pad;
     unsigned int bus_arrive[ZL_RT_MAX_BUSES];    // wide buses (one workgroup per voice): the voices of a bus that have written their partial mix
 };
@@ -238,6 +246,10 @@ struct ZlBatch {
     int32_t G;                    // voices per render task (mix group); groups per bus = ceil(VPB / G)
     int32_t groups;
     int32_t NB;                   // buses rendered by one K2 workgroup (narrow buses in batches), else 1
+    int32_t host_fmt;             // offline bounce, direct delivery: K2 also stores the finished bus into the caller's page-locked HOST buffer
+                                  // (0 = fp32 planar [B][2][host_total], 1 = 16-bit stereo [B][host_total][2]) -- no conversion pass, no copy
+    void   *host_out;             // device view of that buffer, or nullptr
+    long long host_total, host_k0;// frames per row of the host buffer; first block of this call inside it
     uint32_t mode;
     int32_t n_op_ranges;
     int32_t trace;                // 1 = write pos trace

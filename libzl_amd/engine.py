@@ -244,8 +244,8 @@ class SamplerSynth:
         if out.shape != shape or out.dtype != dtype or not out.flags.c_contiguous:
             raise ValueError(f"bounce: out must be a C-contiguous {np.dtype(dtype).name} array of shape {shape}")
         self._ck(self._lib.zlhip_bounce(self._e, nblocks, nframes, C.cast(clocks, C.c_void_p), out.ctypes.data, 1 if pcm else 0, sub_blocks), "bounce")
-        # what read_bus / block_peaks / levels_tick see afterwards: the last sub-batch (the split of zlhip_bounce)
-        sub = min(sub_blocks if sub_blocks > 0 else max(256, (nblocks + 5) // 6), self.cfg.max_batch_blocks, nblocks)
+        # what read_bus / block_peaks / levels_tick see afterwards: the last chunk (the split of zlhip_bounce)
+        sub = min(sub_blocks if sub_blocks > 0 else self.cfg.max_batch_blocks, self.cfg.max_batch_blocks, nblocks)
         self._last = (nblocks - sub * ((nblocks - 1) // sub), nframes)
         return out
 

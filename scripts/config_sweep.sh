@@ -5,7 +5,7 @@ tag=${1:-r01}
 out=gpurun_out/config_sweep_$tag.jsonl
 mkdir -p gpurun_out
 : > $out
-run() { echo "### $*" >> $out; timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --no-repeats --no-spot-check --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/config_sweep_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/config_sweep_err.log >> $out; return 1; }; }
+run() { echo "### $*" >> $out; timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reuse-check --no-repeats --steps 6 --warmup 2 "$@" >> $out 2>gpurun_out/config_sweep_err.log || { echo "FAILED: $*" >> $out; tail -5 gpurun_out/config_sweep_err.log >> $out; return 1; }; }
 run --voices 64 --buses 8 --frames 256 &&
 run --voices 64 --buses 8 --frames 256 --source-rate 44100 --notes 48,72 &&
 run --voices 96 --buses 12 --frames 256 &&

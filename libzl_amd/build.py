@@ -18,7 +18,7 @@ LIBDIR = os.path.join(ROOT, "libzl_amd", "lib")
 LIB = os.path.join(LIBDIR, "libzlhip.so")
 
 HIP_SOURCES = ["zl_kernels.hip", "zl_engine.cpp", "zl_libzl.cpp"]
-HEADERS = ["zl_types.h", "zl_plan.h", "zl_render.h", "zl_kernels.h", "zl_host.h", "zl_sched.h",
+HEADERS = ["zl_types.h", "zl_plan.h", "zl_render.h", "zl_kernels.h", "zl_host.h", "zl_sched.h", "zl_handoff.h",
            os.path.join("..", "..", "include", "zlhip.h"), os.path.join("..", "..", "include", "libzl_hotpath.h")]
 
 
@@ -66,7 +66,7 @@ _INC = os.path.join("..", "..", "include")
 SOURCE_DEPS = {
     "zl_kernels.hip": ["zl_types.h", "zl_plan.h", "zl_render.h", "zl_kernels.h"],
     "zl_engine.cpp": ["zl_types.h", "zl_plan.h", "zl_host.h", "zl_kernels.h", os.path.join(_INC, "zlhip.h")],
-    "zl_libzl.cpp": ["zl_render.h", "zl_types.h", "zl_sched.h", os.path.join(_INC, "zlhip.h"), os.path.join(_INC, "libzl_hotpath.h")],
+    "zl_libzl.cpp": ["zl_render.h", "zl_types.h", "zl_sched.h", "zl_handoff.h", os.path.join(_INC, "zlhip.h"), os.path.join(_INC, "libzl_hotpath.h")],
 }
 
 

@@ -25,6 +25,7 @@
 #include "../../include/libzl_hotpath.h"
 #include "zl_render.h"       // zl_pcm16: the recorder's 16-bit sample format
 #include "zl_sched.h"        // the ClipCommand scheduling front-end (SyncTimer.cpp:452-702,1011-1048)
+#include "zl_handoff.h"      // what crosses from the callers' threads to the cycle: the request queue, the parameter snapshots
 
 namespace {
 
@@ -96,19 +97,6 @@ struct PassState { float dry = 1.0f, fx1 = 1.0f, fx2 = 1.0f, pan = 0.0f; bool mu
 
 }  // namespace
 
-// ---- what the real-time thread reads of a clip: published by the setters through a sequence lock ----------------------
-// The reference's setters run unlocked on the caller's thread and the voice reads the fields per block
-// (libzl.cpp:230-302, SamplerSynthVoice.cpp:189-196).  Here a setter (UI thread; setters of one clip are serialised among
-// themselves by the clip's setMu, which the real-time thread never takes) writes the clip's fields and publishes a snapshot:
-// sequence odd, copy, sequence even, dirty.  The cycle (libzl_hotpath_process / _cycle) picks dirty snapshots up at its top
-// and hands them to zlhip_clip_set, which makes no HIP call -- the device applies them at the cycle boundary.  A snapshot that
-// is being written at that instant is taken at the next cycle: the real-time thread never waits for a setter.
-struct ClipSnapshot {
-    std::atomic<uint32_t> seq{0};
-    std::atomic<bool> dirty{false};
-    zlhip_clip_params params;                                       // guarded by seq
-};
-
 struct ClipAudioSource {
     int id = 0;
     int engineClip = -1;
@@ -128,7 +116,7 @@ struct ClipAudioSource {
     std::vector<double> slicePositions;
     int sliceBaseMidiNote = 60, keyZoneStart = 0, keyZoneEnd = 127, rootNote = 60;
     AdsrParams adsr;
-    ClipSnapshot snap;
+    ZlSnapshot<zlhip_clip_params> snap;
     // real-time side
     PositionsModel positions;
     std::atomic<float> startPositionRt{0.0f};                      // startPositionInSeconds as the cycle reads it (syncProgress, :227)
@@ -141,47 +129,15 @@ struct ClipAudioSource {
 
 namespace {
 
-// ---- requests from any thread to the cycle: a bounded lock-free multi-producer queue (per-cell sequence numbers) -------------
-// ClipAudioSource::play / stop call SyncTimer::scheduleClipCommand on the caller's thread in the reference (the step lists are
-// QLists touched without a lock); here the caller only posts the request and the cycle applies it -- in arrival order, before it
-// looks at the steps that are due -- so the scheduler's state belongs to one thread and the caller never holds a lock the
+// ClipAudioSource::play / stop call SyncTimer::scheduleClipCommand on the caller's thread in the reference (the step lists are QLists
+// touched without a lock); here the caller only posts the request (zl_handoff.h) and the cycle applies it -- in arrival order, before
+// it looks at the steps that are due -- so the scheduler's state belongs to one thread and the caller never holds a lock the
 // real-time thread wants.
 struct Request {
     enum Kind : int32_t { Schedule, QueueStart, QueueStop, TimerStart, TimerStop, SetBpm, TimerTick } kind;
     int32_t a, b;                                                  // QueueStart/Stop: clip, channel; TimerStart / SetBpm: bpm
     uint64_t delay;
     zlhip_clip_command cmd;
-};
-
-struct RequestQueue {
-    static constexpr size_t CAP = 4096;                            // FreshCommandStashSize, SyncTimer.cpp:252
-    struct Cell { std::atomic<size_t> seq; Request r; };
-    Cell cells[CAP];
-    std::atomic<size_t> head{0}, tail{0};
-    RequestQueue() { for (size_t i = 0; i < CAP; ++i) cells[i].seq.store(i, std::memory_order_relaxed); }
-    bool push(const Request &r)
-    {
-        size_t pos = tail.load(std::memory_order_relaxed);
-        for (;;) {
-            Cell &c = cells[pos % CAP];
-            const size_t sq = c.seq.load(std::memory_order_acquire);
-            const intptr_t d = (intptr_t)sq - (intptr_t)pos;
-            if (d == 0) { if (tail.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) { c.r = r; c.seq.store(pos + 1, std::memory_order_release); return true; } }
-            else if (d < 0) return false;                          // full
-            else pos = tail.load(std::memory_order_relaxed);
-        }
-    }
-    bool pop(Request &r)                                           // single consumer: the cycle
-    {
-        const size_t pos = head.load(std::memory_order_relaxed);
-        Cell &c = cells[pos % CAP];
-        if (c.seq.load(std::memory_order_acquire) != pos + 1) return false;
-        r = c.r;
-        c.seq.store(pos + CAP, std::memory_order_release);
-        head.store(pos + 1, std::memory_order_relaxed);
-        return true;
-    }
-    void clear() { Request r; while (pop(r)) { } }
 };
 
 struct Global {
@@ -195,7 +151,7 @@ struct Global {
     std::vector<int64_t> voicePositionId;      // per voice slot: row in its clip's positions model
     std::vector<ClipAudioSource *> voiceClip;  // per voice slot: clip being played (host view)
     std::vector<zlhip_voice_report> reports;
-    RequestQueue requests;
+    ZlRequestQueue<Request, 4096> requests;          // FreshCommandStashSize, SyncTimer.cpp:252
     ZlStepSequencer seq;                       // SyncTimer's step ring (libzl_hotpath_cycle)
     ZlHostTransportSchedule ext;               // the host's SyncTimer owns the transport (libzl_hotpath_process)
     std::vector<ZlDispatch> due;               // commands of the steps due in this cycle
@@ -210,11 +166,7 @@ struct PendingCallback { void (*fn)(float); float value; };
 // setters: the clip's fields -> its published snapshot (call with c->setMu held)
 void publish_params(ClipAudioSource *c)
 {
-    ClipSnapshot &sn = c->snap;
-    const uint32_t s0 = sn.seq.load(std::memory_order_relaxed);
-    sn.seq.store(s0 + 1, std::memory_order_relaxed);
-    std::atomic_thread_fence(std::memory_order_release);
-    zlhip_clip_params &p = sn.params;
+    zlhip_clip_params p;
     std::memset(&p, 0, sizeof p);
     p.start_position_seconds = c->startPositionInSeconds;
     p.length_seconds = c->lengthInSeconds;
@@ -226,26 +178,16 @@ void publish_params(ClipAudioSource *c)
     p.root_note = c->rootNote;
     p.num_slice_positions = (int32_t)std::min<size_t>(c->slicePositions.size(), ZLHIP_MAX_SLICES);
     for (int i = 0; i < p.num_slice_positions; ++i) p.slice_positions[i] = c->slicePositions[(size_t)i];
-    std::atomic_thread_fence(std::memory_order_release);
-    sn.seq.store(s0 + 2, std::memory_order_release);
     c->startPositionRt.store(c->startPositionInSeconds, std::memory_order_relaxed);
-    sn.dirty.store(true, std::memory_order_release);
+    c->snap.publish(p);
 }
 
 // the cycle: a dirty snapshot -> the engine.  Wait-free: a snapshot caught in the middle of a write stays dirty for the next cycle.
 void apply_params(ClipAudioSource *c)
 {
     if (!G.engine || c->engineClip < 0) return;
-    ClipSnapshot &sn = c->snap;
-    if (!sn.dirty.exchange(false, std::memory_order_acq_rel)) return;
-    const uint32_t s1 = sn.seq.load(std::memory_order_acquire);
     zlhip_clip_params p;
-    if (!(s1 & 1u)) {
-        std::memcpy(&p, &sn.params, sizeof p);
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (sn.seq.load(std::memory_order_relaxed) == s1) { zlhip_clip_set(G.engine, c->engineClip, &p); return; }
-    }
-    sn.dirty.store(true, std::memory_order_release);
+    if (c->snap.take(p)) zlhip_clip_set(G.engine, c->engineClip, &p);
 }
 
 void set_slices(ClipAudioSource *c, int slices)                    // ClipAudioSource.cpp:495-528

@@ -262,3 +262,39 @@ def test_numpy_restatement_fma_is_one_rounding():
             a = f32(rng.uniform(-1, 1) * 2.0 ** int(rng.integers(-20, 20))); b = f32(rng.uniform(-1, 1))
             c = f32(rng.uniform(-1, 1) * 2.0 ** int(rng.integers(-30, 10)))
         assert fma32(a, b, c).view(np.int32) == exact32(a, b, c).view(np.int32), (a, b, c)
+
+
+def test_hermite_tap_weight_form_stays_within_rounding_of_the_horner_form(lib):
+    """ZLHIP_MODE_HERMITE was redefined in round 2 (ABI 2) from the Horner evaluation of the Catmull-Rom cubic to the
+    tap-weight form with fused multiply-adds and the gain product formed first.  Both are roundings of the same polynomial: on random
+    material, pitched, the oracle's output stays within a few fp32 ulps of the Horner form evaluated here in fp32 (JUCE's
+    CatmullRomInterpolator shape), and equals the float64 cubic to ~1e-7 -- so a later change of form cannot drift
+    silently past rounding."""
+    rng = np.random.default_rng(0x4E4D)
+    x = rng.uniform(-1, 1, 5000).astype(np.float32)
+    sc = one_voice_scene(x, None, note=53, nframes=64, nblocks=6, beats=3.7, mode=4)
+    tr, _ = oracle_trace(sc)
+    bus, _, _ = run_oracle(sc)
+    ratio = 2.0 ** ((53 - 60) / 12.0)
+    P = 0.0
+    worst_h, worst_64 = 0.0, 0.0
+    for k in range(6):
+        for f in range(64):
+            pos = int(P)
+            assert tr[k, 0, f] == pos
+            a = f32(P - pos)
+            if pos >= 1 and f + 1 < 64:
+                y0, y1, y2, y3 = (x[pos - 1], x[pos], x[pos + 1], x[pos + 2])
+                # Horner form in fp32: y1 + a (c1 + a (c2 + a c3))
+                c1 = f32(0.5) * (y2 - y0)
+                c2 = (y0 + f32(2.0) * y2) - (f32(0.5) * y3 + f32(2.5) * y1)
+                c3 = (f32(0.5) * y3 + f32(1.5) * y1) - (f32(0.5) * y0 + f32(1.5) * y2)
+                horner = f32(y1 + a * f32(c1 + a * f32(c2 + a * c3)))
+                a64 = float(a)
+                d = [float(v) for v in (y0, y1, y2, y3)]
+                exact = d[1] + a64 * (0.5 * (d[2] - d[0]) + a64 * ((d[0] + 2 * d[2] - 0.5 * d[3] - 2.5 * d[1]) + a64 * (0.5 * d[3] + 1.5 * d[1] - 0.5 * d[0] - 1.5 * d[2])))
+                got = float(bus[0, 0, k * 64 + f + 1]) * 2.0          # mono, pan 0: the output is 0.5 x the sample; gain, envelope, volume are 1
+                worst_h = max(worst_h, abs(got - float(horner)))
+                worst_64 = max(worst_64, abs(got - exact))
+            P += ratio
+    assert 0.0 < worst_h < 6e-7 and worst_64 < 4e-7, (worst_h, worst_64)

@@ -62,9 +62,26 @@ struct ZlStepSequencer {
         std::vector<zlhip_clip_command> clipCommands;
         std::vector<int> bpmCommands;                         // TimerCommand::SetBpmOperation parameters
         bool played = true;                                   // :78
-        void ensureFresh() { if (played) { played = false; clipCommands.clear(); bpmCommands.clear(); } }   // :50-62
+        bool listed = false;                                  // (an entry of freshSteps points here)
     };
     std::vector<Step> ring;
+    // the steps that have been made fresh (unplayed) since they were last played: the reference walks all 32768 steps in stop() and
+    // queueClipToStopOnChannel() on the caller's thread; here those calls run on the cycle's thread, which only visits these
+    std::vector<uint32_t> freshSteps;
+    void ensureFresh(uint64_t index)                          // StepData::ensureFresh, :50-62
+    {
+        Step &sd = ring[index];
+        if (sd.played) {
+            sd.played = false; sd.clipCommands.clear(); sd.bpmCommands.clear();
+            if (!sd.listed) { sd.listed = true; freshSteps.push_back((uint32_t)index); }
+        }
+    }
+    void pruneFresh()
+    {
+        size_t n = 0;
+        for (uint32_t i : freshSteps) { if (!ring[i].played) freshSteps[n++] = i; else ring[i].listed = false; }
+        freshSteps.resize(n);
+    }
     uint64_t stepReadHead = 0;                                // index of *stepReadHead
     uint64_t stepNextPlaybackPosition = 0;
     // SyncTimerThread
@@ -88,6 +105,7 @@ struct ZlStepSequencer {
     void reset()
     {
         ring.assign(StepRingCount, Step());
+        freshSteps.clear();
         stepReadHead = 0; stepNextPlaybackPosition = 0;
         bpm = 120; threadPaused = true; isPaused = true;
         jackPlayhead = 0; jackPlayheadBpm = 120; jackNextPlaybackPosition = 0;
@@ -123,9 +141,8 @@ struct ZlStepSequencer {
         uint64_t step;
         if (isPaused) step = (stepReadHead + delay + 1) % StepRingCount;
         else step = (stepReadHeadOnStart + std::max(cumulativeBeat + delay, jackPlayhead + 1)) % StepRingCount;
-        Step &sd = ring[step];
-        if (ensureFresh) sd.ensureFresh();
-        return sd;
+        if (ensureFresh) this->ensureFresh(step);
+        return ring[step];
     }
 
     void scheduleClipCommand(const zlhip_clip_command &command, uint64_t delay)           // :1011-1048
@@ -159,18 +176,33 @@ struct ZlStepSequencer {
     {
         threadPaused = true; isPaused = true;
         beat = 0; cumulativeBeat = 0; jackPlayhead = 0;
-        for (uint64_t step = 0; step < StepRingCount; ++step) {
-            const uint64_t idx = (step + stepReadHead) % StepRingCount;
+        // the reference walks the whole ring from the read head; only unplayed steps matter, and only the target of delay 0 -- the step
+        // behind the read head, offset 1 of the walk -- can become unplayed DURING the walk (when the read-head step re-schedules into
+        // it).  So: the unplayed steps in walk order, with the target looked at in its turn whether it was unplayed before or not.
+        pruneFresh();
+        const uint64_t target = (stepReadHead + 1) % StepRingCount;
+        std::vector<uint32_t> walk(freshSteps);
+        std::sort(walk.begin(), walk.end(), [this](uint32_t a, uint32_t b) {
+            return (a + StepRingCount - stepReadHead) % StepRingCount < (b + StepRingCount - stepReadHead) % StepRingCount; });
+        bool targetDone = false;
+        auto visit = [&](uint64_t idx) {
             Step &sd = ring[idx];
-            if (!sd.played) {
-                const uint64_t target = (stepReadHead + 1) % StepRingCount;
-                // (the target step itself: each of its commands is equivalent to itself, so it folds into the step it is already in
-                // and nothing is appended -- the step is marked played with its commands, which are never dispatched)
-                if (idx != target)
-                    for (zlhip_clip_command c : sd.clipCommands) { c.change_volume = 1; c.volume = 0; scheduleClipCommand(c, 0); }
-                sd.played = true;
+            if (sd.played) return;
+            // (the target step itself: each of its commands is equivalent to itself, so it folds into the step it is already in
+            // and nothing is appended -- the step is marked played with its commands, which are never dispatched)
+            if (idx != target) {
+                const std::vector<zlhip_clip_command> cmds(sd.clipCommands);
+                for (zlhip_clip_command c : cmds) { c.change_volume = 1; c.volume = 0; scheduleClipCommand(c, 0); }
             }
+            ring[idx].played = true;
+        };
+        for (uint32_t idx : walk) {
+            const uint64_t off = (idx + StepRingCount - stepReadHead) % StepRingCount;
+            if (off >= 1 && !targetDone) { visit(target); targetDone = true; if (idx == target) continue; }
+            visit(idx);
         }
+        if (!targetDone) visit(target);
+        pruneFresh();
     }
 
     // the clock's tick: the timer thread calls this once per subbeat interval while it runs (:391-418)
@@ -195,11 +227,11 @@ struct ZlStepSequencer {
 
     void queueClipToStopOnChannel(int32_t clip, int midiChannel)                           // :834-860
     {
-        for (Step &sd : ring) {
-            if (!sd.played) {
-                for (size_t i = 0; i < sd.clipCommands.size(); ++i)
-                    if (sd.clipCommands[i].clip == clip) { sd.clipCommands.erase(sd.clipCommands.begin() + (long)i); break; }
-            }
+        pruneFresh();
+        for (uint32_t idx : freshSteps) {                                                  // every unplayed step (:837-850)
+            Step &sd = ring[idx];
+            for (size_t i = 0; i < sd.clipCommands.size(); ++i)
+                if (sd.clipCommands[i].clip == clip) { sd.clipCommands.erase(sd.clipCommands.begin() + (long)i); break; }
         }
         zlhip_clip_command command;
         zlhip_clip_command_clear_inline(command);
@@ -212,6 +244,7 @@ struct ZlStepSequencer {
     void process(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, std::vector<ZlDispatch> &out)
     {
         (void)period_usecs;
+        if (freshSteps.size() > 1024) pruneFresh();                                         // (entries of steps played long ago)
         double thisStepBpm = jackPlayheadBpm;
         double thisStepSubbeatLengthInMicroseconds = (double)subbeatCountToNanoseconds((uint64_t)jackPlayheadBpm, 1) / 1000.0;   // :484
         jackPlayheadReturn = jackPlayhead;

@@ -57,7 +57,7 @@ for wl, loops in (("reuse", 2.0), ("noreuse", 10.0)):
                    traffic_bytes_total=traffic, algorithmic_bytes_total=alg_total, traffic_over_algorithmic=traffic / alg_total,
                    rocprof_avg_launch_us=big["avg"] / 1e3, rocprof_launches=big["n"], bench_live_avg_launch_us=live_ms * 1e3,
                    achieved_GBs_from_rocprof=alg_launch / (big["avg"] / 1e9) / 1e9, valu_busy=busy, wait_any_frac=wait, ta_busy=ta)
-    hdr = f"""# rocprofv3 summary, round 2 ({name}; written by scripts/publish_profile_r2.py from scripts/profile_r2.sh {tag}), kernel-source digest {digest}
+    hdr = f"""# rocprofv3 summary ({name}; written by scripts/publish_profile_r2.py from scripts/profile_r2.sh {tag}), kernel-source digest {digest}
 # workload: bench.py defaults (1024 stereo voices, 8 buses x 128, 256-frame blocks, 8192 blocks per call, ratio 1, linear, faithful) with
 #   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits' if wl == 'reuse' else ' -- NO source byte is re-read inside a plan window (2048 blocks = 10.9 s): every source read comes from HBM'}
 # commands (one pass each; raw CSVs condensed by scripts/summarize_prof.py; long torch kernel names cut):

@@ -553,3 +553,27 @@ def test_errors_are_reported(Engine):
     with pytest.raises(ZlHipError):
         syn.register_clip(np.zeros(1 << 20, dtype=np.float32), None, 48000.0)   # arena full
     syn.close()
+
+
+@pytest.mark.parametrize("window", [7, 64])
+def test_moving_playhead_across_plan_windows(Engine, window):
+    """beat-locked loops against a MOVING SyncTimer playhead (golden g4b: a timer that has been running for 12 000
+    cycles, start ticks that are not 0, a nextLoopTick behind the playhead -- the u64 wrap of SamplerSynthVoice.cpp:180-181,236-237 -- and
+    the edge scenes) rendered in ONE batch cut into several plan windows: every window's planner reads the playhead of its own blocks'
+    clocks (the restart block is found by bisection over clocks that each carry a different playhead).  Traced and pipelined."""
+    from golden_util import load_golden
+    from edge_scenes import SCENES
+    sc, ex = load_golden("g4b_beat_locked_moving_playhead")
+    bus, rep, syn, trace = run_backend(sc, Engine, batch=1 << 30, trace=True, plan_window_blocks=window)
+    assert np.array_equal(bus.view(np.int32), ex["bus"].view(np.int32)), f"max diff {np.abs(bus - ex['bus']).max()}"
+    assert np.array_equal(trace, ex["trace"])
+    syn.close()
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=90, pipelined=True, plan_window_blocks=window)
+    assert np.array_equal(bus.view(np.int32), ex["bus"].view(np.int32))
+    syn.close()
+    for name in ("beat_locked_moving_playhead", "beat_locked_moving_playhead_long"):
+        es = SCENES[name]()
+        ref_bus, ref_rep, ref_syn = run_oracle(es)
+        bus, rep, syn, _ = run_backend(es, Engine, batch=1 << 30, plan_window_blocks=window * 8)
+        compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, es.num_buses * es.voices_per_bus)
+        syn.close()

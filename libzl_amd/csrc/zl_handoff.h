@@ -69,7 +69,10 @@ struct ZlSnapshot {
     }
     bool take(T &out)
     {
-        if (!dirty.exchange(false, std::memory_order_acq_rel)) return false;
+        if (!dirty.load(std::memory_order_acquire)) return false;          // (a plain load first: the cycle looks at every clip, every cycle)
+        // cleared with a read-modify-write: the reads of the record below may not move in front of it (a publication that lands
+        // after the clearing sets the flag again; one that landed before is the one being read)
+        (void)dirty.exchange(false, std::memory_order_acq_rel);
         const uint32_t s1 = seq.load(std::memory_order_acquire);
         if (!(s1 & 1u)) {
             uint32_t tmp[sizeof(T) / 4];

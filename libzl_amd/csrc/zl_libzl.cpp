@@ -147,6 +147,7 @@ struct Global {
     zlhip_engine *engine = nullptr;
     int status = ZLHIP_ERR_STATE;
     std::vector<ClipAudioSource *> clips;      // createdClips, libzl.cpp:126
+    std::vector<ClipAudioSource *> byEngineClip; // engine clip id -> clip (live or parked)
     int nextClipId = 1;                        // libzl.cpp:122
     std::vector<int64_t> voicePositionId;      // per voice slot: row in its clip's positions model
     std::vector<ClipAudioSource *> voiceClip;  // per voice slot: clip being played (host view)
@@ -249,6 +250,10 @@ ClipAudioSource *make_clip(const float *L, const float *R, int length, double sr
     }
     c->id = G.nextClipId++;                                        // libzl.cpp:122-124
     G.clips.push_back(c);
+    if (c->engineClip >= 0) {
+        if ((size_t)c->engineClip >= G.byEngineClip.size()) G.byEngineClip.resize((size_t)c->engineClip + 1, nullptr);
+        G.byEngineClip[(size_t)c->engineClip] = c;
+    }
     { std::lock_guard<std::mutex> sl(c->setMu); publish_params(c); }
     apply_params(c);
     return c;
@@ -338,10 +343,9 @@ void sync_progress(ClipAudioSource *c, int64_t now, std::vector<PendingCallback>
     }
 }
 
-ClipAudioSource *clip_by_engine_id(int engineClip)
+ClipAudioSource *clip_by_engine_id(int engineClip)                 // (a table: the cycle asks once per playing voice)
 {
-    for (ClipAudioSource *c : G.clips) if (c->engineClip == engineClip) return c;
-    return nullptr;
+    return (engineClip >= 0 && (size_t)engineClip < G.byEngineClip.size()) ? G.byEngineClip[(size_t)engineClip] : nullptr;
 }
 
 PassState *pass_for(int channel)                                   // libzl.cpp:476-575 channel mapping
@@ -432,7 +436,7 @@ int render_and_report(uint32_t nframes, const zlhip_clock *clock, float *out_lef
             bool used = false;
             for (int v = 0; v < V; ++v) used = used || (G.reports[(size_t)v].playing && G.reports[(size_t)v].clip == c->engineClip);
             if (!used) {
-                if (c->engineClip >= 0) zlhip_sound_release(G.engine, c->engineClip);
+                if (c->engineClip >= 0) { zlhip_sound_release(G.engine, c->engineClip); G.byEngineClip[(size_t)c->engineClip] = nullptr; }
                 delete c;
                 G.clips.erase(G.clips.begin() + (long)i);
                 continue;
@@ -587,6 +591,7 @@ void initJuce(void)                                                 // libzl.cpp
     G.voiceClip.assign(V, nullptr);
     G.reports.assign(V, zlhip_voice_report{});
     G.requests.clear(); G.seq.reset(); G.ext.clear(); G.due.clear(); G.lastNframes = 0;
+    G.byEngineClip.clear();
     for (ClipAudioSource *c : G.clips) c->engineClip = -1;
 }
 
@@ -594,7 +599,7 @@ void shutdownJuce(void)                                             // libzl.cpp
 {
     std::lock_guard<std::mutex> lk(G.mu);
     for (ClipAudioSource *c : G.clips) delete c;
-    G.clips.clear();
+    G.clips.clear(); G.byEngineClip.clear();
     if (G.engine) { zlhip_engine_destroy(G.engine); G.engine = nullptr; }
     G.requests.clear(); G.seq.reset(); G.ext.clear(); G.due.clear();
     G.status = ZLHIP_ERR_STATE;

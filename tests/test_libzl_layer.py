@@ -544,3 +544,88 @@ def test_callbacks_may_call_back_into_the_api_and_setters_do_not_evict_the_resid
     finally:
         zl.shutdownJuce()
         zl.libzl_hotpath_set_clock_ms(libzl.CLOCK_MS())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [61, 62, 63])
+def test_random_sessions_through_the_libzl_names(zl, seed):
+    """A seeded session of everything a host does through the libzl names while audio runs -- play / stop (also twice in a cycle),
+    playOnChannel / stopOnChannel, SyncTimer_startTimer / _setBpm / _stopTimer / _queueClipToStart / _queueClipToStop, and the setters
+    (length in beats, pan, volume, start position, slices, root note, ADSR attack / release) -- against the oracle's SyncTimer + ClipAudioSource
+    setters + SamplerSynth, cycle by cycle: audio bit for bit, the transport triple, the positions-model read-outs."""
+    from libzl_amd import Clock
+    rng = np.random.default_rng(seed)
+    lib = zo.load()
+    N = int(rng.choice([64, 128, 256])); fs = 48000.0
+    per = int(round(1e6 * N / fs))
+    zl.initJuce()
+    try:
+        host = _OracleHost(N)
+        st = zo.OracleSyncTimer()
+        st.set_latency(N, fs)
+        nclips = 6
+
+        def setup(i, c, oc):
+            beats = float(rng.choice([1.0, 2.0, 0.37, 0.61]))
+            zl.ClipAudioSource_setLength(c, beats, 120); lib.zlo_clip_set_length(C.byref(oc), C.c_float(beats), 120)
+        clips = _mk_clips(zl, host, rng, nclips, setup)
+        outL = np.zeros((12, N), dtype=np.float32); outR = np.zeros((12, N), dtype=np.float32)
+        t0 = int(rng.integers(1, 5)) * 1_000_003
+        ndisp = nsound = 0
+        for k in range(260):
+            for _ in range(int(rng.integers(0, 4)) if rng.random() < 0.45 else 0):
+                i = int(rng.integers(0, nclips)); c, oid = clips[i]; oc = host.osyn.clips[oid]
+                a = int(rng.integers(0, 16))
+                if a < 4:
+                    loop = bool(rng.integers(0, 2)); ch = int(rng.choice([-2, -2, -1, 0, 3]))
+                    if ch == -2: zl.ClipAudioSource_play(c, loop)
+                    else: zl.ClipAudioSource_playOnChannel(c, loop, ch)
+                    st.schedule(host.play(oid, loop, ch), 0)
+                elif a < 6:
+                    if rng.random() < 0.5:
+                        zl.ClipAudioSource_stop(c); [st.schedule(x, 0) for x in host.stop(oid)]
+                    else:
+                        ch = int(rng.choice([-2, -1, 0, 3])); zl.ClipAudioSource_stopOnChannel(c, ch); [st.schedule(x, 0) for x in host.stop(oid, ch)]
+                elif a == 6:
+                    b = int(rng.choice([90, 120, 174])); zl.SyncTimer_startTimer(b); st.start(b)
+                elif a == 7:
+                    zl.SyncTimer_stopTimer(); st.stop()
+                elif a == 8:
+                    b = int(rng.choice([60, 120, 150, 240])); zl.SyncTimer_setBpm(b); st.set_bpm(b)
+                elif a == 9:
+                    ch = int(rng.choice([-1, 2])); zl.SyncTimer_queueClipToStartOnChannel(c, ch); st.queue_start(oid, ch)
+                elif a == 10:
+                    ch = int(rng.choice([-1, 2])); zl.SyncTimer_queueClipToStopOnChannel(c, ch); st.queue_stop(oid, ch)
+                elif a == 11:
+                    v = float(np.float32(rng.uniform(-1, 1))); zl.ClipAudioSource_setPan(c, v); lib.zlo_clip_set_pan(C.byref(oc), C.c_float(v))
+                elif a == 12:
+                    v = float(np.float32(rng.uniform(0, 1.2))); zl.ClipAudioSource_setVolumeAbsolute(c, v); lib.zlo_clip_set_volume_absolute(C.byref(oc), C.c_float(v))
+                elif a == 13:
+                    beats = float(rng.choice([1.0, 0.29, 0.53, 2.0])); zl.ClipAudioSource_setLength(c, beats, 120); lib.zlo_clip_set_length(C.byref(oc), C.c_float(beats), 120)
+                elif a == 14:
+                    v = float(np.float32(rng.uniform(0, 0.02))); zl.ClipAudioSource_setStartPosition(c, v); lib.zlo_clip_set_start_position(C.byref(oc), C.c_float(v))
+                else:
+                    if rng.random() < 0.5:
+                        v = float(np.float32(rng.choice([0.0, 0.003, 0.02]))); zl.ClipAudioSource_setADSRAttack(c, v); lib.zlo_clip_set_adsr_attack(C.byref(oc), C.c_float(v))
+                    else:
+                        v = float(np.float32(rng.choice([0.0, 0.01, 0.08]))); zl.ClipAudioSource_setADSRRelease(c, v); lib.zlo_clip_set_adsr_release(C.byref(oc), C.c_float(v))
+            cu, nx = t0 + k * per, t0 + (k + 1) * per
+            for cm, tick in st.process(N, cu, nx):
+                host.osyn.handle_clip_command(cm, tick)
+                ndisp += 1
+            oclk = st.clock(cu, nx)
+            assert zl.libzl_hotpath_cycle(N, cu, nx, float(nx - cu), outL.ctypes.data, outR.ctypes.data) == 0
+            got = Clock()
+            zl.libzl_hotpath_transport(C.byref(got))
+            assert (got.jack_playhead, got.jack_playhead_usecs, got.jack_subbeat_length_usecs) == (oclk.jackPlayhead, oclk.jackPlayheadUsecs, oclk.jackSubbeatLengthInMicroseconds), k
+            bus = host.render([oclk])
+            assert np.array_equal(outL.view(np.int32), bus[:, 0].view(np.int32)) and np.array_equal(outR.view(np.int32), bus[:, 1].view(np.int32)), (seed, k)
+            nsound += int(np.abs(bus).max() > 0)
+            if not st.t.contents.threadPaused:
+                st.timer_callback()
+        assert ndisp > 20 and nsound > 100, (ndisp, nsound)
+        st.close()
+        for c, _ in clips:
+            zl.ClipAudioSource_destroy(c)
+    finally:
+        zl.shutdownJuce()

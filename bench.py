@@ -563,7 +563,8 @@ def main():
             "output_check": {"rows_vs_oracle": check, "what": "3 random (bus, block) rows of one extra step rendered after the timed region, bit-exact against oracle/zl_oracle.c"} if check is not None else None,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, seed)
+            # the CPU leg is timed on rank 0 at N = 1 only (a reported baseline of the same workload, not part of the scaling curve)
+            out["cpu_baseline"] = cpu_baseline(args, seed) if world == 1 else None
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

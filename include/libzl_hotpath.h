@@ -128,6 +128,12 @@ int  libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *ou
  * with the clock SyncTimer's getters return (:990-1009), and, while the timer runs, the timer thread's tick
  * (hiResTimerCallback, :391-418) is taken once.  Arguments as jack_get_cycle_times returns them (SamplerSynth.cpp:128). */
 int  libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, float *out_left, float *out_right);
+/* Offline bounce of the running session to WAV files (BASELINE configs[4] from / to real files): what nblocks calls of
+ * libzl_hotpath_cycle would render -- the library's own transport, JACK time start_usecs + k * round(1e6 * nframes / fs), commands
+ * dispatched in the cycle their step falls due in -- rendered in batches through zlhip_bounce and written as one stereo WAV per sampler
+ * channel, "<prefix>-channel_<bus>.wav": bits_per_sample 16 = the recorder's format (AudioLevels.cpp:53-58), 32 = float.  The
+ * positions models and callbacks are not driven.  Returns 0 or a negative zlhip status. */
+int  libzl_hotpath_bounce_to_wav(const char *prefix, int64_t nblocks, uint32_t nframes, uint64_t start_usecs, int bits_per_sample);
 /* SyncTimer::scheduleClipCommand(command, delay) (SyncTimer.cpp:1011-1048): what ClipAudioSource_play / _stop call with delay 0;
  * command->clip is the zlhip clip id (ClipAudioSource_engineClip) */
 void libzl_hotpath_schedule_clip_command(const zlhip_clip_command *command, uint64_t delay);

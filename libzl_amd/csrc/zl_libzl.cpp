@@ -811,6 +811,82 @@ int libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_
     return rc;
 }
 
+// ---- offline bounce of the running session to WAV files (BASELINE configs[4] from / to real files) ------------------
+// What nblocks calls of libzl_hotpath_cycle would render -- the library's own transport, JACK time advancing by the nominal period
+// per cycle, commands dispatched in the cycle their step falls due in -- but rendered in batches (zlhip_bounce: the render kernel
+// writes the recorder's 16-bit format, or floats, straight into page-locked host memory) and appended to one stereo WAV per sampler
+// channel.  A batch ends where a cycle has commands to dispatch (they apply at that cycle's boundary) or at the engine's
+// max_batch_blocks.  The positions models and callbacks are not driven (no real time passes).
+int libzl_hotpath_bounce_to_wav(const char *prefix, int64_t nblocks, uint32_t nframes, uint64_t start_usecs, int bits_per_sample)
+{
+    if (!prefix || nblocks < 1 || nframes == 0 || !(bits_per_sample == 16 || bits_per_sample == 32)) return ZLHIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (!G.engine) return G.status;
+    zlhip_config cfg;
+    if (G.cfgSet) cfg = G.cfg; else { zlhip_config_default(&cfg); cfg.max_batch_blocks = 16; }
+    const int B = cfg.num_buses;
+    const double fs = cfg.playback_sample_rate;
+    const uint64_t period = (uint64_t)std::llround(1e6 * (double)nframes / fs);
+    const uint64_t totalFrames = (uint64_t)nblocks * nframes;
+    const int frameBytes = bits_per_sample == 16 ? 4 : 8;                       // stereo
+    if (totalFrames * (uint64_t)frameBytes > 0xffffffffull - 36) return ZLHIP_ERR_CAPACITY;    // RIFF sizes are 32 bit
+    const int64_t cap = std::max(1, cfg.max_batch_blocks);
+    void *host = nullptr;
+    // fp32 arrives planar per bus ([B][2][frames]) and is interleaved on the way to the file; 16 bit arrives as the file wants it
+    if (zlhip_host_alloc((size_t)B * (size_t)cap * nframes * (size_t)frameBytes, &host) != ZLHIP_OK) return ZLHIP_ERR_CAPACITY;
+    std::vector<FILE *> files((size_t)B, nullptr);
+    int rc = ZLHIP_OK;
+    for (int b = 0; b < B && rc == ZLHIP_OK; ++b) {
+        const std::string path = std::string(prefix) + "-channel_" + std::to_string(b) + ".wav";
+        files[(size_t)b] = std::fopen(path.c_str(), "wb");
+        unsigned char h[44];
+        wav_header(h, (uint32_t)totalFrames, 2, fs, bits_per_sample);
+        if (!files[(size_t)b] || std::fwrite(h, 1, 44, files[(size_t)b]) != 44) rc = ZLHIP_ERR_INVALID;
+    }
+    std::vector<zlhip_clock> clocks;
+    std::vector<float> inter;
+    auto flush = [&]() -> int {
+        const size_t n = clocks.size();
+        if (n == 0) return ZLHIP_OK;
+        const size_t frames = n * nframes;
+        int r = zlhip_bounce(G.engine, (int64_t)n, (int32_t)nframes, clocks.data(), host, bits_per_sample == 16 ? ZLHIP_BOUNCE_PCM16_STEREO : ZLHIP_BOUNCE_F32_PLANAR, 0);
+        if (r != ZLHIP_OK) return r;
+        for (int b = 0; b < B; ++b) {
+            if (bits_per_sample == 16) {
+                if (std::fwrite((const char *)host + (size_t)b * frames * 4, 1, frames * 4, files[(size_t)b]) != frames * 4) return ZLHIP_ERR_INVALID;
+            } else {
+                const float *L = (const float *)host + (size_t)b * 2 * frames, *R = L + frames;
+                inter.resize(frames * 2);
+                for (size_t i = 0; i < frames; ++i) { inter[2 * i] = L[i]; inter[2 * i + 1] = R[i]; }
+                if (std::fwrite(inter.data(), 1, frames * 8, files[(size_t)b]) != frames * 8) return ZLHIP_ERR_INVALID;
+            }
+        }
+        clocks.clear();
+        return ZLHIP_OK;
+    };
+    if (nframes != G.lastNframes) { G.seq.set_jack_latency(nframes, fs); G.lastNframes = nframes; }
+    drain_requests(true);
+    for (ClipAudioSource *c : G.clips) if (c->id >= 0) apply_params(c);
+    for (int64_t k = 0; k < nblocks && rc == ZLHIP_OK; ++k) {
+        const uint64_t cu = start_usecs + (uint64_t)k * period, nx = cu + period;
+        G.seq.process(nframes, cu, nx, (float)period, G.due);
+        if (!G.due.empty() || (int64_t)clocks.size() == cap) {
+            rc = flush();                                                            // the blocks before this cycle's commands
+            if (rc == ZLHIP_OK) rc = dispatch_due();
+        }
+        zlhip_clock clk;
+        clk.current_usecs = cu; clk.next_usecs = nx;
+        clk.jack_playhead = G.seq.jackPlayheadGetter(); clk.jack_playhead_usecs = G.seq.jackPlayheadUsecsGetter();
+        clk.jack_subbeat_length_usecs = G.seq.jackSubbeatLengthInMicroseconds;
+        clocks.push_back(clk);
+        if (!G.seq.threadPaused) G.seq.hi_res_timer_callback();
+    }
+    if (rc == ZLHIP_OK) rc = flush();
+    for (FILE *f : files) if (f && std::fclose(f) != 0 && rc == ZLHIP_OK) rc = ZLHIP_ERR_INVALID;
+    zlhip_host_free(host);
+    return rc;
+}
+
 // ---- JackPassthrough bridge (libzl.cpp:476-575) ------------------------------------------------------------
 void  JackPassthrough_setPanAmount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->pan = amount; }
 float JackPassthrough_getPanAmount(int channel) { PassState *p = pass_for(channel); return p ? p->pan : 0.0f; }

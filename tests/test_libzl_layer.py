@@ -629,3 +629,84 @@ def test_random_sessions_through_the_libzl_names(zl, seed):
             zl.ClipAudioSource_destroy(c)
     finally:
         zl.shutdownJuce()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [16, 32])
+def test_offline_bounce_of_a_session_to_wav_files(zl, tmp_path, bits):
+    """SURVEY 8f n3, BASELINE configs[4] 'from / to real files': clips loaded from WAV files, a running SyncTimer, commands that fall
+    due in the middle of the bounce (one scheduled 40 steps ahead, a queued bar-aligned start), then libzl_hotpath_bounce_to_wav --
+    one stereo WAV per sampler channel.  Every file equals the oracle's cycle-by-cycle rendering of the same session: as floats bit
+    for bit, as 16 bit through the oracle's recorder conversion (zlo_pcm16_stereo)."""
+    from libzl_amd import _abi
+    from scenario import engine_cmd
+    rng = np.random.default_rng(71)
+    lib = zo.load()
+    N, fs, K = 128, 48000.0, 800        # 2.13 s: the bar-aligned start (384 steps of 5208 us ahead) falls inside
+    per = int(round(1e6 * N / fs))
+    cfg = _abi.Config()
+    _abi.bind(zl)
+    zl.zlhip_config_default(C.byref(cfg))
+    cfg.max_batch_blocks = 64; cfg.max_frames = 256
+    zl.libzl_hotpath_configure(C.byref(cfg))
+    zl.initJuce()
+    try:
+        host = _OracleHost(N)
+        st = zo.OracleSyncTimer()
+        st.set_latency(N, fs)
+        clips = []
+        for i in range(4):
+            ln = 6000 + 700 * i
+            # 16-bit files: what a host loads; the oracle gets the decoded planes
+            L = (rng.uniform(-1, 1, ln) * 0.9).astype(np.float32); R = (rng.uniform(-1, 1, ln) * 0.9).astype(np.float32) if i % 2 == 0 else None
+            path = _wav(tmp_path, zl, L, R, fs, 16, f"src{i}.wav")
+            dL, dR, _ = _read(zl, path)
+            c = zl.ClipAudioSource_new(path, False)
+            assert c
+            oid = host.osyn.register_clip(dL, dR, fs)
+            oc = host.osyn.clips[oid]
+            beats = [1.0, 0.43, 2.0, 0.31][i]
+            zl.ClipAudioSource_setLength(c, beats, 120); lib.zlo_clip_set_length(C.byref(oc), C.c_float(beats), 120)
+            zl.ClipAudioSource_setPan(c, 0.2 * i - 0.3); lib.zlo_clip_set_pan(C.byref(oc), C.c_float(0.2 * i - 0.3))
+            clips.append((c, oid))
+        t0 = 9_000_011
+        zl.SyncTimer_startTimer(120); st.start(120)
+        zl.ClipAudioSource_play(clips[0][0], True); st.schedule(host.play(clips[0][1], True), 0)
+        zl.ClipAudioSource_playOnChannel(clips[1][0], True, 1); st.schedule(host.play(clips[1][1], True, 1), 0)
+        late = host.play(clips[2][1], False, 2)                                       # a one-shot 40 steps from now
+        zl.libzl_hotpath_schedule_clip_command(C.byref(engine_cmd(**{f: getattr(late, f) for f in zo.CMD_FIELDS})), 40); st.schedule(late, 40)
+        zl.SyncTimer_queueClipToStartOnChannel(clips[3][0], 0); st.queue_start(clips[3][1], 0)      # at the next bar
+        prefix = str(tmp_path / f"bounce{bits}").encode()
+        assert zl.libzl_hotpath_bounce_to_wav(prefix, K, N, t0, bits) == 0
+        want = np.zeros((12, 2, K * N), dtype=np.float32)
+        ndisp = 0
+        for k in range(K):
+            cu, nx = t0 + k * per, t0 + (k + 1) * per
+            for cm, tick in st.process(N, cu, nx):
+                host.osyn.handle_clip_command(cm, tick)
+                ndisp += 1
+            want[:, :, k * N:(k + 1) * N] = host.render([st.clock(cu, nx)])
+            if not st.t.contents.threadPaused:
+                st.timer_callback()
+        assert ndisp == 4
+        heard = 0
+        for b in range(12):
+            raw = open(prefix.decode() + f"-channel_{b}.wav", "rb").read()
+            assert raw[:4] == b"RIFF" and len(raw) == 44 + K * N * 2 * (2 if bits == 16 else 4)
+            if bits == 16:
+                got = np.frombuffer(raw[44:], dtype=np.int16).reshape(-1, 2)
+                exp = np.empty((K * N, 2), dtype=np.int16)
+                Lr, Rr = np.ascontiguousarray(want[b, 0]), np.ascontiguousarray(want[b, 1])
+                lib.zlo_pcm16_stereo(Lr.ctypes.data, Rr.ctypes.data, K * N, exp.ctypes.data)
+                assert np.array_equal(got, exp), b
+            else:
+                got = np.frombuffer(raw[44:], dtype=np.float32).reshape(-1, 2)
+                assert np.array_equal(got[:, 0].view(np.int32), want[b, 0].view(np.int32)) and np.array_equal(got[:, 1].view(np.int32), want[b, 1].view(np.int32)), b
+            heard += int(np.abs(want[b]).max() > 0)
+        assert heard == 4                                                             # channels -2, 1, 2, 0 carry sound
+        st.close()
+        for c, _ in clips:
+            zl.ClipAudioSource_destroy(c)
+    finally:
+        zl.shutdownJuce()
+        zl.libzl_hotpath_configure(None)

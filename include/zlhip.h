@@ -77,6 +77,10 @@ typedef struct zlhip_config {
                                         without a cycle before it leaves (it is started again by the next cycle); 0 = 200 000.
                                         A host that makes device-synchronising HIP calls of its own (hipFree, hipDeviceSynchronize)
                                         waits at most this long behind an idle engine; calls made through this library do not wait. */
+    uint64_t sound_arena_max_bytes;  /* (ABI 2) sound_arena_bytes is what the engine reserves at creation; when a source no longer fits it
+                                        allocates further segments of at least that size, up to this total (0 = no limit but the
+                                        device's memory; = sound_arena_bytes: a fixed arena, uploads beyond it fail with
+                                        ZLHIP_ERR_CAPACITY until clips are released) */
 } zlhip_config;
 
 /* clock inputs of one block: JACK cycle times + SyncTimer playhead getters

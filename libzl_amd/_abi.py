@@ -30,7 +30,7 @@ class Config(C.Structure):
         ("voices_per_bus", C.c_int32), ("max_frames", C.c_int32), ("max_batch_blocks", C.c_int32),
         ("max_sounds", C.c_int32), ("mode", C.c_uint32), ("playback_sample_rate", C.c_double),
         ("sound_arena_bytes", C.c_uint64), ("voices_per_task", C.c_int32), ("plan_window_blocks", C.c_int32),
-        ("rt_idle_timeout_us", C.c_int32),
+        ("rt_idle_timeout_us", C.c_int32), ("sound_arena_max_bytes", C.c_uint64),
     ]
 
 

@@ -66,6 +66,11 @@ struct zlhip_engine {
     // arena allocator: free extents (offset, floats), sorted by offset, neighbours coalesced on release -- clips are
     // loaded and destroyed freely (SamplerSynth::registerClip / unregisterClip, SamplerSynth.cpp:285-312)
     std::vector<std::pair<size_t, size_t>> arenaFree;
+    // further arena segments, allocated when a source does not fit any more (clips are loaded freely; 288 GB of HBM): a source in
+    // one of them is addressed like any other, by its float offset from `arena` -- taken modulo 2^64, so a segment below the first
+    // one in the address space has a "negative" offset that the kernels' 64-bit address arithmetic wraps back
+    std::vector<float *> arenaSegments;
+    size_t arenaSegmentFloats = 0;       // floats in those segments (zlhip_memory_bytes)
     std::vector<size_t> soundFloats;     // per sound slot: floats it holds in the arena
     ZlSound *dSounds = nullptr; ZlClip *dClips = nullptr;
     ZlVoiceState *dVoices = nullptr;
@@ -312,6 +317,7 @@ void zlhip_config_default(zlhip_config *cfg)
     cfg->sound_arena_bytes = 256ull << 20;
     cfg->voices_per_task = 0;
     cfg->rt_idle_timeout_us = 0;     // 200 ms
+    cfg->sound_arena_max_bytes = 0;  // the arena grows in segments as clips are loaded
 }
 
 void zlhip_engine_destroy(zlhip_engine *e)
@@ -334,6 +340,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->planStream) (void)hipStreamSynchronize(e->planStream);
     if (e->asmStream) (void)hipStreamSynchronize(e->asmStream);
+    for (float *seg : e->arenaSegments) if (seg) (void)hipFree(seg);
     void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dTrace, e->dPass, e->dPassCache };
     for (void *p : dev) if (p) (void)hipFree(p);
     for (auto &q : e->ps) {
@@ -600,7 +607,24 @@ static int alloc_sound_slot(zlhip_engine *e, int32_t length, int channels, doubl
             break;
         }
     }
-    if (off == (size_t)-1) return fail(e, ZLHIP_ERR_CAPACITY, "sound arena full");
+    if (off == (size_t)-1) {
+        // no extent holds it: one more arena segment, at least as large as the first one (and as the source)
+        const size_t segFloats = (std::max(floats, e->arenaFloats) + 3) & ~(size_t)3;
+        if (e->cfg.sound_arena_max_bytes > 0 && (e->arenaFloats + e->arenaSegmentFloats + segFloats) * sizeof(float) > e->cfg.sound_arena_max_bytes)
+            return fail(e, ZLHIP_ERR_CAPACITY, "sound arena full");
+        float *seg = nullptr;
+        if (hipMalloc((void **)&seg, (segFloats + 1024) * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fail(e, ZLHIP_ERR_CAPACITY, "sound arena full (no memory for another segment)"); }
+        e->arenaSegments.push_back(seg);
+        e->arenaSegmentFloats += segFloats;
+        e->deviceBytes += (segFloats + 1024) * sizeof(float);
+        // float offset of the segment from `arena`, modulo 2^64 (exact: both are multiples of 4 bytes)
+        const int64_t diffBytes = (int64_t)((uintptr_t)seg - (uintptr_t)e->arena);
+        off = (size_t)(uint64_t)(diffBytes / 4);
+        if (segFloats > floats) {
+            const std::pair<size_t, size_t> rest(off + floats, segFloats - floats);
+            e->arenaFree.insert(std::lower_bound(e->arenaFree.begin(), e->arenaFree.end(), rest), rest);
+        }
+    }
     ZlSound s; s.offset = off; s.length = length; s.channels = channels; s.sample_rate = sample_rate;
     *dst = e->arena + off;
     e->hc.sounds[id] = s;
@@ -1652,7 +1676,7 @@ int zlhip_memory_bytes(zlhip_engine *e, uint64_t *total_device_bytes, uint64_t *
 {
     if (!e) return ZLHIP_ERR_INVALID;
     if (total_device_bytes) *total_device_bytes = (uint64_t)e->deviceBytes;
-    if (arena_bytes) *arena_bytes = (uint64_t)e->arenaFloats * sizeof(float);
+    if (arena_bytes) *arena_bytes = (uint64_t)(e->arenaFloats + e->arenaSegmentFloats) * sizeof(float);
     return ZLHIP_OK;
 }
 

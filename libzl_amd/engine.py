@@ -99,7 +99,8 @@ class SamplerSynth:
     def __init__(self, num_buses: int = 12, voices_per_bus: int = 8, *, max_frames: int = 1024,
                  max_batch_blocks: int = 64, max_sounds: int = 1024, mode: int = MODE_FAITHFUL,
                  playback_sample_rate: float = 48000.0, sound_arena_bytes: int = 256 << 20,
-                 voices_per_task: int = 0, plan_window_blocks: int = 0, device: int = 0, rt_idle_timeout_us: int = 0):
+                 voices_per_task: int = 0, plan_window_blocks: int = 0, device: int = 0, rt_idle_timeout_us: int = 0,
+                 sound_arena_max_bytes: int = 0):
         self._lib = _abi.load()
         cfg = Config()
         self._lib.zlhip_config_default(C.byref(cfg))
@@ -115,6 +116,7 @@ class SamplerSynth:
         cfg.voices_per_task = voices_per_task
         cfg.plan_window_blocks = plan_window_blocks
         cfg.rt_idle_timeout_us = rt_idle_timeout_us
+        cfg.sound_arena_max_bytes = sound_arena_max_bytes
         self.cfg = cfg
         self._e = C.c_void_p()
         rc = self._lib.zlhip_engine_create(C.byref(cfg), C.byref(self._e))

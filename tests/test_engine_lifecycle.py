@@ -28,7 +28,7 @@ def test_arena_space_is_reused_after_release(Engine):
     from oracle import zl_oracle as zo
     rng = np.random.default_rng(3)
     arena = 1 << 20                                                       # 1 MiB = 131072 stereo frames
-    syn = Engine(2, 4, max_frames=128, max_batch_blocks=4, max_sounds=16, sound_arena_bytes=arena)
+    syn = Engine(2, 4, max_frames=128, max_batch_blocks=4, max_sounds=16, sound_arena_bytes=arena, sound_arena_max_bytes=arena)   # a FIXED arena
     live = []
     total = 0
     for i in range(60):
@@ -68,7 +68,7 @@ def test_arena_space_is_reused_after_release(Engine):
 def test_failed_upload_keeps_neither_slot_nor_space(Engine):
     from libzl_amd import ZlHipError
     rng = np.random.default_rng(4)
-    syn = Engine(1, 2, max_frames=64, max_batch_blocks=1, max_sounds=4, sound_arena_bytes=1 << 16)
+    syn = Engine(1, 2, max_frames=64, max_batch_blocks=1, max_sounds=4, sound_arena_bytes=1 << 16, sound_arena_max_bytes=1 << 16)
     L, R = rand_source(rng, 100000, stereo=True)                          # 800 KB into a 64 KB arena
     for _ in range(8):                                                    # more failures than sound slots
         with pytest.raises(ZlHipError):
@@ -265,3 +265,54 @@ def test_peak_conversion_of_non_finite_and_huge_samples(Engine):
     assert np.array_equal(got, want)
     assert want.max() == 2147483647 and (want == 0).sum() == 0
     syn.close()
+
+
+
+def test_the_source_arena_grows_in_segments(Engine):
+    """Clips are loaded freely (SamplerSynth::registerClip has no budget, SamplerSynth.cpp:285-295): when a source does not fit the
+    arena reserved at creation the engine allocates another segment; sources in later segments (wherever the allocator put them in
+    the address space) render the same bits as the oracle; released extents of every segment are reused; a cap makes loading fail."""
+    from libzl_amd import ZlHipError, clip_command
+    from libzl_amd.engine import synthetic_clocks
+    from oracle import zl_oracle as zo
+    rng = np.random.default_rng(11)
+    arena = 1 << 20
+    syn = Engine(2, 8, max_frames=128, max_batch_blocks=8, max_sounds=32, sound_arena_bytes=arena)
+    osyn = zo.OracleSynth(2, 8, 48000.0, 0, max_sounds=32)
+    total0, a0 = syn.memory_bytes()
+    assert a0 == arena
+    clips = []
+    for i in range(12):
+        n = int(rng.integers(50000, 70000)) if i != 7 else 400000          # 400-560 KB each; one source of 3.2 MB (larger than a segment)
+        L, R = rand_source(rng, n, stereo=(i % 4 != 1))
+        cid = syn.register_clip(L, R, [48000.0, 44100.0][i % 2])
+        oid = osyn.register_clip(L, R, [48000.0, 44100.0][i % 2])
+        assert cid == oid == i
+        p = syn.default_clip_params(n / [48000.0, 44100.0][i % 2]); p.length_in_beats = 0.41; p.length_seconds = float(np.float32(0.02 + 0.003 * i)); p.pan = 0.1 * i - 0.5
+        syn.set_clip_params(cid, p)
+        oc = osyn.clips[oid]; oc.lengthInBeats = 0.41; oc.lengthInSeconds = float(np.float32(0.02 + 0.003 * i)); oc.pan = float(np.float32(0.1 * i - 0.5))
+        clips.append((L, R))
+    total1, a1 = syn.memory_bytes()
+    assert a1 >= 6 * arena and total1 - total0 >= a1 - a0
+    for i in range(12):
+        f = dict(clip=i, midi_note=57 + i, midi_channel=(i % 2) - 2, start_playback=1, looping=1, change_volume=1, volume=0.5 + 0.03 * i)
+        assert syn.handle_clip_command(clip_command(**f), 0) == 1
+        osyn.handle_clip_command(zo.clip_command(clip=i, midiNote=57 + i, midiChannel=(i % 2) - 2, startPlayback=1, looping=1, changeVolume=1, volume=0.5 + 0.03 * i), 0)
+    clk = synthetic_clocks(8, 128, 48000.0)
+    syn.render_batch(8, 128, clk)
+    ref, _ = osyn.render_batch(8, 128, clk)
+    assert np.array_equal(syn.read_bus().view(np.int32), ref.view(np.int32)) and np.abs(ref).max() > 0.5
+    # real-time cycles from the same sources (the resident kernel addresses them the same way)
+    L1, R1 = syn.process(128, synthetic_clocks(1, 128, 48000.0, start_block=8)[0])
+    ref1, _ = osyn.render_batch(1, 128, synthetic_clocks(1, 128, 48000.0, start_block=8))
+    assert np.array_equal(L1.view(np.int32), ref1[:, 0].view(np.int32)) and np.array_equal(R1.view(np.int32), ref1[:, 1].view(np.int32))
+    syn.close()
+    # capped: the same uploads stop fitting
+    cap = Engine(2, 8, max_frames=128, max_batch_blocks=8, max_sounds=32, sound_arena_bytes=arena, sound_arena_max_bytes=3 * arena)
+    ok = 0
+    with pytest.raises(ZlHipError):
+        for L, R in clips:
+            cap.register_clip(L, R, 48000.0)
+            ok += 1
+    assert 2 <= ok <= 7
+    cap.close()

@@ -545,7 +545,7 @@ def test_real_time_blocks_of_wide_buses_are_split_per_voice(Engine, nframes):
 def test_errors_are_reported(Engine):
     from libzl_amd import ZlHipError
     from libzl_amd.engine import synthetic_clocks
-    syn = Engine(2, 4, max_frames=128, max_batch_blocks=2, max_sounds=2, sound_arena_bytes=1 << 16)
+    syn = Engine(2, 4, max_frames=128, max_batch_blocks=2, max_sounds=2, sound_arena_bytes=1 << 16, sound_arena_max_bytes=1 << 16)   # a fixed arena
     with pytest.raises(ZlHipError):
         syn.render_batch(3, 128, synthetic_clocks(3, 128, 48000.0))        # more blocks than max_batch_blocks
     with pytest.raises(ZlHipError):

@@ -175,6 +175,12 @@ class SamplerSynth:
         self._ck(self._lib.zlhip_sound_upload_device(self._e, left_ptr, right_ptr, length, float(sample_rate), C.byref(out)), "sound_upload_device")
         return out.value
 
+    def register_clip_device_on(self, left_ptr: int, right_ptr: Optional[int], length: int, sample_rate: float, producer_stream: Optional[int]) -> int:
+        """register_clip_device with the HIP stream the planes were produced on: the engine waits for that stream (an event), not for the device."""
+        out = C.c_int32(-1)
+        self._ck(self._lib.zlhip_sound_upload_device_on(self._e, left_ptr, right_ptr, length, float(sample_rate), producer_stream, C.byref(out)), "sound_upload_device_on")
+        return out.value
+
     def unregister_clip(self, clip: int):
         self._ck(self._lib.zlhip_sound_release(self._e, clip), "sound_release")
 

@@ -316,3 +316,34 @@ def test_the_source_arena_grows_in_segments(Engine):
             ok += 1
     assert 2 <= ok <= 7
     cap.close()
+
+
+
+def test_device_upload_behind_the_producers_stream(Engine):
+    """zlhip_sound_upload_device_on: source planes produced on a side stream (a long chain of kernels) are uploaded with that stream
+    as the only thing waited for -- no device-wide wait -- and the engine reads the finished planes: the render equals the oracle's
+    on the same data."""
+    import torch
+    from libzl_amd import clip_command
+    from libzl_amd.engine import synthetic_clocks
+    from oracle import zl_oracle as zo
+    n = 200_000
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.Generator(device="cuda"); g.manual_seed(5)
+        x = torch.rand((2, n), generator=g, device="cuda") * 2 - 1
+        for _ in range(200):                       # keep the producer busy: the planes are final only at the end of the chain
+            x = torch.roll(x, 1, dims=1) * 0.999
+    syn = Engine(1, 2, max_frames=128, max_batch_blocks=4, max_sounds=2, sound_arena_bytes=(n + 64) * 8)
+    cid = syn.register_clip_device_on(x[0].data_ptr(), x[1].data_ptr(), n, 48000.0, side.cuda_stream)
+    side.synchronize()
+    h = x.cpu().numpy()
+    osyn = zo.OracleSynth(1, 2, 48000.0, 0, max_sounds=2)
+    oid = osyn.register_clip(np.ascontiguousarray(h[0]), np.ascontiguousarray(h[1]), 48000.0)
+    syn.handle_clip_command(clip_command(clip=cid, midi_note=60, midi_channel=-2, start_playback=1, looping=1, change_volume=1, volume=0.9), 0)
+    osyn.handle_clip_command(zo.clip_command(clip=oid, midiNote=60, midiChannel=-2, startPlayback=1, looping=1, changeVolume=1, volume=0.9), 0)
+    clk = synthetic_clocks(4, 128, 48000.0)
+    syn.render_batch(4, 128, clk)
+    ref, _ = osyn.render_batch(4, 128, clk)
+    assert np.array_equal(syn.read_bus().view(np.int32), ref.view(np.int32)) and np.abs(ref).max() > 0.1
+    syn.close()

@@ -74,12 +74,14 @@ float ClipAudioSource_adsrRelease(ClipAudioSource *c);                          
 void ClipAudioSource_setADSRRelease(ClipAudioSource *c, float newValue);                /* libzl.h:61 */
 
 /* ---- SyncTimer API bridge, the part that schedules ClipCommands (libzl.h:69-79, libzl.cpp:311-349) ----
- * Served by the step ring of libzl_hotpath_cycle.  SyncTimer_instance and the timer-callback registration belong to the
- * reference's timer thread / Qt object and are not declared here. */
+ * Served by the step ring of libzl_hotpath_cycle; the registered timer callbacks fire on the cycle's thread after each cycle, once per
+ * tick the timer went through.  SyncTimer_instance returns the reference's Qt object and is not declared here. */
 void SyncTimer_startTimer(int interval);                                                /* libzl.h:70: SyncTimer::start(bpm), SyncTimer.cpp:870-879 */
 void SyncTimer_setBpm(unsigned int bpm);                                                /* libzl.h:71, SyncTimer.cpp:954-975 */
 int  SyncTimer_getMultiplier(void);                                                     /* libzl.h:72, SyncTimer.cpp:946-948 */
 void SyncTimer_stopTimer(void);                                                         /* libzl.h:73, SyncTimer.cpp:881-925 */
+void SyncTimer_registerTimerCallback(void (*functionPtr)(int));                         /* libzl.h:74, SyncTimer.cpp:790-794: functionPtr(beat) per timer tick */
+void SyncTimer_deregisterTimerCallback(void (*functionPtr)(int));                       /* libzl.h:75, SyncTimer.cpp:796-812 */
 void SyncTimer_queueClipToStart(ClipAudioSource *clip);                                 /* libzl.h:76 */
 void SyncTimer_queueClipToStartOnChannel(ClipAudioSource *clip, int midiChannel);       /* libzl.h:77, SyncTimer.cpp:815-832 */
 void SyncTimer_queueClipToStop(ClipAudioSource *clip);                                  /* libzl.h:78 */

@@ -159,6 +159,9 @@ struct Global {
     std::vector<zlhip_clip_command> dueBatch;
     uint32_t lastNframes = 0;
     std::atomic<uint64_t> dropped{0};          // requests lost to a full queue
+    std::mutex cbMu;                           // SyncTimer::addCallback / removeCallback (SyncTimer.cpp:790-812): ticks for the host's sequencer
+    void (*timerCallbacks[16])(int) = {};      // CallbackSpaces, SyncTimer.cpp:249
+    std::vector<int> beats;                    // beats the timer ticked through in this cycle (hiResTimerCallback, :397-399)
     PassState pass[11];                        // [0] GlobalPlayback (channel -1), [1..10] channels 0..9 (MidiRouter.cpp:876-883)
 } G;
 
@@ -388,7 +391,7 @@ void drain_requests(bool internalTransport)
         case Request::TimerStart: if (internalTransport) G.seq.start(r.a); break;
         case Request::TimerStop:  if (internalTransport) G.seq.stop(); break;
         case Request::SetBpm:     if (internalTransport) G.seq.setBpm((uint64_t)(uint32_t)r.a); break;
-        case Request::TimerTick:  if (internalTransport) G.seq.hi_res_timer_callback(); break;
+        case Request::TimerTick:  if (internalTransport) { G.seq.beatSink = &G.beats; G.seq.hi_res_timer_callback(); } break;
         }
     }
 }
@@ -739,6 +742,19 @@ void SyncTimer_queueClipToStartOnChannel(ClipAudioSource *clip, int midiChannel)
 void SyncTimer_queueClipToStopOnChannel(ClipAudioSource *clip, int midiChannel) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::QueueStop; r.a = clip->engineClip; r.b = midiChannel; post(r); }
 void SyncTimer_queueClipToStart(ClipAudioSource *clip) { SyncTimer_queueClipToStartOnChannel(clip, -1); }   // SyncTimer.cpp:862-864
 void SyncTimer_queueClipToStop(ClipAudioSource *clip) { SyncTimer_queueClipToStopOnChannel(clip, -1); }     // :866-868
+// SyncTimer::addCallback / removeCallback (SyncTimer.cpp:790-812).  The reference calls callbacks[i](beat) from its timer thread for every
+// tick of cumulativeBeat; here they fire on the cycle's thread after the cycle (libzl_hotpath_cycle), once per tick the timer went
+// through.  (The reference's removeCallback leaves a null entry and drops the callback behind it; here the entry is simply removed.)
+void SyncTimer_registerTimerCallback(void (*functionPtr)(int))
+{
+    std::lock_guard<std::mutex> lk(G.cbMu);
+    for (auto &cb : G.timerCallbacks) if (!cb) { cb = functionPtr; return; }
+}
+void SyncTimer_deregisterTimerCallback(void (*functionPtr)(int))
+{
+    std::lock_guard<std::mutex> lk(G.cbMu);
+    for (auto &cb : G.timerCallbacks) if (cb == functionPtr) cb = nullptr;
+}
 void libzl_hotpath_schedule_clip_command(const zlhip_clip_command *command, uint64_t delay) { if (command) schedule_command(*command, delay); }
 void libzl_hotpath_timer_tick(void) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::TimerTick; post(r); }
 
@@ -786,6 +802,7 @@ int libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out
 int libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, float *out_left, float *out_right)
 {
     static thread_local std::vector<PendingCallback> cbs;
+    static thread_local std::vector<int> beats;
     int rc;
     {
         std::lock_guard<std::mutex> lk(G.mu);
@@ -805,9 +822,17 @@ int libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_
             rc = render_and_report(nframes, &clk, out_left, out_right, cbs);
         }
         // the timer thread ticks once per subbeat while it runs (SyncTimer.cpp:117-163): modelled as one tick between two cycles
+        G.seq.beatSink = &G.beats;
         if (!G.seq.threadPaused) G.seq.hi_res_timer_callback();
+        beats.swap(G.beats);
     }
     fire(cbs);
+    if (!beats.empty()) {
+        void (*tcb[16])(int);
+        { std::lock_guard<std::mutex> cl(G.cbMu); std::memcpy(tcb, G.timerCallbacks, sizeof tcb); }
+        for (int b : beats) for (auto cb : tcb) if (cb) cb(b);
+        beats.clear();
+    }
     return rc;
 }
 

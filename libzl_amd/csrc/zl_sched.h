@@ -206,9 +206,11 @@ struct ZlStepSequencer {
     }
 
     // the clock's tick: the timer thread calls this once per subbeat interval while it runs (:391-418)
+    std::vector<int> *beatSink = nullptr;                     // where the registered timer callbacks' argument goes (callbacks[i](beat), :397-399)
     void hi_res_timer_callback()
     {
         while (cumulativeBeat < (jackPlayhead + (scheduleAheadAmount * 2))) {
+            if (beatSink) beatSink->push_back(beat);
             beat = (beat + 1) % (int)(BeatSubdivisions * 4);
             ++cumulativeBeat;
         }

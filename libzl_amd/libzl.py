@@ -10,6 +10,7 @@ from ._abi import Clock, PassthroughParams
 _P = C.c_void_p
 CB = C.CFUNCTYPE(None, C.c_float)
 CLOCK_MS = C.CFUNCTYPE(C.c_int64)
+TIMER_CB = C.CFUNCTYPE(None, C.c_int)
 
 SIGNATURES = {
     "ClipAudioSource_byID": (_P, [C.c_int]),
@@ -50,6 +51,8 @@ SIGNATURES = {
     "SyncTimer_startTimer": (None, [C.c_int]),
     "SyncTimer_setBpm": (None, [C.c_uint]),
     "SyncTimer_stopTimer": (None, []),
+    "SyncTimer_registerTimerCallback": (None, [TIMER_CB]),
+    "SyncTimer_deregisterTimerCallback": (None, [TIMER_CB]),
     "SyncTimer_queueClipToStart": (None, [_P]),
     "SyncTimer_queueClipToStartOnChannel": (None, [_P, C.c_int]),
     "SyncTimer_queueClipToStop": (None, [_P]),

@@ -449,6 +449,10 @@ def test_the_librarys_own_transport_matches_the_oracle_sync_timer(zl):
         outL = np.zeros((12, N), dtype=np.float32); outR = np.zeros((12, N), dtype=np.float32)
         t0 = 3_000_017
         ndisp = 0
+        from libzl_amd import libzl
+        got_beats, want_beats = [], []
+        tcb = libzl.TIMER_CB(lambda b: got_beats.append(b))               # SyncTimer_registerTimerCallback: the host sequencer's tick
+        zl.SyncTimer_registerTimerCallback(tcb)
         for k in range(420):
             if k == 2:
                 zl.ClipAudioSource_play(clips[0][0], True); st.schedule(host.play(clips[0][1], True), 0)
@@ -479,8 +483,14 @@ def test_the_librarys_own_transport_matches_the_oracle_sync_timer(zl):
             bus = host.render([oclk])
             assert np.array_equal(outL.view(np.int32), bus[:, 0].view(np.int32)) and np.array_equal(outR.view(np.int32), bus[:, 1].view(np.int32)), k
             if not st.t.contents.threadPaused:
+                b0, c0 = st.t.contents.beat, st.t.contents.cumulativeBeat
                 st.timer_callback()
+                want_beats += [(b0 + i) % 384 for i in range(st.t.contents.cumulativeBeat - c0)]      # callbacks[i](beat) per tick, SyncTimer.cpp:395-405
+            if k == 200:
+                zl.SyncTimer_deregisterTimerCallback(tcb)
+                n200 = len(want_beats)
         assert ndisp >= 6 and host.voices_playing(clips[0][1]) >= 1
+        assert got_beats == want_beats[:n200] and len(got_beats) > 150
         st.close()
         for c, _ in clips:
             zl.ClipAudioSource_destroy(c)

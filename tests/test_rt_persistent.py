@@ -1,6 +1,6 @@
 """GPU tier: zlhip_render through the resident real-time kernel (the default for narrow buses; ZL_RT_PERSISTENT=0 disables it) -- the same bits as the launched
-path, block by block, across commands, idle spells (the kernel leaves and is started again), block-size changes, parameter edits
-and batch calls in between (which stop the kernel)."""
+path, block by block, across commands and parameter edits (applied by the resident kernel itself), idle spells (the kernel leaves and is
+started again), block-size changes, batch calls in between (which stop the kernel) and device-wide waits of other engines."""
 import ctypes as C
 import os
 import time
@@ -48,11 +48,11 @@ def _play_blockwise(sc, *, pause_at=(), batch_at=(), edit_at=()):
                 syn.start_voice(ev[1], ev[2], engine_cmd(**ev[3]), ev[4])
             elif ev[0] == "clip":
                 ev[2](ref.lib, ref.clips[ev[1]])
-                syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))      # stops the resident kernel; the next cycle restarts it
+                syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))      # host-only: the resident kernel applies the edit at the next cycle
         if k in pause_at:
             time.sleep(0.35)                                                    # longer than the kernel's idle timeout (200 ms)
         if k in edit_at:
-            syn.set_clip_params(0, snapshot_clip(ref.clips[0]))                 # same parameters again: only the stop / restart matters
+            syn.set_clip_params(0, snapshot_clip(ref.clips[0]))                 # the same parameters again: an edit that changes nothing
         L, R = syn.process(N, sc.make_clocks(k, 1)[0])
         out[:, 0, k * N:(k + 1) * N] = L
         out[:, 1, k * N:(k + 1) * N] = R

@@ -16,11 +16,26 @@
 
 using clk = std::chrono::steady_clock;
 
-static void run(const char *label, std::vector<ClipAudioSource *> &clips, int cycles, int nframes, double fs, bool setter, uint64_t &block)
+static void run(const char *label, std::vector<ClipAudioSource *> &clips, int cycles, int nframes, double fs, bool setter, uint64_t &block, bool commands = false)
 {
     std::atomic<bool> stop{false};
     std::atomic<long> edits{0};
-    std::thread th;
+    std::thread th, th2;
+    if (commands) {
+        // a second caller thread: retriggers and stops clips 50 times a second through the request queue
+        th2 = std::thread([&] {
+            auto next = clk::now();
+            long i = 0;
+            while (!stop.load(std::memory_order_relaxed)) {
+                next += std::chrono::microseconds(20000);
+                std::this_thread::sleep_until(next);
+                ClipAudioSource *c = clips[(size_t)((i * 7) % (long)clips.size())];
+                if (i % 3 == 2) ClipAudioSource_stopOnChannel(c, (int)((i * 7) % (long)clips.size()) / 8 - 2);
+                else ClipAudioSource_playOnChannel(c, true, (int)((i * 7) % (long)clips.size()) / 8 - 2);
+                ++i;
+            }
+        });
+    }
     if (setter) {
         th = std::thread([&] {
             auto next = clk::now();
@@ -53,6 +68,7 @@ static void run(const char *label, std::vector<ClipAudioSource *> &clips, int cy
     }
     stop.store(true);
     if (th.joinable()) th.join();
+    if (th2.joinable()) th2.join();
     std::sort(us.begin(), us.end());
     uint64_t starts = 0, cyc = 0;
     zlhip_rt_stats(libzl_hotpath_engine(), &starts, &cyc);
@@ -84,6 +100,7 @@ int main(int argc, char **argv)
         run("quiet", clips, cycles, nframes, fs, false, block);
         run("200 Hz setPan thread", clips, cycles, nframes, fs, true, block);
     }
+    run("setPan + 50 Hz play/stop", clips, cycles, nframes, fs, true, block, true);
     for (ClipAudioSource *c : clips) ClipAudioSource_destroy(c);
     shutdownJuce();
     return 0;

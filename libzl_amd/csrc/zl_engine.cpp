@@ -1305,6 +1305,7 @@ static int rt_start(zlhip_engine *e, int nframes)
     else { A.G = A.VPB; A.groups = 1; }                             // one workgroup per bus
     A.NB = 1;
     A.clocks_regular = 1; A.inline_clock = 1; A.fuse_assemble = 1;
+    A.rt_stamps = e->rt.stampsOn ? 1 : 0;
     A.mode = e->cfg.mode;
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena; A.voices = e->dVoices; A.reports = c.dReports; A.pass_cache = e->dPassCache;
     A.bus = e->hBusDev; A.stats = nullptr; A.levels = e->dLevels;

@@ -1250,7 +1250,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         __syncthreads();
         if (!s_go) break;
         last = s_cmd[0];
-        if (z == 0 && tid == 0) sh->stamps[0] = __builtin_amdgcn_s_memrealtime();
+        if (A0.rt_stamps && z == 0 && tid == 0) sh->stamps[0] = __builtin_amdgcn_s_memrealtime();
         ZlBatch A = A0;
         A.N = (int)(uint32_t)s_cmd[1]; A.n_op_ranges = (int)(uint32_t)(s_cmd[1] >> 32);
         A.ops = reinterpret_cast<const ZlVoiceOp *>((uintptr_t)s_cmd[2]); A.op_ranges = reinterpret_cast<const ZlOpRange *>((uintptr_t)s_cmd[3]);
@@ -1302,7 +1302,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         if (tid == 0) s_clk0 = A.clock0;
         __threadfence_block();
         __syncthreads();
-        if (z == 0 && tid == 0) sh->stamps[1] = __builtin_amdgcn_s_memrealtime();
+        if (A0.rt_stamps && z == 0 && tid == 0) sh->stamps[1] = __builtin_amdgcn_s_memrealtime();
         // ---- K1: one lane per voice of the workgroup, the single block of this cycle
         for (int v = vbeg + tid; v < vend; v += (int)blockDim.x) {
             ZlPlanner pl;
@@ -1312,7 +1312,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         }
         __threadfence_block();
         __syncthreads();
-        if (z == 0 && tid == 0) sh->stamps[2] = __builtin_amdgcn_s_memrealtime();
+        if (A0.rt_stamps && z == 0 && tid == 0) sh->stamps[2] = __builtin_amdgcn_s_memrealtime();
         // ---- K1c: plan records of the block, multi-segment blocks expanded by whole waves
         for (int v0 = vbeg; v0 < vend; v0 += (int)blockDim.x) {
             const int v = v0 + tid;
@@ -1323,7 +1323,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         }
         __threadfence_block();
         __syncthreads();
-        if (z == 0 && tid == 0) sh->stamps[3] = __builtin_amdgcn_s_memrealtime();
+        if (A0.rt_stamps && z == 0 && tid == 0) sh->stamps[3] = __builtin_amdgcn_s_memrealtime();
         // ---- K2: this bus (WIDE: each of this workgroup's voices into its own partial row: A.groups = voices per bus, one voice per group)
         if (WIDE) { for (int v = vbeg; v < vend; ++v) zl_k2_body<MODE, 1, false>(A, 0u, 0u, (unsigned)v, 1u, 1u); }
         else zl_k2_body<MODE, 1, false>(A, 0u, 0u, (unsigned)z, 1u, 1u);
@@ -1348,7 +1348,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
             __threadfence_block();
             __syncthreads();
         }
-        if (z == 0 && tid == 0) sh->stamps[4] = __builtin_amdgcn_s_memrealtime();
+        if (A0.rt_stamps && z == 0 && tid == 0) sh->stamps[4] = __builtin_amdgcn_s_memrealtime();
         // ---- reports (gain = peakGain * 0.5f, SamplerSynthVoice.cpp:266) straight into host memory
         for (int v = vbeg + tid; v < vend; v += (int)blockDim.x) {
             const ZlReport r = A.reports[v];
@@ -1359,7 +1359,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this bus's mix and reports (host memory), its levels (HBM)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (z == 0) sh->stamps[5] = __builtin_amdgcn_s_memrealtime();
+            if (A0.rt_stamps && z == 0) sh->stamps[5] = __builtin_amdgcn_s_memrealtime();
             const unsigned int old = __hip_atomic_fetch_add(&dev->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned int)W - 1u) {                     // the last workgroup: the block is complete
                 __hip_atomic_store(&dev->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

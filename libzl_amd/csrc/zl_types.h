@@ -267,7 +267,9 @@ struct ZlBatch {
     const ZlVoiceOp    *ops;
     const ZlOpRange    *op_ranges;
     const ZlClipEdit   *clip_edits; // [n_clip_edits] clip-parameter edits of the call (mapped host memory), applied by K0
-    int32_t             n_clip_edits, pad_edits;
+    int32_t             n_clip_edits;
+    int32_t             rt_stamps;  // resident kernel: 1 = workgroup 0 writes its stage times into the mailbox (ZL_RT_STAMPS; each is a store to host
+                                    // memory that the stage's barrier then waits for -- 1 to 10 us per cycle depending on the box: off by default)
     ZlVoiceConst       *vconst;   // [V]
     ZlRunList          *runs;     // [V]
     ZlTSeg             *tsegs;    // [V][ZL_MAXTSEG] segment stream of the window

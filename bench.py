@@ -355,7 +355,8 @@ def main():
         fan = torch.zeros((B, 6, KB * N), device=dev, dtype=torch.float32)
         fan_params = [PassthroughParams(0.9, 0.5, 0.25, 0.1 * (b % 3 - 1), 0) for b in range(B)]     # every pair multiplied
 
-    def step(i, timed):
+    def step(i, timed, warm=False):
+        nonlocal overlapped
         if exchange and args.dist_backend != "nccl":
             # rehearsal path: the exchange runs on a host copy of the partial bus
             syn.render_batch(KB, N, clock_sets[i], bus_out_dev=bus.data_ptr(), stream=sptr)
@@ -365,6 +366,11 @@ def main():
             if rank == 0:
                 bus.copy_(host)
                 syn.levels_scan_device(bus.data_ptr(), KB, N, stream=sptr)
+        elif exchange and warm:
+            # a collective this RCCL build refuses fails in a warm-up step, synchronously and on every rank: the exchange is then
+            # rebuilt on the plain reduce (OverlappedBusReduce.step_or_fall_back; tests/test_dist_gloo.py runs that path)
+            _, overlapped = overlapped.step_or_fall_back(KB, N, clock_sets[i], stream=sptr, log=(lambda m: sys.stderr.write(f"bench: {m}\n")) if rank == 0 else None)
+            args.reduce_algo = overlapped.algorithm
         elif exchange:
             overlapped.step(KB, N, clock_sets[i], stream=sptr)       # exchange of step i overlaps rendering of step i+1
         elif args.fanout == "fused":
@@ -381,17 +387,7 @@ def main():
     gc.collect(); gc.disable()                                       # as timeit does: no collector pause of this harness inside a timed region
     # (collected here, in front of the warm-up steps, so that the GPU goes from them straight into the timed region)
     for i in range(args.warmup):
-        try:
-            step(i, False)
-        except RuntimeError as err:
-            # a collective this RCCL build refuses (every rank gets the same synchronous error): fall back to the plain
-            # RCCL reduce, the most basic of the three exchanges, rather than losing the run
-            if overlapped is None or overlapped.algorithm == "reduce":
-                raise
-            sys.stderr.write(f"bench: bus exchange '{overlapped.algorithm}' failed ({str(err)[:200]}); falling back to dist.reduce\n")
-            args.reduce_algo = "reduce"
-            overlapped = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32), dst=0, algorithm="reduce")
-            step(i, False)
+        step(i, False, warm=True)
     torch.cuda.synchronize()
     syn.profile_totals(reset=True)                                   # HIP-event sums start with the timed region
     if distributed:

@@ -237,13 +237,16 @@ class OverlappedBusReduce:
                 self.synth.levels_scan_device(self.bus[j].data_ptr(), nb, nf, stream=stream)   # levels see the final mix
             # ("mesh": every rank scanned its reduced piece inside zlhip_bus_reduce_sum_scan; the root imported the levels)
 
-    def step(self, nblocks: int, nframes: int, clocks, stream=None):
-        import torch
-        import torch.distributed as dist
+    def _render(self, nblocks, nframes, clocks, stream):
         j = self.i & 1
         self._finish(j, stream)                       # buffer j was reduced two steps ago
         self.synth.render_batch(nblocks, nframes, clocks, bus_out_dev=self.bus[j].data_ptr(), stream=stream)
         _order_collective_behind_render(self.synth, self.bus[j], stream)
+        return j
+
+    def _exchange(self, j, nblocks, nframes, stream):
+        import torch
+        import torch.distributed as dist
         if self.algorithm == "reduce":
             if self.cuda and stream:                  # RCCL orders the collective behind torch's *current* stream
                 with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.bus[j].device)):
@@ -268,6 +271,31 @@ class OverlappedBusReduce:
         self.i += 1
         return self.bus[j]
 
+    def step(self, nblocks: int, nframes: int, clocks, stream=None):
+        j = self._render(nblocks, nframes, clocks, stream)
+        return self._exchange(j, nblocks, nframes, stream)
+
     def flush(self, stream=None):
         for j in ((self.i & 1), ((self.i + 1) & 1)):
             self._finish(j, stream)
+
+    def step_or_fall_back(self, nblocks: int, nframes: int, clocks, stream=None, log=None):
+        """step() with the safety net bench.py uses in its warm-up steps: a collective this RCCL build refuses raises the same
+        synchronous RuntimeError on every rank, before it has moved anything.  The batch is rendered once; when its exchange is
+        refused, the exchanges still in flight are finished, the exchange is rebuilt on the plain RCCL reduce -- the most basic
+        of the three -- over the SAME two partial buses, and the rendered batch goes through that one (the voices are not rendered
+        a second time).  Returns (bus, exchange): `exchange` is self, or the rebuilt one the caller goes on with."""
+        j = self._render(nblocks, nframes, clocks, stream)
+        try:
+            return self._exchange(j, nblocks, nframes, stream), self
+        except RuntimeError as err:
+            if self.algorithm == "reduce":
+                raise
+            if log is not None:
+                log(f"bus exchange '{self.algorithm}' failed ({str(err)[:200]}); falling back to dist.reduce")
+            self.work[j] = None
+            self._finish(j ^ 1, stream)               # the batch before this one went through the old exchange: complete it
+            bufs = iter(self.bus)
+            other = OverlappedBusReduce(self.synth, lambda: next(bufs), dst=self.dst, group=self.group, algorithm="reduce")
+            other.i, other.shape = self.i, list(self.shape)
+            return other._exchange(j, nblocks, nframes, stream), other

@@ -187,3 +187,87 @@ def test_bus_aligned_partition_needs_no_collective(built):
         exp = np.abs(np.float32(131072.0) * full[buses].reshape(len(buses), 2, sc.nblocks, sc.nframes)).astype(np.int64).max(axis=3).transpose(2, 0, 1)
         assert np.array_equal(peaks, exp)
     assert sorted(seen) == list(range(6))
+
+
+def _fallback_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_harness.sim import SimSynth
+    from libzl_amd import sharding
+    from libzl_amd.engine import synthetic_clocks
+    from scenario import run_backend
+    sc = _scene(world)
+    lo, hi = sharding.slots_for_rank(sc.voices_per_bus, world, rank)
+    sc.events[0] = [("start", b, s - lo, f, t) for (_, b, s, f, t) in sc.events[0] if lo <= s < hi]
+    sc.voices_per_bus = hi - lo
+    _, _, syn, _ = run_backend(sc, SimSynth, batch=5)
+    # the collective of the mesh exchange is refused from its 2nd call on, on every rank alike and before it moves anything --
+    # what an RCCL build without that collective does
+    orig, calls = dist.all_to_all_single, [0]
+
+    def refusing(*a, **k):
+        calls[0] += 1
+        if calls[0] >= 2:
+            raise RuntimeError("all_to_all_single: not supported by this build (injected)")
+        return orig(*a, **k)
+    dist.all_to_all_single = refusing
+    renders = [0]
+    render_batch = syn.render_batch
+    syn.render_batch = lambda *a, **k: (renders.__setitem__(0, renders[0] + 1), render_batch(*a, **k))[1]
+    ov = sharding.OverlappedBusReduce(syn, lambda: torch.zeros((sc.num_buses, 2, 4 * sc.nframes), dtype=torch.float32), dst=0, algorithm="mesh")
+    logged, outs, algos, first = [], [], [], None
+    for i in range(3):
+        b, ov = ov.step_or_fall_back(4, sc.nframes, synthetic_clocks(4, sc.nframes, sc.fs, start_block=sc.nblocks + 4 * i, bpm=sc.bpm), log=logged.append)
+        outs.append(b)
+        algos.append(ov.algorithm)
+        if i == 1:
+            first = outs[0].numpy().copy()             # batch 0 (through the mesh exchange) before batch 2 reuses its buffer
+    ov.flush()
+    second, third = outs[1].numpy().copy(), outs[2].numpy().copy()
+    peaks = getattr(syn, "scanned_peaks", None)
+    # a reduce that is refused has nothing to fall back to: the error reaches the caller
+    dist.reduce, orig_reduce = (lambda *a, **k: (_ for _ in ()).throw(RuntimeError("reduce refused (injected)"))), dist.reduce
+    try:
+        ov.step_or_fall_back(4, sc.nframes, synthetic_clocks(4, sc.nframes, sc.fs, start_block=sc.nblocks + 12, bpm=sc.bpm))
+        raised = False
+    except RuntimeError:
+        raised = True
+    dist.reduce = orig_reduce
+    if rank == 0:
+        q.put((first, second, third, peaks, algos, logged, renders[0], raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_falls_back_to_the_plain_reduce(built):
+    """bench.py's warm-up safety net (OverlappedBusReduce.step_or_fall_back): the mesh exchange is refused on its second batch; the
+    batch already rendered goes through a plain reduce over the same buffers, nothing is rendered twice, and all three batches are
+    the oracle's grouped mix bit for bit (two ranks: a + b has one order), with the levels scanned on the root."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenario import run_oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    b0, b1, b2, peaks, algos, logged, renders, raised = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert algos == ["mesh", "reduce", "reduce"]
+    assert len(logged) == 1 and "falling back to dist.reduce" in logged[0] and "injected" in logged[0]
+    assert renders == 4                                              # 3 batches + the one whose refused reduce was raised: none rendered twice
+    assert raised
+    sc = _scene(world)
+    sc.mix_group = sc.voices_per_bus // world
+    sc.nblocks = 22
+    longer, _, _ = run_oracle(sc)
+    N = sc.nframes
+    for want, have in ((longer[:, :, 10 * N:14 * N], b0), (longer[:, :, 14 * N:18 * N], b1), (longer[:, :, 18 * N:22 * N], b2)):
+        assert np.array_equal(want.view(np.int32), have.view(np.int32))
+    exp = np.abs(np.float32(131072.0) * b2.reshape(sc.num_buses, 2, 4, N)).astype(np.int64).max(axis=3).transpose(2, 0, 1)
+    assert peaks is not None and np.array_equal(peaks, exp)          # the plain reduce's levels: scanned on the reduced bus, on the root

@@ -220,6 +220,12 @@ typedef float zl_f2a4 __attribute__((ext_vector_type(2), aligned(4)));
 #ifndef ZL_K2_U_HERMITE
 #define ZL_K2_U_HERMITE 4    // voices per chunk with 4-tap interpolation (two 16-byte gathers per voice)
 #endif
+#ifndef ZL_K2_WAVES_LINEAR
+// linear mode, one block per workgroup (the headline shape): waves per SIMD asked of the register allocator.  The LDS cap of
+// zl_launch_render holds this kernel at 5 workgroups per CU = 5 waves per SIMD whatever its registers: with 5 the allocator may use
+// 96 registers instead of 80 and the kernel gains 0.5 % (headline) to 2 % (64-voice engines) -- profiles/round3_k2_roll_ab.txt
+#define ZL_K2_WAVES_LINEAR 5
+#endif
 #ifndef ZL_K2_MINWAVES
 #define ZL_K2_MINWAVES 1      // __launch_bounds__ minimum waves per SIMD (caps the VGPR budget)
 #endif
@@ -830,7 +836,9 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
     const int v0 = bus0 * A.VPB + g * A.G;
     const int vlim = (NB > 1) ? ((bus0 + NB) * A.VPB < V ? (bus0 + NB) * A.VPB : V) : (bus0 + 1) * A.VPB;
     const int v1 = (NB > 1) ? vlim : ((v0 + A.G < vlim) ? v0 + A.G : vlim);
-    const bool wantPeak = live && (A.k0 + k == A.Ktot - 1);        // the report covers the last block of the call
+    // the report covers the last block of the call (the same for every lane of a wave -- a wave is a 64-frame tile of one block --
+    // and said so: the per-voice test is then a scalar branch instead of two vector instructions)
+    const bool wantPeak = __builtin_amdgcn_readfirstlane((int)(live && (A.k0 + k == A.Ktot - 1))) != 0;
     const double fd = (double)f;
 #ifdef ZL_STAMPS
     unsigned long long zl_t0 = __builtin_amdgcn_s_memrealtime(), zl_t1 = 0, zl_paths = 0;
@@ -931,8 +939,19 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
         }
     };
 
+    int vbase = v0;                                               // first voice of the staging pass under way
+    // after a chunk of U voices: if it held the last voice of a narrow bus (VPB is a multiple of the chunk size there), write that
+    // bus and start the next one
+    auto chunk_end = [&](int c) {
+        if (NB > 1 && vbase + c + U == busEnd) {
+            store_bus(curBus);
+            accL = 0.0f; accR = 0.0f;
+            ++curBus; busEnd += A.VPB;
+        }
+    };
     for (int vb = v0; vb < v1; vb += CH) {
         const int nv = (v1 - vb < CH) ? v1 - vb : CH;
+        vbase = vb;
         // ---- stage the per-voice records of this pass in LDS: one lane per (block, voice) issues every load it may
         //      need at once (voice constants, run list; plan header + first segment when no run covers the block), so
         //      the prologue is one memory round trip (two for blocks with a second segment) and one barrier
@@ -1106,7 +1125,7 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
                 if (c0 + US < nvR) step(c0 + US, pb, pa);
             }
         } else
-        for (int c0 = 0; c0 < nv; c0 += U) {
+        for (int c0 = 0; c0 < nv; ) {
             const int cc = __builtin_amdgcn_readfirstlane(s_chunk[c0 / U]);
 #ifdef ZL_STAMPS
             if (cc) zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
@@ -1134,12 +1153,8 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
                     else        zl_k2_chunk<MODE, false, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, f, wantPeak, accL, accR);
                 }
             }
-            if (NB > 1 && vb + c0 + U == busEnd) {
-                // that was the last chunk of a bus (VPB is a multiple of the chunk size here): write it, start the next one
-                store_bus(curBus);
-                accL = 0.0f; accR = 0.0f;
-                ++curBus; busEnd += A.VPB;
-            }
+            chunk_end(c0);
+            c0 += U;
         }
     }
 
@@ -1155,12 +1170,12 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
 }
 
 // the kernel: one workgroup = one (bus or group of narrow buses, mix group, block or BPW short blocks, frame tile)
-// (faithful linear mode, one block per workgroup -- the headline shape: ask for the 6 waves per SIMD its 78 registers
-// allow; left to itself the allocator takes 82 and drops to 5.  Two 128-frame blocks per workgroup: 5 waves -- what its 28.8 KB of
+// (faithful linear mode, one block per workgroup -- the headline shape: ZL_K2_WAVES_LINEAR = 5 waves per SIMD, which is what the LDS
+// cap of the launch allows anyway.  Two 128-frame blocks per workgroup: 5 waves -- what its 28.8 KB of
 // LDS allow -- instead of the 4 its 104 registers give: +2..3 % with 10 spilled registers, profiles/round2_e_k2_experiments.txt;
 // four 64-frame blocks: likewise 5, with 64 voices per staging pass)
 template <uint32_t MODE, int BPW, bool ST>
-__global__ void __launch_bounds__(256, ST ? 3 : (MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 ? (BPW == 1 ? 6 : 5) : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
+__global__ void __launch_bounds__(256, ST ? 3 : (MODE & (ZL_MODE_HERMITE | ZL_MODE_FIX_DELAY)) == 0 ? (BPW == 1 ? ZL_K2_WAVES_LINEAR : 5) : ZL_K2_MINWAVES) zl_k2_render(const ZlBatch A)
 {
     zl_k2_body<MODE, BPW, ST>(A, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }

@@ -136,6 +136,10 @@ int  libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next
  * channel, "<prefix>-channel_<bus>.wav": bits_per_sample 16 = the recorder's format (AudioLevels.cpp:53-58), 32 = float.  The
  * positions models and callbacks are not driven.  Returns 0 or a negative zlhip status. */
 int  libzl_hotpath_bounce_to_wav(const char *prefix, int64_t nblocks, uint32_t nframes, uint64_t start_usecs, int bits_per_sample);
+/* Extension: the parameters of a clip as the engine receives them at the next cycle -- among them the slice table that
+ * ClipAudioSource_setSlices builds (ClipAudioSource.cpp:495-528; the reference exposes it as a Qt property only).  No device needed.
+ * Returns 0, or -1 for a null argument. */
+int  libzl_hotpath_clip_params(ClipAudioSource *c, zlhip_clip_params *out);
 /* SyncTimer::scheduleClipCommand(command, delay) (SyncTimer.cpp:1011-1048): what ClipAudioSource_play / _stop call with delay 0;
  * command->clip is the zlhip clip id (ClipAudioSource_engineClip) */
 void libzl_hotpath_schedule_clip_command(const zlhip_clip_command *command, uint64_t delay);

@@ -199,6 +199,10 @@ int zlhip_handle_command(zlhip_engine *e, const zlhip_clip_command *cmd, uint64_
  * voice-table update (K0) before the next rendered block.  taken[i] (optional) receives what zlhip_handle_command
  * would have returned for command i; the return value is their sum, < 0 on error. */
 int zlhip_handle_commands(zlhip_engine *e, const zlhip_clip_command *cmds, int32_t count, uint64_t current_tick, int32_t *taken);
+/* The same, and voices[i] (optional) receives the voice -- bus * voices_per_bus + slot, the index of zlhip_voice_reports -- that
+ * command i STARTED (startNote, SamplerSynthVoice.cpp:110-144), -1 if it started none.  For a host that keeps per-voice state of its own
+ * in the order the reference creates it (the libzl layer's playback-positions rows: created in command order at dispatch, :129). */
+int zlhip_handle_commands_voices(zlhip_engine *e, const zlhip_clip_command *cmds, int32_t count, uint64_t current_tick, int32_t *taken, int32_t *voices);
 /* Same, addressed to an explicit voice slot of a bus (bypasses first-free allocation; used to
  * build large synthetic scenes deterministically). */
 int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd, uint64_t current_tick);

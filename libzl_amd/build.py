@@ -138,7 +138,7 @@ def build_cpu_harness(force: bool = False) -> str:
     hdir = os.path.join(ROOT, "tests", "cpu_harness")
     target = os.path.join(hdir, "_build", "libzl_plan_host.so")
     src = os.path.join(hdir, "plan_host.cpp")
-    deps = [src] + [os.path.join(CSRC, h) for h in ("zl_types.h", "zl_plan.h", "zl_render.h")]
+    deps = [src] + [os.path.join(CSRC, h) for h in ("zl_types.h", "zl_plan.h", "zl_render.h", "zl_host.h")] + [os.path.join(ROOT, "include", "zlhip.h")]
     if force or _stale(target, deps):
         os.makedirs(os.path.dirname(target), exist_ok=True)
         cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",

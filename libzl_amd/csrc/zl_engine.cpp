@@ -783,6 +783,11 @@ int zlhip_handle_command(zlhip_engine *e, const zlhip_clip_command *cmd, uint64_
 
 int zlhip_handle_commands(zlhip_engine *e, const zlhip_clip_command *cmds, int32_t count, uint64_t current_tick, int32_t *taken)
 {
+    return zlhip_handle_commands_voices(e, cmds, count, current_tick, taken, nullptr);
+}
+
+int zlhip_handle_commands_voices(zlhip_engine *e, const zlhip_clip_command *cmds, int32_t count, uint64_t current_tick, int32_t *taken, int32_t *voices)
+{
     if (!e || (!cmds && count > 0) || count < 0) return ZLHIP_ERR_INVALID;
     int rc = refresh_host_voices(e);                               // once for the whole batch
     if (rc != ZLHIP_OK) return rc;
@@ -790,6 +795,7 @@ int zlhip_handle_commands(zlhip_engine *e, const zlhip_clip_command *cmds, int32
     for (int32_t i = 0; i < count; ++i) {
         const int t = e->hc.handle_command(cmds[i], current_tick); // arrival order, as the channel's command ring
         if (taken) taken[i] = t;
+        if (voices) voices[i] = e->hc.lastStartedVoice;
         n += t;
     }
     return n;

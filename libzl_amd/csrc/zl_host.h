@@ -105,11 +105,14 @@ struct ZlHostControl {
             if (voices[v].isPlaying && !reports[v].playing) voices[v] = ZlHostVoice();
     }
 
+    int lastStartedVoice = -1;                 // the voice the last handled command started (-1: it started none)
+
     void push_start(int v, const zlhip_clip_command &cmd, uint64_t tick)
     {
         // setCurrentCommand on an idle voice takes the command (SamplerSynthVoice.cpp:94-96), setStartTick,
         // juce::Synthesiser::startVoice -> startNote (SamplerSynthVoice.cpp:110-144)
         ZlHostVoice &hv = voices[(size_t)v];
+        lastStartedVoice = v;
         hv.cmd = cmd; hv.hasCommand = true; hv.isPlaying = true; hv.startTick = tick; hv.sound = cmd.clip;
         const ZlSound &sd = sounds[(size_t)cmd.clip];
         const zlhip_clip_params &cp = clipParams[(size_t)cmd.clip];
@@ -218,6 +221,7 @@ struct ZlHostControl {
     int handle_command(const zlhip_clip_command &c, uint64_t tick)
     {
         const int bus = c.midi_channel + 2;                            // SamplerSynth.cpp:330-331
+        lastStartedVoice = -1;
         if (bus < 0 || bus >= num_buses) return 0;
         return handle_on_bus(bus, c, tick, -1);
     }

@@ -150,6 +150,7 @@ struct Global {
     std::vector<ClipAudioSource *> byEngineClip; // engine clip id -> clip (live or parked)
     int nextClipId = 1;                        // libzl.cpp:122
     std::vector<int64_t> voicePositionId;      // per voice slot: row in its clip's positions model
+    std::vector<int32_t> dueVoices;            // per command of a dispatched step: the voice it started (zlhip_handle_commands_voices)
     std::vector<ClipAudioSource *> voiceClip;  // per voice slot: clip being played (host view)
     std::vector<zlhip_voice_report> reports;
     ZlRequestQueue<Request, 4096> requests;          // FreshCommandStashSize, SyncTimer.cpp:252
@@ -168,9 +169,8 @@ struct Global {
 struct PendingCallback { void (*fn)(float); float value; };
 
 // setters: the clip's fields -> its published snapshot (call with c->setMu held)
-void publish_params(ClipAudioSource *c)
+void fill_params(const ClipAudioSource *c, zlhip_clip_params &p)
 {
-    zlhip_clip_params p;
     std::memset(&p, 0, sizeof p);
     p.start_position_seconds = c->startPositionInSeconds;
     p.length_seconds = c->lengthInSeconds;
@@ -182,6 +182,12 @@ void publish_params(ClipAudioSource *c)
     p.root_note = c->rootNote;
     p.num_slice_positions = (int32_t)std::min<size_t>(c->slicePositions.size(), ZLHIP_MAX_SLICES);
     for (int i = 0; i < p.num_slice_positions; ++i) p.slice_positions[i] = c->slicePositions[(size_t)i];
+}
+
+void publish_params(ClipAudioSource *c)
+{
+    zlhip_clip_params p;
+    fill_params(c, p);
     c->startPositionRt.store(c->startPositionInSeconds, std::memory_order_relaxed);
     c->snap.publish(p);
 }
@@ -405,8 +411,21 @@ int dispatch_due()
         size_t j = i;
         G.dueBatch.clear();
         while (j < G.due.size() && G.due[j].tick == G.due[i].tick) G.dueBatch.push_back(G.due[j++].cmd);
-        const int rc = zlhip_handle_commands(G.engine, G.dueBatch.data(), (int32_t)G.dueBatch.size(), G.due[i].tick, nullptr);
+        G.dueVoices.assign(G.dueBatch.size(), -1);
+        const int rc = zlhip_handle_commands_voices(G.engine, G.dueBatch.data(), (int32_t)G.dueBatch.size(), G.due[i].tick, nullptr, G.dueVoices.data());
         if (rc < 0) return rc;
+        // startNote creates the voice's row in its clip's positions model right here, command by command (SamplerSynthVoice.cpp:126-129)
+        // -- before any voice of the cycle is processed; which row a voice gets, and so whose progress firstProgress() reports,
+        // depends on that order
+        const int64_t now = now_ms();
+        for (size_t k = 0; k < G.dueBatch.size(); ++k) {
+            const int v = G.dueVoices[k];
+            if (v < 0 || v >= (int)G.voiceClip.size()) continue;
+            ClipAudioSource *c = clip_by_engine_id(G.dueBatch[k].clip);
+            if (G.voiceClip[(size_t)v]) G.voiceClip[(size_t)v]->positions.remove(G.voicePositionId[(size_t)v], now);   // (a slot whose end this layer has not seen yet)
+            G.voiceClip[(size_t)v] = c;
+            G.voicePositionId[(size_t)v] = c ? c->positions.create(0.0f, now) : -1;
+        }
         i = j;
     }
     G.due.clear();
@@ -710,6 +729,15 @@ void ClipAudioSource_setVolumeAbsolute(ClipAudioSource *c, float vol)   // ClipA
 float ClipAudioSource_volumeAbsolute(ClipAudioSource *c) { return c->volumeAbsolute; }
 float dBFromVolume(float vol) { return volumeFaderPositionToDB(vol); }                                                              // libzl.cpp:429
 
+// extension: the parameters of a clip as the engine receives them (the slice table of setSlices has no getter in libzl.h: the
+// reference exposes it as a QVariantList property, ClipAudioSource.h).  Works without a device.
+int libzl_hotpath_clip_params(ClipAudioSource *c, zlhip_clip_params *out)
+{
+    if (!c || !out) return -1;
+    std::lock_guard<std::mutex> sl(c->setMu);
+    fill_params(c, *out);
+    return 0;
+}
 void ClipAudioSource_setSlices(ClipAudioSource *c, int slices) { std::lock_guard<std::mutex> sl(c->setMu); set_slices(c, slices); publish_params(c); }
 int  ClipAudioSource_keyZoneStart(ClipAudioSource *c) { return c->keyZoneStart; }
 void ClipAudioSource_setKeyZoneStart(ClipAudioSource *c, int v) { c->keyZoneStart = v; }

@@ -196,11 +196,16 @@ class SamplerSynth:
     def handle_clip_command(self, cmd: ClipCommand, current_tick: int = 0) -> int:
         return self._ck(self._lib.zlhip_handle_command(self._e, C.byref(cmd), current_tick), "handle_command")
 
-    def handle_clip_commands(self, cmds: Sequence[ClipCommand], current_tick: int = 0):
-        """A block's worth of commands in one call; returns the per-command results (1 taken / 0 dropped)."""
+    def handle_clip_commands(self, cmds: Sequence[ClipCommand], current_tick: int = 0, want_voices: bool = False):
+        """A block's worth of commands in one call; returns the per-command results (1 taken / 0 dropped) -- with want_voices also
+        the voice (bus * voices_per_bus + slot) each command started, -1 if none."""
         n = len(cmds)
         arr = (ClipCommand * n)(*cmds)
         taken = (C.c_int32 * n)()
+        if want_voices:
+            voices = (C.c_int32 * n)()
+            self._ck(self._lib.zlhip_handle_commands_voices(self._e, arr, n, current_tick, taken, voices), "handle_commands")
+            return list(taken), list(voices)
         self._ck(self._lib.zlhip_handle_commands(self._e, arr, n, current_tick, taken), "handle_commands")
         return list(taken)
 

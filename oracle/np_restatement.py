@@ -163,6 +163,7 @@ class Clip:
     duration: np.float32 = f32(0.0)
     root_note: int = 60
     slice_pos: List[float] = field(default_factory=list)
+    slices: int = 0                                               # ClipAudioSource::Private::slices (the count setSlices compares with)
     adsr: tuple = (f32(0.0), f32(0.1), f32(1.0), f32(0.05))      # ctor :164-168
 
     def get_start(self, slice_):                                  # :261-268
@@ -182,13 +183,33 @@ class Clip:
         self.length_sec = f32(f32(ns) / f32(1000000000))
         self.length_beats = f32(beat)
 
-    def set_slices(self, n):                                      # :495-528 from an empty list
-        inc = f64(1.0) / f64(n)
-        pos = f64(0.0)
-        self.slice_pos = []
-        for _ in range(n):
-            self.slice_pos.append(float(pos))
-            pos = f64(pos + inc)
+    def set_slices(self, n):                                      # :495-528
+        """ClipAudioSource::setSlices: 0 clears the table, fewer slices drop the last entries, more slices fit the NEW entries evenly
+        between the last position and 1 (all double arithmetic: `1.0f - last`, divided by the int count of added slices)."""
+        n = int(n)
+        if self.slices == n:
+            return
+        if n == 0:
+            self.slice_pos = []
+        elif self.slices > n:
+            while len(self.slice_pos) > n:
+                self.slice_pos.pop()
+        else:
+            last = f64(self.slice_pos[-1]) if self.slice_pos else f64(0.0)
+            inc = f64(f64(1.0) - last) / f64(n - self.slices)
+            pos = f64(last + inc)
+            if not self.slice_pos:
+                self.slice_pos.append(0.0)
+            while len(self.slice_pos) < n:
+                self.slice_pos.append(float(pos))
+                pos = f64(pos + inc)
+        self.slices = n
+
+    def set_volume_absolute(self, vol):                           # :328-336 (clamp; the fader readback taken as identity)
+        self.volume_abs = f32(max(f32(0.0), min(f32(vol), f32(1.0))))
+
+    def set_start_position(self, sec):                            # :255-259
+        self.start_sec = f32(max(f32(0.0), f32(sec)))
 
 
 @dataclass

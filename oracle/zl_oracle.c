@@ -1068,14 +1068,15 @@ typedef struct batch_job {
     const zlo_sound *sounds; zlo_clip *clips; const zlo_clock *clocks;
     uint32_t nblocks, nframes, mode; int32_t mix_group;
     float *busL, *busR; zlo_report *reports;
+    int64_t now_ms;                 /* the wall clock of the render (positions model: lastUpdated) */
 } batch_job;
 
 static void render_bus_block(zlo_channel *ch, float *L, float *R, uint32_t nframes, const zlo_clock *clk,
                              const zlo_sound *sounds, zlo_clip *clips, uint32_t mode, int32_t mix_group,
-                             zlo_report *reports, float *tmpL, float *tmpR)
+                             zlo_report *reports, float *tmpL, float *tmpR, int64_t now_ms)
 {
     if (mix_group <= 0 || mix_group >= ch->nvoices) {
-        zlo_channel_process(ch, L, R, nframes, clk, sounds, clips, mode, 0, reports);
+        zlo_channel_process(ch, L, R, nframes, clk, sounds, clips, mode, now_ms, reports);
         return;
     }
     /* engine summation order: consecutive groups of mix_group voices are summed sequentially into a
@@ -1090,7 +1091,7 @@ static void render_bus_block(zlo_channel *ch, float *L, float *R, uint32_t nfram
         memset(tmpR, 0, nframes * sizeof(float));
         for (int i = g0; i < g1; ++i)
             if (ch->voices[i].isPlaying)
-                zlo_voice_process(&ch->voices[i], tmpL, tmpR, nframes, clk, sounds, clips, mode, 0, reports ? &reports[i] : NULL, NULL);
+                zlo_voice_process(&ch->voices[i], tmpL, tmpR, nframes, clk, sounds, clips, mode, now_ms, reports ? &reports[i] : NULL, NULL);
         for (uint32_t f = 0; f < nframes; ++f) { L[f] += tmpL[f]; R[f] += tmpR[f]; }
     }
 }
@@ -1110,7 +1111,7 @@ static void *batch_worker(void *arg)
                 rp = j->reports + (size_t)b * ch->nvoices;
             }
             render_bus_block(ch, j->busL + b * total + (size_t)k * j->nframes, j->busR + b * total + (size_t)k * j->nframes,
-                             j->nframes, &j->clocks[k], j->sounds, j->clips, j->mode, j->mix_group, rp, tmpL, tmpR);
+                             j->nframes, &j->clocks[k], j->sounds, j->clips, j->mode, j->mix_group, rp, tmpL, tmpR, j->now_ms);
         }
     }
     free(tmpL);
@@ -1121,6 +1122,15 @@ void zlo_render_batch(zlo_channel *channels, int32_t nbuses, const zlo_sound *so
                       const zlo_clock *clocks, uint32_t nblocks, uint32_t nframes, uint32_t mode,
                       int32_t mix_group, float *busL, float *busR, zlo_report *reports, int32_t threads)
 {
+    zlo_render_batch_at(channels, nbuses, sounds, clips, clocks, nblocks, nframes, mode, mix_group, busL, busR, reports, threads, 0);
+}
+
+/* ... with the wall clock the positions models stamp their rows with (QDateTime::currentMSecsSinceEpoch() in
+ * ClipAudioSourcePositionsModel.cpp:131,191-209: rows not updated for a second are taken for orphans at the next create / remove) */
+void zlo_render_batch_at(zlo_channel *channels, int32_t nbuses, const zlo_sound *sounds, zlo_clip *clips,
+                         const zlo_clock *clocks, uint32_t nblocks, uint32_t nframes, uint32_t mode,
+                         int32_t mix_group, float *busL, float *busR, zlo_report *reports, int32_t threads, int64_t now_ms)
+{
     if (threads < 1) threads = 1;
     if (threads > nbuses) threads = nbuses;
     batch_job jobs[256];
@@ -1130,7 +1140,7 @@ void zlo_render_batch(zlo_channel *channels, int32_t nbuses, const zlo_sound *so
         batch_job *j = &jobs[t];
         j->channels = channels; j->bus_begin = (int32_t)((int64_t)nbuses * t / threads); j->bus_end = (int32_t)((int64_t)nbuses * (t + 1) / threads);
         j->sounds = sounds; j->clips = clips; j->clocks = clocks; j->nblocks = nblocks; j->nframes = nframes; j->mode = mode;
-        j->mix_group = mix_group; j->busL = busL; j->busR = busR; j->reports = reports;
+        j->mix_group = mix_group; j->busL = busL; j->busR = busR; j->reports = reports; j->now_ms = now_ms;
     }
     if (threads == 1) { batch_worker(&jobs[0]); return; }
     for (int t = 0; t < threads; ++t) pthread_create(&tids[t], NULL, batch_worker, &jobs[t]);

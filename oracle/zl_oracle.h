@@ -310,6 +310,9 @@ void zlo_passthrough_process(const zlo_passthrough *p, const float *inL, const f
 void zlo_render_batch(zlo_channel *channels, int32_t nbuses, const zlo_sound *sounds, zlo_clip *clips,
                       const zlo_clock *clocks, uint32_t nblocks, uint32_t nframes, uint32_t mode,
                       int32_t mix_group, float *busL, float *busR, zlo_report *reports, int32_t threads);
+void zlo_render_batch_at(zlo_channel *channels, int32_t nbuses, const zlo_sound *sounds, zlo_clip *clips,
+                      const zlo_clock *clocks, uint32_t nblocks, uint32_t nframes, uint32_t mode,
+                      int32_t mix_group, float *busL, float *busR, zlo_report *reports, int32_t threads, int64_t now_ms);
 
 #ifdef __cplusplus
 }

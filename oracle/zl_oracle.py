@@ -192,6 +192,8 @@ _SIGS = {
     "zlo_passthrough_process": (None, [C.POINTER(Passthrough), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]),
     "zlo_render_batch": (None, [C.POINTER(Channel), C.c_int32, C.POINTER(Sound), C.POINTER(Clip), C.POINTER(Clock), C.c_uint32, C.c_uint32,
                                 C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Report), C.c_int32]),
+    "zlo_render_batch_at": (None, [C.POINTER(Channel), C.c_int32, C.POINTER(Sound), C.POINTER(Clip), C.POINTER(Clock), C.c_uint32, C.c_uint32,
+                                C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Report), C.c_int32, C.c_int64]),
 }
 
 
@@ -325,8 +327,8 @@ class OracleSynth:
             oclocks[k].jackPlayhead = getattr(c, "jack_playhead", getattr(c, "jackPlayhead", 0))
             oclocks[k].jackPlayheadUsecs = getattr(c, "jack_playhead_usecs", getattr(c, "jackPlayheadUsecs", 0))
             oclocks[k].jackSubbeatLengthInMicroseconds = getattr(c, "jack_subbeat_length_usecs", getattr(c, "jackSubbeatLengthInMicroseconds", 0))
-        self.lib.zlo_render_batch(self.channels, self.B, self.sounds, self.clips, oclocks, nblocks, nframes, self.mode,
-                                  self.mix_group, busL.ctypes.data, busR.ctypes.data, reports if want_reports else None, threads)
+        self.lib.zlo_render_batch_at(self.channels, self.B, self.sounds, self.clips, oclocks, nblocks, nframes, self.mode,
+                                     self.mix_group, busL.ctypes.data, busR.ctypes.data, reports if want_reports else None, threads, self.now_ms)
         bus[:, 0, :] = busL
         bus[:, 1, :] = busR
         return bus, reports

@@ -257,9 +257,52 @@ def moving_playhead_goldens():
               playhead=lambda k, period, sub: rows[block0 + k])
 
 
+def command_patch_goldens():
+    """g10: commands that PATCH playing voices (SamplerSynth.cpp:216-229 -> SamplerSynthVoice::setCurrentCommand, :58-100), which
+    the other goldens only do with changeVolume: changeLooping in both directions (a loop that becomes a one-shot runs into its
+    release tail and ends; a one-shot that becomes a loop wraps instead of ending), the stored-only fields (pitch / speed / gain:
+    no audible effect in this version of the reference), equivalence by (note, channel) with two voices of ONE clip -- a patch and a
+    stop addressed to one note leave the other alone --, equivalence by slice, a patch nobody matches, and slice tables that went
+    through setSlices' shrink and grow branches (ClipAudioSource.cpp:495-528) with a slice index beyond the table (:261-277: the
+    clip's own start / stop)."""
+    rng = np.random.default_rng(0x610)
+
+    def src(n, stereo=True):
+        L = rng.uniform(-1, 1, n).astype(np.float32)
+        return (L, rng.uniform(-1, 1, n).astype(np.float32) if stereo else None)
+
+    play = lambda clip, ch=-2, loop=True, note=60, vol=1.0, **kw: dict(clip=clip, midi_channel=ch, midi_note=note, start=True, stop=loop,
+                                                                      looping=loop, change_volume=True, volume=vol, **kw)
+    a, b, c = src(2900), src(3300), src(2500, stereo=False)
+    tbl = nr.Clip()
+    for n in (16, 4, 6):                                           # ctor's 16 (:204), shrink, grow: [0, 1/16, 2/16, 3/16, 0.59375, 1.0]
+        tbl.set_slices(n)
+    events = {
+        0: [play(0, note=60, vol=0.8), play(0, note=64, vol=0.7), play(1, loop=False, note=62, vol=0.9),
+            play(2, note=60, vol=0.6, change_slice=True, slice=2),            # a slice voice (equivalence by slice from now on)
+            play(2, loop=False, note=67, vol=0.5, change_slice=True, slice=9)],   # beyond the table: the clip's own start and stop
+        3: [dict(clip=0, midi_channel=-2, midi_note=64, change_looping=True, looping=False, change_pitch=True, pitch_change=0.25,
+                 change_speed=True, speed_ratio=1.5, change_gain_db=True, gain_db=-6.0)],       # note 64 only: loop -> one-shot
+        5: [dict(clip=1, midi_channel=-2, midi_note=62, change_looping=True, looping=True)],     # one-shot -> loop, before its end
+        7: [dict(clip=2, midi_channel=-2, midi_note=1, change_slice=True, slice=2, change_volume=True, volume=0.25),   # by slice (the note is not compared)
+            dict(clip=2, midi_channel=-2, midi_note=60, change_slice=True, slice=3, change_volume=True, volume=1.0),   # no voice plays slice 3
+            dict(clip=1, midi_channel=-1, midi_note=62, change_volume=True, volume=0.0)],                               # other channel: nobody
+        11: [dict(clip=0, midi_channel=-2, midi_note=60, stop=True)],                                                    # note 60 only
+        22: [dict(clip=1, midi_channel=-2, midi_note=62, change_looping=True, looping=False, change_volume=True, volume=0.5)],   # (it has wrapped once by now)
+    }
+    clips = [dict(length_beats=0.37, length_sec=0.03, volume_abs=0.8, pan=-0.3, adsr=(0.0, 0.1, 1.0, 0.004)),
+             dict(length_beats=0.41, length_sec=0.05, volume_abs=0.9, pan=0.2, adsr=(0.002, 0.003, 0.7, 0.006)),
+             dict(length_beats=0.29, length_sec=0.04, volume_abs=0.7, pan=0.5, slice_pos=tbl.slice_pos)]
+    for mode, nm in ((0, "g10_command_patches"), (4, "g10_command_patches_hermite")):
+        run_scene(nm, B=1, VPB=6, fs=48000.0, mode=mode, nframes=128, nblocks=40,
+                  sounds=[(a[0], a[1], 48000.0), (b[0], b[1], 44100.0), (c[0], None, 48000.0)], clips=clips, events=events)
+
+
 def main():
     if "--config1" in sys.argv:
         return config1_full_shape()
+    if "--patches" in sys.argv:
+        return command_patch_goldens()
     if "--scheduler" in sys.argv:
         return scheduler_golden()
     if "--moving-playhead" in sys.argv:

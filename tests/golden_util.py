@@ -11,7 +11,8 @@ from scenario import Scene
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _MAP = {"clip": "clip", "midi_channel": "midiChannel", "midi_note": "midiNote", "start": "startPlayback", "stop": "stopPlayback",
         "looping": "looping", "change_looping": "changeLooping", "change_volume": "changeVolume", "volume": "volume",
-        "change_slice": "changeSlice", "slice": "slice"}
+        "change_slice": "changeSlice", "slice": "slice", "change_pitch": "changePitch", "pitch_change": "pitchChange",
+        "change_speed": "changeSpeed", "speed_ratio": "speedRatio", "change_gain_db": "changeGainDb", "gain_db": "gainDb"}
 
 
 def golden_names():

@@ -211,15 +211,19 @@ def rand_cmd(rng):
     return c
 
 
-def random_session(seed, ncycles=300):
+def random_session(seed, ncycles=300, xruns=False):
     """A seeded list of operations per cycle: [("schedule", Command, delay) | ("start", bpm) | ("stop",) | ("bpm", bpm) |
-    ("qstart", clip, ch) | ("qstop", clip, ch) | ("tick",)]"""
+    ("qstart", clip, ch) | ("qstop", clip, ch) | ("tick",) | ("gap", cycles)].  xruns: now and then JACK time jumps ahead by a few or by
+    hundreds of cycles before a cycle (an xrun, a suspended host): the step loop then catches up one step per FRAME until the cycle's
+    frames run out (SyncTimer.cpp:512,517-523) and goes on in the next cycle."""
     rng = np.random.default_rng(seed)
     N = int(rng.choice([64, 128, 256, 1024])); fs = float(rng.choice([44100.0, 48000.0, 96000.0]))
     t0 = int(rng.integers(0, 3)) * 1000003
     ops = []
     for _ in range(ncycles):
         cyc = []
+        if xruns and rng.random() < 0.04:
+            cyc.append(("gap", int(rng.choice([1, 2, 9, 60, 700]))))
         for _ in range(int(rng.integers(0, 4)) if rng.random() < 0.3 else 0):
             a = int(rng.integers(0, 12))
             if a < 6: cyc.append(("schedule", rand_cmd(rng), int(rng.choice([0, 0, 0, 1, 2, 7, 96]))))
@@ -240,7 +244,8 @@ def run_session(impl, conv, N, fs, t0, ops, running):
     disp, clocks = [], []
     for k, cyc in enumerate(ops):
         for op in cyc:
-            if op[0] == "schedule": impl.schedule(conv(op[1]), op[2])
+            if op[0] == "gap": t0 += op[1] * per
+            elif op[0] == "schedule": impl.schedule(conv(op[1]), op[2])
             elif op[0] == "start": impl.start(op[1])
             elif op[0] == "stop": impl.stop()
             elif op[0] == "bpm": impl.set_bpm(op[1])
@@ -285,6 +290,31 @@ def test_product_scheduler_equals_the_oracle(seed, built):
     pd, pc = run_session(p, to_e, N, fs, t0, ops, lambda i: None)
     # (the product harness cannot be asked whether it runs: redo with the oracle's paused flags)
     p.close()
+    flags = []
+    o = zo.OracleSyncTimer()
+    run_session(o, to_o, N, fs, t0, ops, lambda i: flags.append(not i.t.contents.threadPaused) or flags[-1])
+    o.close()
+    it = iter(flags)
+    p = ProductScheduler()
+    pd, pc = run_session(p, to_e, N, fs, t0, ops, lambda i: next(it))
+    p.close()
+    assert pd == od
+    assert pc == oc
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_time_jumps_oracle_numpy_and_product_agree(seed, built):
+    """Sessions with xruns (random_session(xruns=True)): the catch-up of the step loop -- one step per frame while the step clock is
+    behind the cycle, the exit when the cycle's frames are used up (SyncTimer.cpp:512), a step placed behind the frames already taken
+    (:524-531) -- on the oracle, its numpy twin and the product's scheduler."""
+    from cpu_harness.sched import ProductScheduler
+    N, fs, t0, ops = random_session(seed, ncycles=260, xruns=True)
+    assert any(op[0] == "gap" for cyc in ops for op in cyc)
+    od, oc = oracle_session(N, fs, t0, ops)
+    m = npr.SyncTimerModel()
+    md, mc = run_session(m, lambda c: c, N, fs, t0, ops, lambda i: not i.paused)
+    assert [[(tup(c), t) for c, t in cyc] for cyc in md] == od
+    assert [(c.playhead, c.playhead_usecs, c.subbeat_usecs) for c in mc] == oc
     flags = []
     o = zo.OracleSyncTimer()
     run_session(o, to_o, N, fs, t0, ops, lambda i: flags.append(not i.t.contents.threadPaused) or flags[-1])

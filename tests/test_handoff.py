@@ -18,7 +18,16 @@ def test_request_queue_and_parameter_snapshots_are_race_free_under_tsan(tmp_path
     if res.returncode != 0 and ("tsan" in res.stderr.lower() or "sanitize" in res.stderr.lower()):
         pytest.skip("ThreadSanitizer runtime not available: " + res.stderr.strip().splitlines()[-1])
     assert res.returncode == 0, res.stderr
-    run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    if run.returncode != 0 and "unexpected memory mapping" in run.stderr:
+        # this gcc's ThreadSanitizer runtime cannot place its shadow under the kernel's address-space randomisation (seen on the GPU
+        # boxes): once more without ASLR, or skip -- an environment limit, not a finding
+        import shutil
+        if shutil.which("setarch"):
+            run = subprocess.run(["setarch", os.uname().machine, "-R", exe], capture_output=True, text=True, timeout=300, env=env)
+        if run.returncode != 0 and ("unexpected memory mapping" in run.stderr or "setarch" in run.stderr):
+            pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel: " + run.stderr.strip().splitlines()[-1])
     assert run.returncode == 0, run.stdout + run.stderr
     assert "ThreadSanitizer" not in run.stderr, run.stderr
     assert "out of order 0, torn 0" in run.stdout and "requests 80000 of 80000" in run.stdout, run.stdout

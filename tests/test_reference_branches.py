@@ -167,9 +167,9 @@ def test_more_voices_of_one_clip_than_position_rows_and_the_level_floor(zl, tmp_
             cycle[0] = k
             now[0] += 3 if k < 70 else 31
             osyn.now_ms = now[0]
-            if k in (1, 2, 3, 4):                                    # 12 more voices per cycle, one-shots at four pitches
-                for ch in range(-2, 10):
-                    both(midiChannel=ch, midiNote=57 + 3 * (k - 1), changeVolume=1, volume=0.3 + 0.05 * (k - 1), looping=0, startPlayback=1)
+            if k in (1, 2, 3, 4):                                    # 12 more voices per cycle, one-shots at four pitches, issued from the
+                for ch in reversed(range(-2, 10)):                   # LAST channel to the first: rows are handed out in command order
+                    both(midiChannel=ch, midiNote=57 + 3 * ((k + ch) % 4), changeVolume=1, volume=0.3 + 0.05 * (k - 1), looping=0, startPlayback=1)
             if k == 30:                                               # a second generation while rows come and go
                 for ch in range(-2, 10, 2):
                     both(midiChannel=ch, midiNote=72, changeVolume=1, volume=0.4, looping=1, startPlayback=1, stopPlayback=1)
@@ -191,7 +191,7 @@ def test_more_voices_of_one_clip_than_position_rows_and_the_level_floor(zl, tmp_
         assert max_rows == 32                                         # the model was full while 48 voices played
         assert got_lvl == want_lvl and got_prog == want_prog
         assert want_lvl[-1][1] < -99.4 and want_lvl[-1][0] < 320      # the chain came within one 0.54 dB step of its -100 dB floor and fell silent
-        assert len(want_lvl) > 150 and len(want_prog) > 5
+        assert len(want_lvl) > 150 and len(want_prog) >= 3           # (progress notifies at most every 100 ms)
         zl.ClipAudioSource_destroy(c)
         zl.shutdownJuce()
     finally:

@@ -224,6 +224,8 @@ def random_session(seed, ncycles=300, xruns=False):
         cyc = []
         if xruns and rng.random() < 0.04:
             cyc.append(("gap", int(rng.choice([1, 2, 9, 60, 700]))))
+            if rng.random() < 0.7:   # a clip queued right behind that cycle, before the timer thread has caught up with the playhead:
+                cyc.append(("late_qstart", int(rng.integers(0, 3)), int(rng.integers(-2, 2))))   # the next bar lies BEHIND the playhead (:823-831)
         for _ in range(int(rng.integers(0, 4)) if rng.random() < 0.3 else 0):
             a = int(rng.integers(0, 12))
             if a < 6: cyc.append(("schedule", rand_cmd(rng), int(rng.choice([0, 0, 0, 1, 2, 7, 96]))))
@@ -245,6 +247,7 @@ def run_session(impl, conv, N, fs, t0, ops, running):
     for k, cyc in enumerate(ops):
         for op in cyc:
             if op[0] == "gap": t0 += op[1] * per
+            elif op[0] == "late_qstart": pass
             elif op[0] == "schedule": impl.schedule(conv(op[1]), op[2])
             elif op[0] == "start": impl.start(op[1])
             elif op[0] == "stop": impl.stop()
@@ -255,6 +258,8 @@ def run_session(impl, conv, N, fs, t0, ops, running):
         cu, nx = t0 + k * per, t0 + (k + 1) * per
         disp.append(impl.process(N, cu, nx))
         clocks.append(impl.clock(cu, nx) if not hasattr(impl, "ext_process") else impl.clock())
+        for op in cyc:
+            if op[0] == "late_qstart": impl.queue_start(op[1], op[2])
         if running(impl):
             impl.timer_callback()
     return disp, clocks

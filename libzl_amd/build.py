@@ -141,7 +141,8 @@ def build_cpu_harness(force: bool = False) -> str:
     deps = [src] + [os.path.join(CSRC, h) for h in ("zl_types.h", "zl_plan.h", "zl_render.h", "zl_host.h")] + [os.path.join(ROOT, "include", "zlhip.h")]
     if force or _stale(target, deps):
         os.makedirs(os.path.dirname(target), exist_ok=True)
-        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+        # (-Bsymbolic: the header-inline code of this library binds to ITS copies, not to libzlhip.so's when both are loaded)
+        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wl,-Bsymbolic",
                "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", target, src]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
@@ -151,7 +152,7 @@ def build_cpu_harness(force: bool = False) -> str:
     t2 = os.path.join(hdir, "_build", "libzl_sched_host.so")
     src2 = os.path.join(hdir, "sched_host.cpp")
     if force or _stale(t2, [src2, os.path.join(CSRC, "zl_sched.h"), os.path.join(ROOT, "include", "zlhip.h")]):
-        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall",
+        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall", "-Wl,-Bsymbolic",
                "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", t2, src2]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:

@@ -313,6 +313,22 @@ class OracleSynth:
             return 1
         return 0
 
+    def update_voice(self, bus, slot, cmd: ClipCommand):
+        """SamplerSynthVoice::setCurrentCommand on a playing voice (zlhip_update_voice; SamplerSynthVoice.cpp:58-100)"""
+        v = self.channels[bus].voices[slot]
+        if not v.isPlaying:
+            return 0
+        self.lib.zlo_voice_set_current_command(C.byref(v), C.byref(cmd), self.clips, self.sounds)
+        return 1
+
+    def stop_voice(self, bus, slot, allow_tail_off=True):
+        """SamplerSynthVoice::stopNote on one voice (zlhip_stop_voice; SamplerSynthVoice.cpp:146-169)"""
+        v = self.channels[bus].voices[slot]
+        if not v.isPlaying:
+            return 0
+        self.lib.zlo_voice_stop_note(C.byref(v), 1 if allow_tail_off else 0, self.clips, self.now_ms)
+        return 1
+
     def render_batch(self, nblocks, nframes, clocks, threads=1, want_reports=True):
         bus = np.zeros((self.B, 2, nblocks * nframes), dtype=np.float32)
         # zlo_render_batch wants busL/busR as [B][nblocks*nframes] planes

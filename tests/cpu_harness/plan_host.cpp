@@ -149,6 +149,18 @@ int zlsim_start_voice(ZlSim *S, int bus, int slot, const zlhip_clip_command *c, 
     return S->hc.handle_on_bus(bus, *c, tick, slot);
 }
 
+int zlsim_update_voice(ZlSim *S, int bus, int slot, const zlhip_clip_command *c)
+{
+    S->absorb();
+    return S->hc.update_voice(bus, slot, *c);
+}
+
+int zlsim_stop_voice(ZlSim *S, int bus, int slot, int allow_tail_off)
+{
+    S->absorb();
+    return S->hc.stop_voice(bus, slot, allow_tail_off != 0);
+}
+
 // bus: [B][2][K*N]
 int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float *bus, int force_slow)
 {
@@ -189,10 +201,15 @@ int zlsim_render_batch(ZlSim *S, int K, int N, const zlhip_clock *clocks, float 
         S->stats.source_bytes += st.source_bytes; S->stats.slow_blocks += st.slow_blocks; S->stats.active_frames += st.active_frames;
     }
     S->expanded = 0;
-    for (int v = 0; v < S->V; ++v) {                              // K1c
+    // K1c, as the kernel cuts it: a lane assembles 2 (8 from 512 voices on) consecutive blocks and finds its place in the voice's
+    // segment stream by itself (ZlAssembler::begin -> locate, also inside the repetitions of a periodic pass)
+    const int bpl = S->V >= 512 ? 8 : 2;
+    for (int v = 0; v < S->V; ++v)
+    for (int kbeg = 0; kbeg < K; kbeg += bpl) {
         ZlAssembler as;
-        as.begin(A, v, 0, K);
-        for (int k = 0; k < K; ++k) {
+        const int kend = kbeg + bpl < K ? kbeg + bpl : K;
+        as.begin(A, v, kbeg, kend);
+        for (int k = kbeg; k < kend; ++k) {
             int idx0 = 0, base0 = 0, n_active = 0;
             if (as.block(A, k, idx0, base0, n_active) <= 2) continue;
             ++S->expanded;

@@ -25,6 +25,8 @@ def lib():
         l.zlsim_sound_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]
         l.zlsim_handle_command.argtypes = [C.c_void_p, C.POINTER(ClipCommand), C.c_uint64]
         l.zlsim_start_voice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ClipCommand), C.c_uint64]
+        l.zlsim_update_voice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ClipCommand)]
+        l.zlsim_stop_voice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         l.zlsim_render_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Clock), C.c_void_p, C.c_int]
         l.zlsim_reports.argtypes = [C.c_void_p, C.POINTER(VoiceReport)]
         l.zlsim_trace.argtypes = [C.c_void_p, C.c_void_p]
@@ -80,6 +82,12 @@ class SimSynth:
 
     def start_voice(self, bus, slot, cmd, current_tick=0):
         return self.l.zlsim_start_voice(self.s, bus, slot, C.byref(cmd), current_tick)
+
+    def update_voice(self, bus, slot, cmd):
+        return self.l.zlsim_update_voice(self.s, bus, slot, C.byref(cmd))
+
+    def stop_voice(self, bus, slot, allow_tail_off=True):
+        return self.l.zlsim_stop_voice(self.s, bus, slot, 1 if allow_tail_off else 0)
 
     def render_batch(self, nblocks, nframes, clocks, bus_out_dev=None, stream=None):
         self._bus = np.zeros((self.num_buses, 2, nblocks * nframes), dtype=np.float32)

@@ -106,7 +106,7 @@ def beat_locked_with_irregular_clocks():
     """Beat-locked loops (integer lengthInBeats: restart against the JACK clock, Q9a) under a clock that jitters, changes
     its period and once steps backwards: the planner's walk over the blocks (no bisection) must find the same frames."""
     from libzl_amd._abi import Clock
-    sc = _base(9, nblocks=40, length=9000)
+    sc = _base(9, nblocks=300, length=9000)                            # 0.8 s: the 1-beat loops (345 ms at 174 bpm) restart twice, the 2-beat loops once
     _play_all(sc, [60, 63, 57, 66])
     for i in range(4):
         def setup(lib, clip, i=i):
@@ -121,7 +121,7 @@ def beat_locked_with_irregular_clocks():
         for j in range(n):
             k = start + j
             period = 2667 + (37 if k % 3 == 0 else -21 if k % 5 == 0 else 0)          # changing period
-            cur = k * 2667 + ((k * 7919) % 13) - (900 if k == 17 else 0)              # jitter, one backward step
+            cur = k * 2667 + ((k * 7919) % 13) - (900 if k in (17, 128, 259) else 0)  # jitter, backward steps (one right where a restart falls)
             arr[j].current_usecs = cur
             arr[j].next_usecs = cur + period
             arr[j].jack_playhead = 0
@@ -284,7 +284,66 @@ def loop_edits_while_playing():
     return sc
 
 
-SCENES = {f.__name__: f for f in (beat_locked_moving_playhead, beat_locked_moving_playhead_long, unit_step_loops_many_passes, positions_beyond_2_to_24, loop_edits_while_playing, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
+def retrigger_onto_the_cached_pass():
+    """Steady loops at the playback rate whose recorded pass the planner replays window after window; the voices are stopped without a
+    tail and the SAME notes started again on the same slots, one slot then taken by another clip: the slot's cached pass belongs to a
+    voice that is gone -- the new voice starts off the pass (its phase is unknown) and must be planned afresh, with a fresh clock state
+    (nextLoopUsecs is formed at the top of ITS first block, SamplerSynthVoice.cpp:179-182) -- and later the clips get an integer
+    lengthInBeats, so that value decides when the loops restart.  Moving playhead."""
+    rng = np.random.default_rng(78)
+    sc = Scene(num_buses=2, voices_per_bus=4, fs=48000.0, nframes=64, nblocks=420, bpm=200, moving_playhead=True, block0=9000)
+    for i in range(4):
+        n = int(rng.integers(800, 1400))
+        L, R = rand_source(rng, n, stereo=bool(i % 2))
+        sc.sounds.append((L, R, 48000.0))
+
+        def setup(lib, clip, n=n, i=i):
+            lib.zlo_clip_set_length(clip, C.c_float(0.0217 + 0.0031 * i), 120)      # fractional beats: sample-space loop
+            clip.lengthInSeconds = float(np.float32(n / 48000.0 * 0.5))
+            lib.zlo_clip_set_volume_absolute(clip, C.c_float(0.7))
+        sc.clip_setup[i] = setup
+    slots = [(0, 0), (0, 2), (1, 1), (1, 3)]
+    starts = lambda k: [("start", b, s, play_cmd(i, midi_channel=b - 2, loop=True, note=60, volume=0.8), sc.tick_at(k)) for i, (b, s) in enumerate(slots)]
+    sc.events[0] = starts(0)
+    sc.events[150] = [("stopv", b, s, False) for (b, s) in slots] + starts(150)       # hard stop, the same voices again on the same slots
+    sc.events[151] = [("stopv", 0, 2, False), ("start", 0, 2, play_cmd(1, midi_channel=-2, loop=True, note=60, volume=0.5), sc.tick_at(151))]
+
+    def set_beats(b):
+        return lambda lib, clip: setattr(clip, "lengthInBeats", b)
+    sc.events[230] = [("clip", 0, set_beats(1.0)), ("clip", 2, set_beats(2.0))]        # clock-driven restarts from here on (144 ms per beat at 200 bpm)
+    return sc
+
+
+def voice_level_calls():
+    """The JUCE SynthesiserVoice surface behind include/zlhip_voice_adapter.h: setCurrentCommand on a PLAYING voice with every patch
+    (SamplerSynthVoice.cpp:58-100) -- among them startPlayback = "restart playback": the position goes back to the start of the voice's
+    slice (:86-91), and changeSlice + startPlayback = jump to another slice's start --, stopNote with a tail and stopNote(.., false)
+    in the middle of a loop (:146-169), a patch and a stop addressed to voices that do not play."""
+    sc = _base(11, nblocks=26, nsounds=3, length=5200)
+    for i in range(3):
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = 0.37
+            clip.lengthInSeconds = float(np.float32(0.05 + 0.01 * i))
+            lib.zlo_clip_set_slices(clip, 4)                        # [0, 1/16, 2/16, 3/16] (the constructor's 16, shrunk)
+            lib.zlo_clip_set_adsr_release(clip, C.c_float(0.004))
+        sc.clip_setup[i] = setup
+    sc.events[0] = [("start", 0, 0, play_cmd(0, midi_channel=-2, loop=True, note=60, volume=0.8), 0),
+                    ("start", 0, 2, play_cmd(1, midi_channel=-2, loop=True, note=64, volume=0.7, changeSlice=1, slice=1), 0),
+                    ("start", 1, 1, play_cmd(2, midi_channel=-1, loop=False, note=57, volume=0.9), 0),
+                    ("start", 1, 3, play_cmd(0, midi_channel=-1, loop=True, note=67, volume=0.5), 0)]
+    sc.events[4] = [("update", 0, 0, dict(clip=0, midiChannel=-2, midiNote=60, startPlayback=1)),                       # restart from the top
+                    ("update", 0, 1, dict(clip=0, midiChannel=-2, midiNote=60, changeVolume=1, volume=0.1))]            # slot 1 does not play
+    sc.events[7] = [("update", 0, 2, dict(clip=1, midiChannel=-2, midiNote=64, changeSlice=1, slice=3, startPlayback=1, changeVolume=1, volume=0.4)),
+                    ("update", 1, 1, dict(clip=2, midiChannel=-1, midiNote=57, changeLooping=1, looping=1, changePitch=1, pitchChange=0.5,
+                                          changeSpeed=1, speedRatio=2.0, changeGainDb=1, gainDb=-3.0))]
+    sc.events[11] = [("stopv", 1, 3, False), ("stopv", 1, 0, True)]                                                      # hard stop mid-loop; slot 0 does not play
+    sc.events[14] = [("stopv", 0, 0, True), ("start", 1, 3, play_cmd(1, midi_channel=-1, loop=True, note=55, volume=0.6), 0)]   # the freed slot is taken again
+    sc.events[18] = [("update", 1, 3, dict(clip=1, midiChannel=-1, midiNote=55, startPlayback=1, changeLooping=1, looping=0)),
+                     ("stopv", 0, 2, False)]
+    return sc
+
+
+SCENES = {f.__name__: f for f in (voice_level_calls, retrigger_onto_the_cached_pass, beat_locked_moving_playhead, beat_locked_moving_playhead_long, unit_step_loops_many_passes, positions_beyond_2_to_24, loop_edits_while_playing, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
                                   envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}
 for _seed in range(8):
     SCENES[f"random_envelopes_{_seed}"] = (lambda _seed=_seed: random_envelopes(9100 + _seed))

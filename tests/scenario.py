@@ -84,6 +84,7 @@ class Scene:
     clip_setup: Dict[int, Callable] = field(default_factory=dict)
     # events[k] = list of actions applied before block k is rendered:
     #   ("cmd", fields, tick) | ("start", bus, slot, fields, tick) | ("clip", clip_id, fn)
+    #   | ("update", bus, slot, fields) | ("stopv", bus, slot, allow_tail_off): the voice-level calls (zlhip_update_voice / _stop_voice)
     events: Dict[int, list] = field(default_factory=dict)
     clocks: Optional[Callable[[int, int], "C.Array"]] = None     # (start_block, n) -> Clock array
     bpm: int = 120
@@ -133,6 +134,10 @@ def run_oracle(scene: Scene, batch: int = 1 << 30, threads: int = 1, fast: bool 
                 osyn.handle_clip_command(oracle_cmd(**ev[1]), ev[2])
             elif ev[0] == "start":
                 osyn.start_voice(ev[1], ev[2], oracle_cmd(**ev[3]), ev[4])
+            elif ev[0] == "update":
+                osyn.update_voice(ev[1], ev[2], oracle_cmd(**ev[3]))
+            elif ev[0] == "stopv":
+                osyn.stop_voice(ev[1], ev[2], ev[3])
             elif ev[0] == "clip":
                 ev[2](osyn.lib, osyn.clips[ev[1]])
         bus, reports = osyn.render_batch(n, scene.nframes, scene.make_clocks(k0, n), threads=threads)
@@ -175,6 +180,10 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
                 syn.handle_clip_command(engine_cmd(**ev[1]), ev[2])
             elif ev[0] == "start":
                 syn.start_voice(ev[1], ev[2], engine_cmd(**ev[3]), ev[4])
+            elif ev[0] == "update":
+                syn.update_voice(ev[1], ev[2], engine_cmd(**ev[3]))
+            elif ev[0] == "stopv":
+                syn.stop_voice(ev[1], ev[2], ev[3])
             elif ev[0] == "clip":
                 ev[2](ref.lib, ref.clips[ev[1]])
                 syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))

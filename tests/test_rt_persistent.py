@@ -307,3 +307,45 @@ def test_two_engines_device_wide_waits_do_not_wait_for_a_resident_kernel(built, 
     assert starts >= 2 and cycles >= 30, (starts, cycles)         # it was asked to leave and came back
     assert t_foreign < 3 * 1.5, t_foreign                         # three rounds; each would wait >= 2 s (often several times) behind A's kernel
     A.close()
+
+
+def test_kernel_leaving_while_a_cycle_is_posted(built, rt_env):
+    """The race at the idle timeout: with a timeout of 150 us and cycles 0-400 us apart, the resident kernel decides to leave again and
+    again at the very moment the host posts a cycle -- sometimes it has seen the post (and renders it before it goes), sometimes not
+    (the host finds it gone, starts it again, and the new kernel takes the cycle from the mailbox).  2500 cycles with commands and clip
+    edits in between: every block the oracle's, none lost, none rendered twice; the kernel was started hundreds of times."""
+    from libzl_amd import SamplerSynth
+    from oracle import zl_oracle as zo
+    sc = random_scene(411, num_buses=4, voices_per_bus=8, nclips=12, nframes=64, nblocks=2500)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    ref = zo.OracleSynth(1, 1, sc.fs, sc.mode, max_sounds=16)
+    syn = SamplerSynth(num_buses=4, voices_per_bus=8, max_frames=64, max_batch_blocks=4, max_sounds=16, sound_arena_bytes=1 << 21, rt_idle_timeout_us=150)
+    for i, (L, R, sr) in enumerate(sc.sounds):
+        assert ref.register_clip(L, R, sr) == i and syn.register_clip(L, R, sr) == i
+        if i in sc.clip_setup:
+            sc.clip_setup[i](ref.lib, ref.clips[i])
+        syn.set_clip_params(i, snapshot_clip(ref.clips[i]))
+    rng = np.random.default_rng(5)
+    gaps = rng.uniform(0.0, 400e-6, sc.nblocks)
+    N = sc.nframes
+    out = np.zeros((sc.num_buses, 2, sc.nblocks * N), dtype=np.float32)
+    for k in range(sc.nblocks):
+        for ev in sc.events.get(k, []):
+            if ev[0] == "cmd":
+                syn.handle_clip_command(engine_cmd(**ev[1]), ev[2])
+            elif ev[0] == "clip":
+                ev[2](ref.lib, ref.clips[ev[1]])
+                syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < gaps[k]:                                  # (a spin: sleep() is far coarser than the timeout)
+            pass
+        L, R = syn.process(N, sc.make_clocks(k, 1)[0])
+        out[:, 0, k * N:(k + 1) * N] = L
+        out[:, 1, k * N:(k + 1) * N] = R
+    starts, cycles = syn.rt_stats()
+    rep = syn.voice_reports()
+    syn.close()
+    assert np.array_equal(out.view(np.int32), ref_bus.view(np.int32)), int(np.argmax(np.abs(out - ref_bus).max(axis=(0, 1)) > 0)) // N
+    for v in range(32):
+        assert bool(ref_syn.voices[v].isPlaying) == bool(rep[v].playing)
+    assert cycles == sc.nblocks and starts > 100, (starts, cycles)

@@ -117,6 +117,25 @@ def test_level_chain_decays_to_the_floor_and_falls_silent_on_the_oracle():
     assert all(abs((a - b) - 20 * np.log10(0.94)) < 1e-3 for a, b in zip(fired[1:-1], fired[:-2]))
 
 
+def test_a_flood_of_calls_with_no_cycle_to_drain_them(zl, capfd):
+    """play / stop / queue calls post into a bounded lock-free queue that the cycle drains (zl_handoff.h).  With no cycle running --
+    a host that never pulls audio -- the 4096 cells fill up: further calls are dropped with ONE line on stderr, nothing blocks, nothing
+    is overwritten, and the library stays usable (the setters do not go through the queue)."""
+    L = np.zeros(4800, dtype=np.float32)
+    c = zl.ClipAudioSource_newFromBuffer(L.ctypes.data, None, len(L), 48000.0, b"flood")
+    try:
+        for i in range(3000):
+            zl.ClipAudioSource_play(c, bool(i & 1))
+            zl.ClipAudioSource_stopOnChannel(c, i % 10)
+            zl.SyncTimer_queueClipToStartOnChannel(c, -1)
+        err = capfd.readouterr().err
+        assert err.count("request queue full") == 1
+        zl.ClipAudioSource_setPan(c, 0.25)
+        assert _product_params(zl, c).pan == 0.25
+    finally:
+        zl.ClipAudioSource_destroy(c)
+
+
 # ------------------------------------------------------------------------------------------------------------------------ GPU tier
 @pytest.mark.gpu
 def test_more_voices_of_one_clip_than_position_rows_and_the_level_floor(zl, tmp_path):

@@ -349,3 +349,29 @@ def test_kernel_leaving_while_a_cycle_is_posted(built, rt_env):
     for v in range(32):
         assert bool(ref_syn.voices[v].isPlaying) == bool(rep[v].playing)
     assert cycles == sc.nblocks and starts > 100, (starts, cycles)
+
+
+def test_more_voice_operations_in_a_cycle_than_the_mapped_buffers_hold(built, rt_env):
+    """96 voices, and a cycle that patches every one of them three times (288 operations; the engine's host-mapped operation buffers
+    start at voices + 32 entries): the buffers grow while the resident kernel is up -- a device-synchronising step, so the kernel is
+    asked to yield first and is started again -- and the cycle is still the oracle's, as are the cycles around it."""
+    from scenario import Scene, play_cmd, rand_source
+    rng = np.random.default_rng(612)
+    sc = Scene(num_buses=12, voices_per_bus=8, fs=48000.0, nframes=128, nblocks=16)
+    for i in range(12):
+        L, R = rand_source(rng, 3000 + 100 * i, stereo=bool(i % 3))
+        sc.sounds.append((L, R, 48000.0))
+        sc.clip_setup[i] = (lambda lib, clip, i=i: (setattr(clip, "lengthInBeats", 0.37), setattr(clip, "lengthInSeconds", float(np.float32(0.03 + 0.002 * i)))))
+    notes = [52, 55, 58, 60, 62, 65, 67, 70]
+    sc.events[0] = [("cmd", play_cmd(b, midi_channel=b - 2, loop=True, note=n, volume=0.2 + 0.05 * j), 0) for b in range(12) for j, n in enumerate(notes)]
+    sc.events[5] = [("cmd", dict(clip=b, midiChannel=b - 2, midiNote=n, changeVolume=1, volume=v), 0)
+                    for v in (0.9, 0.1, 0.45) for b in range(12) for n in notes]
+    sc.events[9] = [("cmd", dict(clip=b, midiChannel=b - 2, midiNote=n, stopPlayback=1), 0) for b in range(12) for n in notes[::2]]
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn = _play_blockwise(sc)
+    starts, cycles = syn.rt_stats()
+    syn.close()
+    assert np.array_equal(bus.view(np.int32), ref_bus.view(np.int32))
+    for v in range(96):
+        assert bool(ref_syn.voices[v].isPlaying) == bool(rep[v].playing)
+    assert cycles == 16 and starts >= 2                            # (the kernel was restarted by the growth)

@@ -297,8 +297,9 @@ def random_scene(seed, *, num_buses=3, voices_per_bus=8, nframes=128, nblocks=24
         for k in sorted(set(int(x) for x in rng.integers(1, nblocks, size=6))):
             i = int(rng.integers(0, nclips))
             ch_all = [c for c in range(-2, num_buses - 2)]
-            what = int(rng.integers(0, 4))
+            what = int(rng.integers(0, 6))
             lst = sc.events.setdefault(k, [])
+            flip = bool(rng.integers(0, 2))
             for ch in ch_all:
                 if what == 0:
                     lst.append(("cmd", stop_cmd(i, midi_channel=ch, note=ev0[i][1]["midiNote"]), 0))
@@ -307,6 +308,12 @@ def random_scene(seed, *, num_buses=3, voices_per_bus=8, nframes=128, nblocks=24
                                             volume=float(np.float32(rng.uniform(0.1, 1.0)))), 0))
                 elif what == 2:
                     lst.append(("cmd", play_cmd(i, midi_channel=ch, loop=(kinds[i] != "oneshot"), note=int(rng.integers(55, 66)), volume=0.6), k * 7))
+                elif what == 4:      # a patch of the playing voice: loop <-> one-shot (+ the stored-only fields), SamplerSynthVoice.cpp:58-100
+                    lst.append(("cmd", dict(clip=i, midiChannel=ch, midiNote=ev0[i][1]["midiNote"], changeLooping=1, looping=1 if flip else 0,
+                                            changePitch=1, pitchChange=0.5, changeGainDb=1, gainDb=-2.0), 0))
+                elif what == 5:      # a patch addressed by slice: reaches only voices started with that slice
+                    lst.append(("cmd", dict(clip=i, midiChannel=ch, midiNote=60, changeSlice=1, slice=ev0[i][1].get("slice", 3),
+                                            changeVolume=1, volume=float(np.float32(0.3 + 0.4 * flip))), 0))
             if what == 3:
                 newpan, newvol = float(rng.uniform(-1, 1)), float(rng.uniform(0.1, 1))
 

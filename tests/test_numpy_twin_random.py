@@ -1,0 +1,90 @@
+"""The two restatements of the reference path -- oracle/zl_oracle.c and the independently written oracle/np_restatement.py -- against
+each other on RANDOM scenes (tests/scenario.random_scene: looping, beat-locked and one-shot clips, mono / stereo, pitched and resampled,
+envelopes, slices, stop / patch / retrigger commands and clip edits between blocks), beyond the committed golden scenes: audio, the
+voices' playing flags and positions and the last block's reports, bit for bit, in the faithful, the fixed and the Hermite mode.
+CPU tier; the scenes are small because the numpy twin steps frame by frame in Python."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import np_restatement as nr
+from scenario import random_scene, run_oracle
+
+f32 = np.float32
+
+_CMD = {"clip": "clip", "midiNote": "midi_note", "midiChannel": "midi_channel", "startPlayback": "start", "stopPlayback": "stop",
+        "changeSlice": "change_slice", "slice": "slice", "changeLooping": "change_looping", "looping": "looping",
+        "changePitch": "change_pitch", "pitchChange": "pitch_change", "changeSpeed": "change_speed", "speedRatio": "speed_ratio",
+        "changeGainDb": "change_gain_db", "gainDb": "gain_db", "changeVolume": "change_volume", "volume": "volume"}
+_F32 = {"volume", "pitch_change", "speed_ratio", "gain_db"}
+_BOOL = {"start", "stop", "change_slice", "change_looping", "looping", "change_pitch", "change_speed", "change_gain_db", "change_volume"}
+
+
+def _np_command(fields):
+    kw = {}
+    for k, v in fields.items():
+        a = _CMD[k]
+        kw[a] = f32(v) if a in _F32 else bool(v) if a in _BOOL else int(v)
+    return nr.Command(**kw)
+
+
+def _copy_clip(oc, c: nr.Clip):
+    """the fields the voice reads, from the oracle's clip struct (whose restated setters configured it) to the numpy clip"""
+    c.start_sec = f32(oc.startPositionInSeconds); c.length_sec = f32(oc.lengthInSeconds); c.length_beats = f32(oc.lengthInBeats)
+    c.volume_abs = f32(oc.volumeAbsolute); c.pan = f32(oc.pan); c.duration = f32(oc.duration); c.root_note = int(oc.rootNote)
+    c.slice_pos = [float(oc.slicePositions[i]) for i in range(oc.nSlicePositions)]
+    c.adsr = (f32(oc.adsr.p.attack), f32(oc.adsr.p.decay), f32(oc.adsr.p.sustain), f32(oc.adsr.p.release))
+
+
+def run_numpy(scene):
+    from oracle import zl_oracle as zo
+    ref = zo.OracleSynth(1, 1, scene.fs, scene.mode, max_sounds=max(8, len(scene.sounds)))     # only its clip structs + restated setters
+    syn = nr.Synth(scene.num_buses, scene.voices_per_bus, scene.fs, scene.mode)
+    for i, (L, R, sr) in enumerate(scene.sounds):
+        assert ref.register_clip(L, R, sr) == i and syn.register(L, R, sr) == i
+        if i in scene.clip_setup:
+            scene.clip_setup[i](ref.lib, ref.clips[i])
+        _copy_clip(ref.clips[i], syn.clips[i])
+    N, K, B = scene.nframes, scene.nblocks, scene.num_buses
+    bus = np.zeros((B, 2, K * N), dtype=np.float32)
+    reports = {}
+    for k in range(K):
+        for ev in scene.events.get(k, []):
+            if ev[0] == "cmd":
+                syn.handle(_np_command(ev[1]), ev[2])
+            elif ev[0] == "clip":
+                ev[2](ref.lib, ref.clips[ev[1]])
+                _copy_clip(ref.clips[ev[1]], syn.clips[ev[1]])
+            else:
+                raise AssertionError(ev[0])
+        ck = scene.make_clocks(k, 1)[0]
+        L, R, reports = syn.process(N, nr.Clock(int(ck.current_usecs), int(ck.next_usecs), int(ck.jack_playhead), int(ck.jack_playhead_usecs),
+                                                int(ck.jack_subbeat_length_usecs)))
+        bus[:, 0, k * N:(k + 1) * N] = L
+        bus[:, 1, k * N:(k + 1) * N] = R
+    return bus, reports, syn
+
+
+_SHAPES = [{}, dict(nframes=64, nblocks=20), dict(nframes=256, nblocks=8), dict(fs=44100.0), dict(voices_per_bus=2), dict(num_buses=3, nclips=8, nblocks=16)]
+
+
+@pytest.mark.parametrize("seed,mode,kw", [(7001 + i, [0, 0, 4, 3, 2, 0, 4, 1][i % 8], _SHAPES[i % len(_SHAPES)]) for i in range(32)])
+def test_c_oracle_equals_the_numpy_restatement_on_random_scenes(seed, mode, kw):
+    args = dict(num_buses=2, voices_per_bus=3, nframes=128, nblocks=12, nclips=5, min_len=900, max_len=2600, mode=mode)
+    args.update(kw)
+    sc = random_scene(seed, **args)
+    obus, orep, osyn = run_oracle(sc)
+    nbus, nrep, nsyn = run_numpy(sc)
+    assert np.abs(obus).max() > 0
+    assert np.array_equal(obus.view(np.int32), nbus.view(np.int32)), f"first difference at frame {np.argwhere(obus != nbus)[:2].tolist()}"
+    VPB = sc.voices_per_bus
+    for b in range(sc.num_buses):
+        for i, v in enumerate(nsyn.voices[b]):
+            ov = osyn.voices[b * VPB + i]
+            assert bool(ov.isPlaying) == bool(v.is_playing), (b, i)
+            if v.is_playing:
+                assert ov.sourceSamplePosition == float(v.P), (b, i)
+                r = orep[b * VPB + i]
+                valid, gain, prog, _ = nrep[(b, i)]
+                assert bool(r.valid) == bool(valid) and r.gain == gain and r.progress == prog, (b, i)

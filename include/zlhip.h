@@ -60,7 +60,7 @@ typedef struct zlhip_config {
     int32_t  device;                 /* HIP device ordinal */
     int32_t  num_buses;              /* SamplerChannels (reference: 12, SamplerSynth.cpp:258) */
     int32_t  voices_per_bus;         /* voices per channel (reference: 8, SamplerSynth.cpp:23) */
-    int32_t  max_frames;             /* largest nframes per block; multiple of 64, <= 4096 */
+    int32_t  max_frames;             /* largest nframes per block, 1 .. 4096 (any JACK period: 16, 32, 441, 480 ... -- a block runs on whole 64-lane waves) */
     int32_t  max_batch_blocks;       /* largest nblocks per zlhip_render_batch call */
     int32_t  max_sounds;             /* clip / sound table size */
     uint32_t mode;                   /* ZLHIP_MODE_* */

@@ -392,8 +392,8 @@ int zlhip_engine_create(const zlhip_config *cfg_in, zlhip_engine **out)
     }
     const zlhip_config *cfg = &cfg_full;
     if (cfg->rt_idle_timeout_us < 0) return ZLHIP_ERR_INVALID;
-    if (cfg->num_buses < 1 || cfg->voices_per_bus < 1 || cfg->max_frames < 64 || cfg->max_frames > 4096
-        || (cfg->max_frames % 64) != 0 || cfg->max_batch_blocks < 1 || cfg->max_sounds < 1
+    if (cfg->num_buses < 1 || cfg->voices_per_bus < 1 || cfg->max_frames < 1 || cfg->max_frames > 4096
+        || cfg->max_batch_blocks < 1 || cfg->max_sounds < 1
         || !(cfg->playback_sample_rate > 0.0) || (cfg->mode & ~7u))
         return ZLHIP_ERR_INVALID;
     int ndev = 0;
@@ -942,8 +942,8 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
 {
     if (!e || !clocks || ((fan_params == nullptr) != (fan_out_dev == nullptr))) return ZLHIP_ERR_INVALID;
     if (nblocks < 1 || nblocks > e->cfg.max_batch_blocks) return fail(e, ZLHIP_ERR_CAPACITY, "nblocks exceeds max_batch_blocks");
-    if (nframes < 64 || nframes > e->cfg.max_frames || (nframes % 64) != 0 || (nframes > 256 && (nframes % 256) != 0))
-        return fail(e, ZLHIP_ERR_INVALID, "nframes must be a multiple of 64 (of 256 above 256) and <= max_frames");
+    if (nframes < 1 || nframes > e->cfg.max_frames)
+        return fail(e, ZLHIP_ERR_INVALID, "nframes must be in [1, max_frames]");
     if (e->failed) return fail(e, ZLHIP_ERR_STATE, "engine failed (the resident kernel stopped answering in the middle of a cycle): destroy it");
     ZL_HIP(e, hipSetDevice(e->device));
     { int r_ = rt_stop(e); if (r_ != ZLHIP_OK) return r_; }         // a batch shares the voice table and the plan records with the resident kernel
@@ -978,7 +978,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         A.NB = std::max(1, std::min(128 / A.VPB, A.B));
     A.clocks_regular = regular ? 1 : 0;
     A.mode = e->cfg.mode;
-    A.staged = (e->staged && !e->trace) ? 1 : 0;                  // (the position trace lives in the gather paths)
+    A.staged = (e->staged && !e->trace && nframes % 64 == 0) ? 1 : 0;   // (the position trace lives in the gather paths; a staged wave is a whole 64-frame tile)
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
     A.voices = e->dVoices; A.reports = c.dReports; A.pass_cache = e->dPassCache;
     A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.stats = c.dStats;
@@ -1193,8 +1193,8 @@ static int bounce_body(zlhip_engine *e, int64_t nblocks, int32_t nframes, const 
 int zlhip_bounce(zlhip_engine *e, int64_t nblocks, int32_t nframes, const zlhip_clock *clocks, void *host_out, int32_t format, int32_t sub_blocks)
 {
     if (!e || !clocks || !host_out || nblocks < 1 || !(format == ZLHIP_BOUNCE_F32_PLANAR || format == ZLHIP_BOUNCE_PCM16_STEREO)) return ZLHIP_ERR_INVALID;
-    if (nframes < 64 || nframes > e->cfg.max_frames || (nframes % 64) != 0 || (nframes > 256 && (nframes % 256) != 0))
-        return fail(e, ZLHIP_ERR_INVALID, "nframes must be a multiple of 64 (of 256 above 256) and <= max_frames");
+    if (nframes < 1 || nframes > e->cfg.max_frames)
+        return fail(e, ZLHIP_ERR_INVALID, "nframes must be in [1, max_frames]");
     ZL_HIP(e, hipSetDevice(e->device));
     constexpr int NBUF = zlhip_engine::Bounce::NBUF;
     const int B = e->cfg.num_buses;
@@ -1325,7 +1325,7 @@ static int rt_start(zlhip_engine *e, int nframes)
     if (g_rt.quiescing.load(std::memory_order_acquire) > 0) return ZL_RT_BUSY;
     __atomic_store_n(&e->rt.h->state, 0u, __ATOMIC_RELEASE);
     __atomic_store_n(&e->rt.h->yield, 0u, __ATOMIC_RELEASE);
-    ZL_KERNEL(e, zl_launch_rt_loop(A, e->rt.d, e->rt.dev, e->rt.seq, e->rt.idleTicks, e->dGain, c.hReportsDev, c.hGainDev, e->rt.devRanges, std::max(e->rt.vw, 1), std::min(256, nframes), e->rt.stream));
+    ZL_KERNEL(e, zl_launch_rt_loop(A, e->rt.d, e->rt.dev, e->rt.seq, e->rt.idleTicks, e->dGain, c.hReportsDev, c.hGainDev, e->rt.devRanges, std::max(e->rt.vw, 1), std::min(256, (nframes + 63) & ~63), e->rt.stream));
     e->rt.running = true; e->rt.nframes = nframes; e->rt.starts += 1;
     if (std::find(g_rt.engines.begin(), g_rt.engines.end(), e) == g_rt.engines.end()) g_rt.engines.push_back(e);
     return ZLHIP_OK;
@@ -1426,7 +1426,7 @@ int zlhip_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, flo
 {
     if (!e || !clock || !out_left || !out_right) return ZLHIP_ERR_INVALID;
     if (e->failed) return fail(e, ZLHIP_ERR_STATE, "engine failed (the resident kernel stopped answering in the middle of a cycle): destroy it");
-    if (nframes >= 64 && nframes <= e->cfg.max_frames && (nframes % 64) == 0 && rt_eligible(e, nframes)) {
+    if (nframes >= 1 && nframes <= e->cfg.max_frames && rt_eligible(e, nframes)) {
         ZL_HIP(e, hipSetDevice(e->device));
         const int rc = rt_render(e, nframes, clock, out_left, out_right);
         if (rc != ZL_RT_BUSY) return rc;

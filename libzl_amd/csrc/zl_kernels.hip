@@ -791,7 +791,7 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
 
 // BPW = blocks per workgroup.  Blocks shorter than 256 frames are rendered 256 / N at a time (BPW = 2 or 4: the 256
 // threads are BPW groups of N frames), so the per-workgroup fixed costs -- launch, staging of the voice records -- are
-// paid once per 256 frames whatever the block size is.  A wavefront never straddles two blocks (N is a multiple of 64).
+// paid once per 256 frames whatever the block size is.  A wavefront never straddles two blocks (BPW > 1 only for N = 64 or 128).
 // ST = the variant with LDS-staged source windows (zl_st_* above): its occupancy is set by the ring in LDS (2-3
 // workgroups per CU), so it may take the registers of 3 waves per SIMD.
 // (the body is a device function so that the persistent real-time kernel below can run it too: bx / by / bz / gdx / gdy stand for
@@ -839,7 +839,12 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
     // the report covers the last block of the call (the same for every lane of a wave -- a wave is a 64-frame tile of one block --
     // and said so: the per-voice test is then a scalar branch instead of two vector instructions)
     const bool wantPeak = __builtin_amdgcn_readfirstlane((int)(live && (A.k0 + k == A.Ktot - 1))) != 0;
-    const double fd = (double)f;
+    // A block length that is no multiple of 64 (JACK periods of 16 or 32 frames, 441, 480 ...) leaves the last wave of a block with
+    // lanes behind the block's end: they recompute the block's LAST frame -- every position, control word and tap they touch is
+    // one a real frame touches -- and nothing of theirs is stored, scanned or reported (a duplicate of an existing value does not
+    // move a maximum).  `f` below is the lane's own frame (stores, masks), `fc` the frame it computes.
+    const int fc = f < N ? f : N - 1;
+    const double fd = (double)fc;
 #ifdef ZL_STAMPS
     unsigned long long zl_t0 = __builtin_amdgcn_s_memrealtime(), zl_t1 = 0, zl_paths = 0;
 #endif
@@ -861,8 +866,8 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
         bool written = false;
         if (live) {
             if (MODE & ZL_MODE_FIX_DELAY) {
-                outL[f] = accL; outR[f] = accR;
-                written = true;
+                written = f < N;
+                if (written) { outL[f] = accL; outR[f] = accR; }
             } else {
                 // quirk Q2: the reference pre-increments its output pointers, so frame f lands in out[f+1],
                 // out[0] stays 0 and the sample of the last frame falls outside the buffer (dropped)
@@ -1099,8 +1104,8 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
                                 zl_st_mix<MODE>(A, cur[u], t, vb + i, wantPeak, ac);
                                 accL = ac.x; accR = ac.y;
                             } else if (cl == 0) { }                                                       // idle (SamplerSynth.cpp:137)
-                            else if (cl & 2) zl_k2_chunk<MODE, true, 1>(A, s_plan, s_vc, s_cls, i, pbase, vb, f, wantPeak, accL, accR);
-                            else zl_k2_chunk<MODE, false, 1>(A, s_plan, s_vc, s_cls, i, pbase, vb, f, wantPeak, accL, accR);
+                            else if (cl & 2) zl_k2_chunk<MODE, true, 1>(A, s_plan, s_vc, s_cls, i, pbase, vb, fc, wantPeak, accL, accR);
+                            else zl_k2_chunk<MODE, false, 1>(A, s_plan, s_vc, s_cls, i, pbase, vb, fc, wantPeak, accL, accR);
                         }
                     }
 #pragma unroll
@@ -1134,23 +1139,23 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
             } else if ((cc & 124) == 100) {
                 // (the shared-tap form needs a wave's lanes to be consecutive frames of one block: true for every launch shape --
                 // a wave is a 64-frame tile of its block)
-                if (ZL_K2_UNIT_SHARE) zl_k2_chunk_unit_shared<MODE, U>(A, s_plan, s_vc, s_unit, c0, vb, f, wantPeak, accL, accR);
-                else zl_k2_chunk_simple<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+                if (ZL_K2_UNIT_SHARE) zl_k2_chunk_unit_shared<MODE, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, wantPeak, accL, accR);
+                else zl_k2_chunk_simple<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, fd, wantPeak, accL, accR);
             }
-            else if ((cc & 92) == 68)   zl_k2_chunk_simple<MODE, false, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 28) == 4)    zl_k2_chunk_simple<MODE, false, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 20) == 4)    zl_k2_chunk_simple<MODE, true, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 124) == 116) zl_k2_chunk_simple_mono<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 92) == 84)   zl_k2_chunk_simple_mono<MODE, false, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 28) == 20)   zl_k2_chunk_simple_mono<MODE, false, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
-            else if ((cc & 20) == 20)   zl_k2_chunk_simple_mono<MODE, true, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, f, fd, wantPeak, accL, accR);
+            else if ((cc & 92) == 68)   zl_k2_chunk_simple<MODE, false, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, fd, wantPeak, accL, accR);
+            else if ((cc & 28) == 4)    zl_k2_chunk_simple<MODE, false, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 4)    zl_k2_chunk_simple<MODE, true, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, fd, wantPeak, accL, accR);
+            else if ((cc & 124) == 116) zl_k2_chunk_simple_mono<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, fd, wantPeak, accL, accR);
+            else if ((cc & 92) == 84)   zl_k2_chunk_simple_mono<MODE, false, false, true, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, fd, wantPeak, accL, accR);
+            else if ((cc & 28) == 20)   zl_k2_chunk_simple_mono<MODE, false, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, fd, wantPeak, accL, accR);
+            else if ((cc & 20) == 20)   zl_k2_chunk_simple_mono<MODE, true, false, false, U>(A, s_plan, s_vc, s_unit, c0, vb, fc, fd, wantPeak, accL, accR);
             else {
                 // general chunks (events, second segments, mixed layouts, per-frame control) are rare: run them as
                 // two half-chunks so their extra per-voice registers do not set the kernel's register budget
                 constexpr int H = U / 2;
                 for (int h = 0; h < U; h += H) {
-                    if (cc & 2) zl_k2_chunk<MODE, true, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, f, wantPeak, accL, accR);
-                    else        zl_k2_chunk<MODE, false, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, f, wantPeak, accL, accR);
+                    if (cc & 2) zl_k2_chunk<MODE, true, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, fc, wantPeak, accL, accR);
+                    else        zl_k2_chunk<MODE, false, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, fc, wantPeak, accL, accR);
                 }
             }
             chunk_end(c0);
@@ -1393,7 +1398,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
 // The AudioLevels scan of one (block, bus) row pair by ONE wave: integer peaks (AudioLevels.cpp:361-383) and the sums of
 // squares of the RMS extension in their defined order (oracle/zl_oracle.c zlo_block_sumsq): tiles of 64 frames from frame
 // `off` (1 with quirk Q2: frame 0 of a bus is the constant 0 and lane f of K2 holds out[f + 1]; 0 with FIX_DELAY), the
-// wave's DPP tree inside a tile, tiles added in order -- the same bits as K2's fused scan.  N is a multiple of 64.
+// wave's DPP tree inside a tile, tiles added in order -- the same bits as K2's fused scan.  Any N: a short last tile is padded with zeros.
 static __device__ __forceinline__ ZlBlockLevels zl_scan_rows(const float *inL, const float *inR, int N, int off, int lane)
 {
     int pkL = 0, pkR = 0; float sqL = 0.0f, sqR = 0.0f;
@@ -1472,7 +1477,7 @@ __global__ void __launch_bounds__(256) zl_k3_finalize(const ZlBatch A, const flo
 }
 
 // K3 without partials to sum (the scan of an existing bus: N > 256, or a bus reduced over several GPUs): one WAVE per
-// (block, bus), reductions on the VALU -- no LDS, no barrier.  N is a multiple of 64.
+// (block, bus), reductions on the VALU -- no LDS, no barrier.
 __global__ void __launch_bounds__(256) zl_k3_scan(const ZlBatch A, const float *bus)
 {
     const int N = A.N;
@@ -1683,10 +1688,12 @@ int zl_launch_assemble(const ZlBatch &A, hipStream_t s)
 
 int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    // blocks shorter than 256 frames: 256 / N blocks per workgroup (batches only; a single block keeps its small workgroup)
-    const int bpw = (A.N < 256 && 256 % A.N == 0 && A.K > 1) ? 256 / A.N : 1;
-    const int tpb = bpw > 1 ? 256 : (A.N < 256 ? A.N : 256);
-    const dim3 grid(bpw > 1 ? 1 : A.N / tpb, (A.K + bpw - 1) / bpw, A.NB > 1 ? (A.B + A.NB - 1) / A.NB : A.B * A.groups), block(tpb);
+    // blocks of 64 / 128 frames: 4 / 2 blocks per workgroup (batches only; a single block keeps its small workgroup; other lengths
+    // below 256 -- 16, 32, 48, 100 ... -- are real-time periods: one block per workgroup of whole waves)
+    const int bpw = ((A.N == 64 || A.N == 128) && A.K > 1) ? 256 / A.N : 1;
+    // (whole waves: a block of 100 frames runs on 128 lanes, one of 300 on two workgroups of 256)
+    const int tpb = bpw > 1 ? 256 : (A.N < 256 ? ((A.N + 63) & ~63) : 256);
+    const dim3 grid(bpw > 1 ? 1 : (A.N + tpb - 1) / tpb, (A.K + bpw - 1) / bpw, A.NB > 1 ? (A.B + A.NB - 1) / A.NB : A.B * A.groups), block(tpb);
     // One-block-per-workgroup kernels fill every SIMD's register file (6 waves x 80 VGPRs; 5 x 96 with 4 taps) and
     // leave no room for a planning wave (88 VGPRs): a K1 launch that arrives after K2 has filled the machine then
     // crawls (measured 550 instead of 130 us).  Unused dynamic LDS caps K2 at 5 workgroups per CU (27 KB each of
@@ -1758,11 +1765,11 @@ int zl_launch_finalize(const ZlBatch &A, const float *bus_in, hipStream_t s)
 {
     // nothing to sum (K2 wrote the bus, or the caller hands one over) and 16-byte aligned rows: the wave-per-block scan
     const float *scan = bus_in ? bus_in : (A.groups == 1 ? A.bus : nullptr);
-    if (scan && (((uintptr_t)scan & 15u) == 0) && (A.N % 64) == 0 && (((size_t)A.Ktot * A.N) % 4) == 0) {
+    if (scan) {
         const long long pairs = (long long)A.K * A.B;
         hipLaunchKernelGGL(zl_k3_scan, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, A, scan);
     } else {
-        hipLaunchKernelGGL(zl_k3_finalize, dim3(A.K, A.B), dim3(A.N < 256 ? A.N : 256), 0, s, A, bus_in);
+        hipLaunchKernelGGL(zl_k3_finalize, dim3(A.K, A.B), dim3(A.N < 256 ? ((A.N + 63) & ~63) : 256), 0, s, A, bus_in);
     }
     ZL_LAUNCH_CHECK();
     return 0;

@@ -105,7 +105,7 @@ def test_bounce_into_caller_memory_and_argument_checks(Engine):
     with pytest.raises(ValueError):
         syn.bounce(20, 256, clocks, out=np.zeros((2, 2, 5), dtype=f32))
     with pytest.raises(ZlHipError):
-        syn.bounce(20, 100, clocks)                                # nframes not a multiple of 64
+        syn.bounce(20, 100000, clocks)                             # nframes beyond max_frames
     with pytest.raises(ZlHipError):
         syn.bounce(0, 256, clocks)
     syn.close()

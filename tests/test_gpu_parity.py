@@ -118,11 +118,13 @@ def test_segment_table_overflow(Engine, window):
     syn.close()
 
 
-@pytest.mark.parametrize("nframes", [64, 128, 192, 256, 512, 1024, 4096])      # 4096 = the largest block the engine accepts
+@pytest.mark.parametrize("nframes", [64, 128, 192, 256, 512, 1024, 4096,        # 4096 = the largest block the engine accepts
+                                     16, 32, 48, 100, 200, 300, 441, 480, 1000, 1])  # ... and any other JACK period: a block runs on whole waves
 @pytest.mark.parametrize("batch", [1, 5, 1 << 30])
 def test_block_sizes(Engine, nframes, batch):
-    """Every supported block size: 64 / 128 frames render 4 / 2 blocks per workgroup in batches, 192 and 256 one, 512 and
-    1024 use several frame tiles per block and the separate level scan (K3); single blocks keep their own workgroup."""
+    """Every block size: 64 / 128 frames render 4 / 2 blocks per workgroup in batches, 192 and 256 one, 512 and
+    1024 use several frame tiles per block and the separate level scan (K3); single blocks keep their own workgroup.  A length that
+    is no multiple of 64 leaves lanes behind the block's end in its last wave: they recompute the last frame and store nothing."""
     sc = random_scene(5000 + nframes, nframes=nframes, nblocks=11, events=True, min_len=900, max_len=9000)
     ref_bus, ref_rep, ref_syn = run_oracle(sc)
     bus, rep, syn, _ = run_backend(sc, Engine, batch=batch)
@@ -418,7 +420,8 @@ def test_levels_tick_matches_oracle(Engine):
 
 @pytest.mark.parametrize("shape", [dict(nframes=128), dict(nframes=256), dict(nframes=64), dict(nframes=512),
                                    dict(nframes=256, mode=2), dict(nframes=128, mode=3), dict(nframes=256, mix_group=4),
-                                   dict(nframes=256, batch=1), dict(nframes=1024, mode=2)])
+                                   dict(nframes=256, batch=1), dict(nframes=1024, mode=2),
+                                   dict(nframes=32), dict(nframes=100, mode=2), dict(nframes=441), dict(nframes=200, mix_group=4), dict(nframes=48, batch=1)])
 def test_rms_extension_is_bit_exact_in_every_kernel_shape(Engine, shape):
     """The sums of squares come from K2's fused scan (N <= 256), from K3's wave-per-block scan (N > 256, single blocks)
     and from K3 behind the mix-group sum: all three follow the order the oracle defines, in the modes with and without
@@ -549,7 +552,7 @@ def test_errors_are_reported(Engine):
     with pytest.raises(ZlHipError):
         syn.render_batch(3, 128, synthetic_clocks(3, 128, 48000.0))        # more blocks than max_batch_blocks
     with pytest.raises(ZlHipError):
-        syn.render_batch(1, 100, synthetic_clocks(1, 100, 48000.0))        # nframes not a multiple of 64
+        syn.render_batch(1, 192, synthetic_clocks(1, 192, 48000.0))        # nframes beyond max_frames
     with pytest.raises(ZlHipError):
         syn.register_clip(np.zeros(1 << 20, dtype=np.float32), None, 48000.0)   # arena full
     syn.close()

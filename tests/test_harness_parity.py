@@ -176,3 +176,15 @@ def test_no_free_voice_drops_command_like_reference(Sim):
     ref_bus, ref_rep, ref_syn = run_oracle(sc)
     bus, rep, _, _ = run_backend(sc, Sim, batch=3)
     compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 2)
+
+
+@pytest.mark.parametrize("nframes", [1, 16, 32, 48, 100, 300, 441, 480, 1000])
+@pytest.mark.parametrize("batch", [1, 5, 1 << 30])
+def test_block_lengths_that_are_no_multiple_of_64(Sim, nframes, batch):
+    """JACK periods of 16 or 32 frames, 441, 480 ...: the planner, the assembler and the per-frame code take any block length (the
+    engine's kernels then run a block on whole 64-lane waves and mask the lanes behind its end: tests/test_gpu_parity.py)."""
+    sc = random_scene(5000 + nframes, nframes=nframes, nblocks=11, events=True, min_len=900, max_len=9000)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Sim, batch=batch)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, sc.num_buses * sc.voices_per_bus)
+    syn.close()

@@ -74,7 +74,8 @@ def test_resident_kernel_renders_the_golden_vectors(built, rt_env, name):
     syn.close()
 
 
-@pytest.mark.parametrize("seed,mode,nframes", [(300, 0, 256), (301, 4, 128), (302, 3, 64), (303, 0, 128)])
+@pytest.mark.parametrize("seed,mode,nframes", [(300, 0, 256), (301, 4, 128), (302, 3, 64), (303, 0, 128),
+                                               (304, 0, 32), (305, 4, 16), (306, 2, 48), (307, 0, 100), (308, 0, 240)])   # JACK periods that are no multiple of 64
 def test_resident_kernel_matches_oracle_on_mixed_scenes(built, rt_env, seed, mode, nframes):
     """The reference's own shape -- 12 channels x 8 voices -- with commands and clip edits between cycles, and the levels."""
     from oracle import zl_oracle as zo

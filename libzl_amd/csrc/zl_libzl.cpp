@@ -404,7 +404,7 @@ void drain_requests(bool internalTransport)
 
 // the commands that fell due -> the engine: one zlhip_handle_commands call per run of equal ticks (a step), i.e. one voice-table
 // update on the device however many commands the cycle carries (SamplerSynth::handleClipCommand per command, SyncTimer.cpp:553-558)
-int dispatch_due()
+int dispatch_due(bool trackPositions = true)   // (false: the offline bounce, which does not drive the positions models)
 {
     size_t i = 0;
     while (i < G.due.size()) {
@@ -418,7 +418,7 @@ int dispatch_due()
         // -- before any voice of the cycle is processed; which row a voice gets, and so whose progress firstProgress() reports,
         // depends on that order
         const int64_t now = now_ms();
-        for (size_t k = 0; k < G.dueBatch.size(); ++k) {
+        for (size_t k = 0; trackPositions && k < G.dueBatch.size(); ++k) {
             const int v = G.dueVoices[k];
             if (v < 0 || v >= (int)G.voiceClip.size()) continue;
             ClipAudioSource *c = clip_by_engine_id(G.dueBatch[k].clip);
@@ -925,7 +925,7 @@ int libzl_hotpath_bounce_to_wav(const char *prefix, int64_t nblocks, uint32_t nf
         G.seq.process(nframes, cu, nx, (float)period, G.due);
         if (!G.due.empty() || (int64_t)clocks.size() == cap) {
             rc = flush();                                                            // the blocks before this cycle's commands
-            if (rc == ZLHIP_OK) rc = dispatch_due();
+            if (rc == ZLHIP_OK) rc = dispatch_due(false);
         }
         zlhip_clock clk;
         clk.current_usecs = cu; clk.next_usecs = nx;

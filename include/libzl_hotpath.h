@@ -77,6 +77,9 @@ void ClipAudioSource_setADSRRelease(ClipAudioSource *c, float newValue);        
  * Served by the step ring of libzl_hotpath_cycle; the registered timer callbacks fire on the cycle's thread after each cycle, once per
  * tick the timer went through.  SyncTimer_instance returns the reference's Qt object and is not declared here. */
 void SyncTimer_startTimer(int interval);                                                /* libzl.h:70: SyncTimer::start(bpm), SyncTimer.cpp:870-879 */
+/* SamplerSynth::setChannelEnabled(channel, enabled) (SamplerSynth.h:48-53, SamplerSynth.cpp:343-351; a method of the SamplerSynth singleton, not a
+ * libzl.h symbol): channels -2 .. 9.  A disabled channel takes its commands, its voices stand still, its output is silent (zlhip_bus_set_enabled). */
+void SamplerSynth_setChannelEnabled(int channel, bool enabled);
 void SyncTimer_setBpm(unsigned int bpm);                                                /* libzl.h:71, SyncTimer.cpp:954-975 */
 int  SyncTimer_getMultiplier(void);                                                     /* libzl.h:72, SyncTimer.cpp:946-948 */
 void SyncTimer_stopTimer(void);                                                         /* libzl.h:73, SyncTimer.cpp:881-925 */

@@ -203,6 +203,11 @@ int zlhip_handle_commands(zlhip_engine *e, const zlhip_clip_command *cmds, int32
  * command i STARTED (startNote, SamplerSynthVoice.cpp:110-144), -1 if it started none.  For a host that keeps per-voice state of its own
  * in the order the reference creates it (the libzl layer's playback-positions rows: created in command order at dispatch, :129). */
 int zlhip_handle_commands_voices(zlhip_engine *e, const zlhip_clip_command *cmds, int32_t count, uint64_t current_tick, int32_t *taken, int32_t *voices);
+/* SamplerSynth::setChannelEnabled(channel, enabled) for bus = channel + 2 (SamplerSynth.cpp:343-351; SamplerChannel::process :116-123): a
+ * disabled bus still takes its commands, but its voices are not processed -- they keep position, envelope and clock state and go on
+ * from there when the bus is enabled again -- and report no progress.  The bus renders silence meanwhile (the reference leaves its JACK
+ * port buffers untouched).  Host-only, takes effect with the next rendered block. */
+int zlhip_bus_set_enabled(zlhip_engine *e, int32_t bus, int enabled);
 /* Same, addressed to an explicit voice slot of a bus (bypasses first-free allocation; used to
  * build large synthetic scenes deterministically). */
 int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd, uint64_t current_tick);

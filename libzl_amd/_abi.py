@@ -115,6 +115,7 @@ SIGNATURES = {
     "zlhip_handle_command": (C.c_int, [_E, C.POINTER(ClipCommand), C.c_uint64]),
     "zlhip_handle_commands": (C.c_int, [_E, C.POINTER(ClipCommand), C.c_int32, C.c_uint64, C.POINTER(C.c_int32)]),
     "zlhip_handle_commands_voices": (C.c_int, [_E, C.POINTER(ClipCommand), C.c_int32, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "zlhip_bus_set_enabled": (C.c_int, [_E, C.c_int32, C.c_int]),
     "zlhip_start_voice": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(ClipCommand), C.c_uint64]),
     "zlhip_stop_voice": (C.c_int, [_E, C.c_int32, C.c_int32, C.c_int]),
     "zlhip_update_voice": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(ClipCommand)]),

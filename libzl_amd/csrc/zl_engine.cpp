@@ -801,6 +801,14 @@ int zlhip_handle_commands_voices(zlhip_engine *e, const zlhip_clip_command *cmds
     return n;
 }
 
+int zlhip_bus_set_enabled(zlhip_engine *e, int32_t bus, int enabled)
+{
+    if (!e || bus < 0 || bus >= e->cfg.num_buses) return ZLHIP_ERR_INVALID;
+    int rc = refresh_host_voices(e);
+    if (rc != ZLHIP_OK) return rc;
+    return e->hc.set_bus_enabled(bus, enabled != 0) ? ZLHIP_OK : ZLHIP_ERR_INVALID;
+}
+
 int zlhip_start_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_clip_command *cmd, uint64_t current_tick)
 {
     if (!e || !cmd || bus < 0 || bus >= e->cfg.num_buses || slot < 0 || slot >= e->cfg.voices_per_bus) return ZLHIP_ERR_INVALID;

@@ -106,6 +106,25 @@ struct ZlHostControl {
     }
 
     int lastStartedVoice = -1;                 // the voice the last handled command started (-1: it started none)
+    std::vector<uint8_t> busDisabled;          // SamplerChannel::enabled == false (SamplerSynth.cpp:60,123,343-351); empty = every bus enabled
+    bool bus_enabled(int bus) const { return busDisabled.empty() || !busDisabled[(size_t)bus]; }
+    // SamplerSynth::setChannelEnabled: the channel's voices are no longer processed (they keep their state and position and go on
+    // when the channel is enabled again); its commands are still handled (:118-122 in front of the test at :123)
+    int set_bus_enabled(int bus, bool enabled)
+    {
+        if (bus < 0 || bus >= num_buses) return 0;
+        if (busDisabled.empty()) busDisabled.assign((size_t)num_buses, 0);
+        if ((busDisabled[(size_t)bus] == 0) == enabled) return 1;
+        busDisabled[(size_t)bus] = enabled ? 0 : 1;
+        for (int i = 0; i < voices_per_bus; ++i) {
+            const int v = bus * voices_per_bus + i;
+            if (!voices[(size_t)v].isPlaying) continue;
+            ZlVoiceOp op; std::memset(&op, 0, sizeof op);
+            op.voice = v; op.kind = enabled ? ZL_OP_THAW : ZL_OP_FREEZE;
+            pendingOps.push_back(op);
+        }
+        return 1;
+    }
 
     void push_start(int v, const zlhip_clip_command &cmd, uint64_t tick)
     {
@@ -136,7 +155,8 @@ struct ZlHostControl {
         if (s.attack_rate > 0.0f)     { s.adsr_state = ZL_ADSR_ATTACK; }
         else if (s.decay_rate > 0.0f) { s.env = 1.0f; s.adsr_state = ZL_ADSR_DECAY; }
         else                          { s.env = cp.adsr_sustain; s.adsr_state = ZL_ADSR_SUSTAIN; }
-        s.clip = cmd.clip; s.slice = cmd.slice; s.looping = cmd.looping ? 1 : 0; s.playing = 1;
+        s.clip = cmd.clip; s.slice = cmd.slice; s.looping = cmd.looping ? 1 : 0;
+        s.playing = bus_enabled(v / voices_per_bus) ? 1 : 2;          // a voice started on a disabled channel waits for the channel
         pendingOps.push_back(op);
     }
 

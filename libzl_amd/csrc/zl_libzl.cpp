@@ -134,8 +134,8 @@ namespace {
 // it looks at the steps that are due -- so the scheduler's state belongs to one thread and the caller never holds a lock the
 // real-time thread wants.
 struct Request {
-    enum Kind : int32_t { Schedule, QueueStart, QueueStop, TimerStart, TimerStop, SetBpm, TimerTick } kind;
-    int32_t a, b;                                                  // QueueStart/Stop: clip, channel; TimerStart / SetBpm: bpm
+    enum Kind : int32_t { Schedule, QueueStart, QueueStop, TimerStart, TimerStop, SetBpm, TimerTick, ChannelEnabled } kind;
+    int32_t a, b;                                                  // QueueStart/Stop: clip, channel; TimerStart / SetBpm: bpm; ChannelEnabled: channel, flag
     uint64_t delay;
     zlhip_clip_command cmd;
 };
@@ -398,6 +398,7 @@ void drain_requests(bool internalTransport)
         case Request::TimerStop:  if (internalTransport) G.seq.stop(); break;
         case Request::SetBpm:     if (internalTransport) G.seq.setBpm((uint64_t)(uint32_t)r.a); break;
         case Request::TimerTick:  if (internalTransport) { G.seq.beatSink = &G.beats; G.seq.hi_res_timer_callback(); } break;
+        case Request::ChannelEnabled: if (G.engine) (void)zlhip_bus_set_enabled(G.engine, r.a + 2, r.b); break;   // (an unknown channel is ignored, SamplerSynth.cpp:345)
         }
     }
 }
@@ -765,6 +766,8 @@ double ClipAudioSource_firstProgress(ClipAudioSource *c) { return c->firstProgre
 int  SyncTimer_getMultiplier(void) { return ZLHIP_BEAT_SUBDIVISIONS; }   // SyncTimer.cpp:946-948
 void SyncTimer_startTimer(int interval) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::TimerStart; r.a = interval; post(r); }   // syncTimer->start(interval): the argument is the bpm (SyncTimer.cpp:870-872)
 void SyncTimer_stopTimer(void) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::TimerStop; post(r); }
+// SamplerSynth::setChannelEnabled (SamplerSynth.cpp:343-351; not in libzl.h: the reference reaches it through the SamplerSynth singleton)
+void SamplerSynth_setChannelEnabled(int channel, bool enabled) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::ChannelEnabled; r.a = channel; r.b = enabled ? 1 : 0; post(r); }
 void SyncTimer_setBpm(unsigned int bpm) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::SetBpm; r.a = (int32_t)bpm; post(r); }
 void SyncTimer_queueClipToStartOnChannel(ClipAudioSource *clip, int midiChannel) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::QueueStart; r.a = clip->engineClip; r.b = midiChannel; post(r); }
 void SyncTimer_queueClipToStopOnChannel(ClipAudioSource *clip, int midiChannel) { Request r; std::memset(&r, 0, sizeof r); r.kind = Request::QueueStop; r.a = clip->engineClip; r.b = midiChannel; post(r); }

@@ -467,7 +467,7 @@ struct ZlPlanner {
         t = 0; nts = 0; t_end = INT_MAX; dead_from = 0;
         Pbs = 0.0; tick_bs = 0; usecs_bs = 0; jbs = 0;
         invN = 1.0 / (double)A.N;
-        valid = st.playing && st.clip >= 0 && A.sounds[st.clip].channels > 0;
+        valid = st.playing == 1 && st.clip >= 0 && A.sounds[st.clip].channels > 0;   // (2: its channel is disabled -- idle for this window, state kept)
         posMode = false; clockMode = false; X = INFINITY; blockBytes = 0; inv_r = 0.0;
         if (!valid) {
             // a neutral record: K2 stages every voice slot of a bus and must find addressable constants in it
@@ -1068,6 +1068,10 @@ ZL_HD inline void zl_apply_op(ZlVoiceState &st, const ZlVoiceOp &op)
         if (st.playing) zl_adsr_note_off(st);                     // stopNote(0, true) :148-151
     } else if (op.kind == ZL_OP_HARD_STOP) {
         if (st.playing) zl_voice_hard_stop(st);                   // stopNote(0, false) :153-168
+    } else if (op.kind == ZL_OP_FREEZE) {                         // SamplerSynth::setChannelEnabled(channel, false), SamplerSynth.cpp:343-351
+        if (st.playing) st.playing = 2;
+    } else if (op.kind == ZL_OP_THAW) {
+        if (st.playing) st.playing = 1;
     } else if (op.kind == ZL_OP_PATCH) {                          // setCurrentCommand merge :58-98
         if (!st.playing) return;
         if (op.patch_mask & ZL_PATCH_LOOPING)  st.looping = op.looping;

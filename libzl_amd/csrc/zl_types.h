@@ -68,13 +68,14 @@ struct ZlVoiceState {
     int32_t  clip;                // clip == sound id; -1 none
     int32_t  slice;
     int32_t  looping;
-    int32_t  playing;             // isPlaying && clipCommand != nullptr
+    int32_t  playing;             // isPlaying && clipCommand != nullptr; 2 = ... on a DISABLED sampler channel: the voice keeps its state and is
+                                  // not processed (SamplerChannel::process, SamplerSynth.cpp:123), commands still reach it
     int32_t  loop_phase1;         // 1 + frames since the last loop restart at the end of the last window; 0 = unknown (a hint for
                                   // the pass cache, verified against P before it is used)
 };
 
 // Host -> device voice operations, applied in order before the next block is planned.
-enum { ZL_OP_START = 1, ZL_OP_NOTE_OFF = 2, ZL_OP_PATCH = 3, ZL_OP_HARD_STOP = 4 };
+enum { ZL_OP_START = 1, ZL_OP_NOTE_OFF = 2, ZL_OP_PATCH = 3, ZL_OP_HARD_STOP = 4, ZL_OP_FREEZE = 5, ZL_OP_THAW = 6 };   // 5 / 6: the voice's sampler channel was disabled / enabled
 enum { ZL_PATCH_GAIN = 1, ZL_PATCH_LOOPING = 2, ZL_PATCH_SLICE = 4, ZL_PATCH_POSITION = 8 };
 struct ZlVoiceOp {
     int32_t  voice;

@@ -209,6 +209,10 @@ class SamplerSynth:
         self._ck(self._lib.zlhip_handle_commands(self._e, arr, n, current_tick, taken), "handle_commands")
         return list(taken)
 
+    def set_bus_enabled(self, bus: int, enabled: bool) -> None:
+        """SamplerSynth::setChannelEnabled for bus = channel + 2: a disabled bus takes commands but its voices stand still."""
+        self._ck(self._lib.zlhip_bus_set_enabled(self._e, bus, 1 if enabled else 0), "bus_set_enabled")
+
     def start_voice(self, bus: int, slot: int, cmd: ClipCommand, current_tick: int = 0) -> int:
         return self._ck(self._lib.zlhip_start_voice(self._e, bus, slot, C.byref(cmd), current_tick), "start_voice")
 

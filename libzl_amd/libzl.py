@@ -49,6 +49,7 @@ SIGNATURES = {
     "ClipAudioSource_setADSRRelease": (None, [_P, C.c_float]),
     "SyncTimer_getMultiplier": (C.c_int, []),
     "SyncTimer_startTimer": (None, [C.c_int]),
+    "SamplerSynth_setChannelEnabled": (None, [C.c_int, C.c_bool]),
     "SyncTimer_setBpm": (None, [C.c_uint]),
     "SyncTimer_stopTimer": (None, []),
     "SyncTimer_registerTimerCallback": (None, [TIMER_CB]),

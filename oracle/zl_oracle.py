@@ -313,6 +313,10 @@ class OracleSynth:
             return 1
         return 0
 
+    def set_bus_enabled(self, bus, enabled):
+        """SamplerSynth::setChannelEnabled (SamplerSynth.cpp:343-351)"""
+        self.channels[bus].enabled = 1 if enabled else 0
+
     def update_voice(self, bus, slot, cmd: ClipCommand):
         """SamplerSynthVoice::setCurrentCommand on a playing voice (zlhip_update_voice; SamplerSynthVoice.cpp:58-100)"""
         v = self.channels[bus].voices[slot]

@@ -149,6 +149,12 @@ int zlsim_start_voice(ZlSim *S, int bus, int slot, const zlhip_clip_command *c, 
     return S->hc.handle_on_bus(bus, *c, tick, slot);
 }
 
+int zlsim_set_bus_enabled(ZlSim *S, int bus, int enabled)
+{
+    S->absorb();
+    return S->hc.set_bus_enabled(bus, enabled != 0);
+}
+
 int zlsim_update_voice(ZlSim *S, int bus, int slot, const zlhip_clip_command *c)
 {
     S->absorb();

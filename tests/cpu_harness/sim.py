@@ -26,6 +26,7 @@ def lib():
         l.zlsim_handle_command.argtypes = [C.c_void_p, C.POINTER(ClipCommand), C.c_uint64]
         l.zlsim_start_voice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ClipCommand), C.c_uint64]
         l.zlsim_update_voice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ClipCommand)]
+        l.zlsim_set_bus_enabled.argtypes = [C.c_void_p, C.c_int, C.c_int]
         l.zlsim_stop_voice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         l.zlsim_render_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Clock), C.c_void_p, C.c_int]
         l.zlsim_reports.argtypes = [C.c_void_p, C.POINTER(VoiceReport)]
@@ -82,6 +83,9 @@ class SimSynth:
 
     def start_voice(self, bus, slot, cmd, current_tick=0):
         return self.l.zlsim_start_voice(self.s, bus, slot, C.byref(cmd), current_tick)
+
+    def set_bus_enabled(self, bus, enabled):
+        self.l.zlsim_set_bus_enabled(self.s, bus, 1 if enabled else 0)
 
     def update_voice(self, bus, slot, cmd):
         return self.l.zlsim_update_voice(self.s, bus, slot, C.byref(cmd))

@@ -314,6 +314,36 @@ def retrigger_onto_the_cached_pass():
     return sc
 
 
+def channels_disabled_and_enabled():
+    """SamplerSynth::setChannelEnabled (SamplerSynth.cpp:343-351, SamplerChannel::process :116-123): a disabled channel still drains its
+    commands -- a voice started on it is set up, a stop releases its envelope, a patch lands -- but none of its voices is processed: they
+    keep position, envelope and clock state, report nothing, and go on from exactly there when the channel is enabled again (a beat-locked
+    loop then finds its next restart time long past: it restarts in the first frame)."""
+    sc = _base(12, nblocks=60, nsounds=4, length=5200)
+    sc.num_buses = 3
+    for i in range(4):
+        def setup(lib, clip, i=i):
+            clip.lengthInBeats = [0.37, 1.0, 0.29, 0.41][i]         # clip 1 is beat-locked
+            clip.lengthInSeconds = float(np.float32(0.04 + 0.01 * i))
+            lib.zlo_clip_set_adsr_release(clip, C.c_float(0.006))
+            if i == 2:
+                clip.adsr.p.attack, clip.adsr.p.decay, clip.adsr.p.sustain = (0.01, 0.01, 0.6)
+        sc.clip_setup[i] = setup
+    sc.bpm = 200
+    sc.events[0] = [("cmd", play_cmd(0, midi_channel=-2, loop=True, note=60, volume=0.8), 0), ("cmd", play_cmd(1, midi_channel=-1, loop=True, note=62, volume=0.7), 0),
+                    ("cmd", play_cmd(2, midi_channel=-1, loop=False, note=57, volume=0.9), 0), ("cmd", play_cmd(3, midi_channel=0, loop=True, note=64, volume=0.6), 0)]
+    sc.events[5] = [("enable", 1, False)]                                            # channel -1 stands still: its loop and its one-shot (in its attack)
+    sc.events[8] = [("cmd", play_cmd(3, midi_channel=-1, loop=True, note=67, volume=0.5), 0),      # started on the disabled channel: waits
+                    ("cmd", dict(clip=1, midiChannel=-1, midiNote=62, changeVolume=1, volume=0.2), 0)]   # a patch lands
+    sc.events[11] = [("enable", 0, False), ("enable", 0, True)]                      # off and on between two cycles: nothing happened
+    sc.events[14] = [("cmd", stop_cmd(2, midi_channel=-1, note=57), 0)]              # the stop releases the envelope of a voice that stands still
+    sc.events[30] = [("enable", 1, True)]                                            # 25 cycles later everything goes on
+    sc.events[40] = [("enable", 2, False), ("enable", 1, False)]
+    sc.events[44] = [("enable", 2, True)]
+    sc.events[52] = [("enable", 1, True), ("enable", 1, True)]
+    return sc
+
+
 def voice_level_calls():
     """The JUCE SynthesiserVoice surface behind include/zlhip_voice_adapter.h: setCurrentCommand on a PLAYING voice with every patch
     (SamplerSynthVoice.cpp:58-100) -- among them startPlayback = "restart playback": the position goes back to the start of the voice's
@@ -343,7 +373,7 @@ def voice_level_calls():
     return sc
 
 
-SCENES = {f.__name__: f for f in (voice_level_calls, retrigger_onto_the_cached_pass, beat_locked_moving_playhead, beat_locked_moving_playhead_long, unit_step_loops_many_passes, positions_beyond_2_to_24, loop_edits_while_playing, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
+SCENES = {f.__name__: f for f in (voice_level_calls, channels_disabled_and_enabled, retrigger_onto_the_cached_pass, beat_locked_moving_playhead, beat_locked_moving_playhead_long, unit_step_loops_many_passes, positions_beyond_2_to_24, loop_edits_while_playing, beat_locked_with_irregular_clocks, beat_locked_long_regular, extreme_ratios, tiny_loops, stop_beyond_the_file, negative_beats_q10, start_near_the_end_and_slices,
                                   envelopes_at_their_limits, mono_and_stereo_neighbours, resampled_sources)}
 for _seed in range(8):
     SCENES[f"random_envelopes_{_seed}"] = (lambda _seed=_seed: random_envelopes(9100 + _seed))

@@ -85,6 +85,7 @@ class Scene:
     # events[k] = list of actions applied before block k is rendered:
     #   ("cmd", fields, tick) | ("start", bus, slot, fields, tick) | ("clip", clip_id, fn)
     #   | ("update", bus, slot, fields) | ("stopv", bus, slot, allow_tail_off): the voice-level calls (zlhip_update_voice / _stop_voice)
+    #   | ("enable", bus, flag): SamplerSynth::setChannelEnabled
     events: Dict[int, list] = field(default_factory=dict)
     clocks: Optional[Callable[[int, int], "C.Array"]] = None     # (start_block, n) -> Clock array
     bpm: int = 120
@@ -138,6 +139,8 @@ def run_oracle(scene: Scene, batch: int = 1 << 30, threads: int = 1, fast: bool 
                 osyn.update_voice(ev[1], ev[2], oracle_cmd(**ev[3]))
             elif ev[0] == "stopv":
                 osyn.stop_voice(ev[1], ev[2], ev[3])
+            elif ev[0] == "enable":
+                osyn.set_bus_enabled(ev[1], ev[2])
             elif ev[0] == "clip":
                 ev[2](osyn.lib, osyn.clips[ev[1]])
         bus, reports = osyn.render_batch(n, scene.nframes, scene.make_clocks(k0, n), threads=threads)
@@ -184,6 +187,8 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
                 syn.update_voice(ev[1], ev[2], engine_cmd(**ev[3]))
             elif ev[0] == "stopv":
                 syn.stop_voice(ev[1], ev[2], ev[3])
+            elif ev[0] == "enable":
+                syn.set_bus_enabled(ev[1], ev[2])
             elif ev[0] == "clip":
                 ev[2](ref.lib, ref.clips[ev[1]])
                 syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))

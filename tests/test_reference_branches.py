@@ -276,3 +276,55 @@ def test_destroying_a_playing_clip_and_queueing_with_a_host_owned_transport(zl):
         zl.ClipAudioSource_destroy(b); zl.ClipAudioSource_destroy(c3)
     finally:
         zl.shutdownJuce()
+
+
+@pytest.mark.gpu
+def test_set_channel_enabled_through_the_libzl_layer(zl):
+    """SamplerSynth::setChannelEnabled (SamplerSynth.cpp:343-351) behind the libzl-named layer: a channel disabled while its loop plays
+    falls silent and stands still, a clip played on it meanwhile waits, and everything goes on from where it stood when the channel
+    comes back; peakGain / firstProgress of the clips follow the oracle's positions models (no updates while the channel is off)."""
+    from libzl_amd.engine import synthetic_clocks
+    rng = np.random.default_rng(93)
+    lib = zo.load()
+    zl.initJuce()
+    try:
+        assert zl.libzl_hotpath_status() == 0
+        osyn = zo.OracleSynth(12, 8, 48000.0, 0)
+        clips = []
+        for i in range(2):
+            n = 5000 + 400 * i
+            L = rng.uniform(-1, 1, n).astype(np.float32); R = rng.uniform(-1, 1, n).astype(np.float32)
+            c = zl.ClipAudioSource_newFromBuffer(L.ctypes.data, R.ctypes.data, n, 48000.0, b"en%d" % i)
+            oid = osyn.register_clip(L, R, 48000.0)
+            zl.ClipAudioSource_setLength(c, 0.27 + 0.04 * i, 120); lib.zlo_clip_set_length(C.byref(osyn.clips[oid]), C.c_float(0.27 + 0.04 * i), 120)
+            clips.append((c, oid))
+        play = lambda oid, ch: osyn.handle_clip_command(zo.clip_command(clip=oid, midiChannel=ch, midiNote=60, changeVolume=1, volume=1.0, looping=1, startPlayback=1, stopPlayback=1), 0)
+        N = 128
+        outL = np.zeros((12, N), dtype=np.float32); outR = np.zeros((12, N), dtype=np.float32)
+        now = 1000
+        for k in range(40):
+            now += 3; osyn.now_ms = now
+            if k == 0:
+                zl.ClipAudioSource_playOnChannel(clips[0][0], True, 1); play(clips[0][1], 1)
+                zl.ClipAudioSource_play(clips[1][0], True); play(clips[1][1], -2)
+            if k == 6:
+                zl.SamplerSynth_setChannelEnabled(1, False); osyn.set_bus_enabled(3, False)
+                zl.SamplerSynth_setChannelEnabled(42, False)                           # no such channel: ignored
+            if k == 9:
+                zl.ClipAudioSource_playOnChannel(clips[1][0], True, 1); play(clips[1][1], 1)      # waits on the disabled channel
+            if k == 20:
+                zl.SamplerSynth_setChannelEnabled(1, True); osyn.set_bus_enabled(3, True)
+            clk = synthetic_clocks(1, N, 48000.0, start_block=k)
+            assert zl.libzl_hotpath_process(N, clk, outL.ctypes.data, outR.ctypes.data) == 0
+            bus, _ = osyn.render_batch(1, N, clk)
+            assert np.array_equal(outL.view(np.int32), bus[:, 0].view(np.int32)) and np.array_equal(outR.view(np.int32), bus[:, 1].view(np.int32)), k
+            if 6 <= k < 20:
+                assert np.abs(bus[3]).max() == 0 and np.abs(bus[0]).max() > 0
+            if k in (5, 25):
+                assert np.abs(bus[3]).max() > 0
+            for c, oid in clips:
+                assert zl.ClipAudioSource_firstProgress(c) == lib.zlo_positions_first_progress(C.byref(osyn.clips[oid].positions)), k
+        for c, _ in clips:
+            zl.ClipAudioSource_destroy(c)
+    finally:
+        zl.shutdownJuce()

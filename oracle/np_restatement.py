@@ -389,6 +389,7 @@ class Synth:
     def __init__(self, num_buses, voices_per_bus, fs, mode=0):
         self.B, self.VPB, self.fs, self.mode = num_buses, voices_per_bus, fs, mode
         self.voices = [[Voice() for _ in range(voices_per_bus)] for _ in range(num_buses)]
+        self.enabled = [True] * num_buses                         # SamplerChannel::enabled (SamplerSynth.cpp:60,343-351)
         self.sounds: List[Sound] = []
         self.clips: List[Clip] = []
 
@@ -437,6 +438,8 @@ class Synth:
         R = np.zeros((self.B, nframes), dtype=np.float32)
         reports = {}
         for b in range(self.B):
+            if not self.enabled[b]:                               # SamplerSynth.cpp:123: a disabled channel processes no voice
+                continue
             for i, v in enumerate(self.voices[b]):
                 if v.is_playing:
                     reports[(b, i)] = v.process(L[b], R[b], nframes, clk, self.mode)

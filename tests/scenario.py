@@ -302,9 +302,15 @@ def random_scene(seed, *, num_buses=3, voices_per_bus=8, nframes=128, nblocks=24
         for k in sorted(set(int(x) for x in rng.integers(1, nblocks, size=6))):
             i = int(rng.integers(0, nclips))
             ch_all = [c for c in range(-2, num_buses - 2)]
-            what = int(rng.integers(0, 6))
+            what = int(rng.integers(0, 7))
             lst = sc.events.setdefault(k, [])
             flip = bool(rng.integers(0, 2))
+            if what == 6:            # SamplerSynth::setChannelEnabled: a channel stands still for a few blocks (or to the end)
+                bus = int(rng.integers(0, num_buses)); back = k + int(rng.integers(1, 6))
+                lst.append(("enable", bus, False))
+                if back < nblocks:
+                    sc.events.setdefault(back, []).append(("enable", bus, True))
+                continue
             for ch in ch_all:
                 if what == 0:
                     lst.append(("cmd", stop_cmd(i, midi_channel=ch, note=ev0[i][1]["midiNote"]), 0))

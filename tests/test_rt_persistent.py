@@ -49,6 +49,14 @@ def _play_blockwise(sc, *, pause_at=(), batch_at=(), edit_at=()):
             elif ev[0] == "clip":
                 ev[2](ref.lib, ref.clips[ev[1]])
                 syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))      # host-only: the resident kernel applies the edit at the next cycle
+            elif ev[0] == "update":
+                syn.update_voice(ev[1], ev[2], engine_cmd(**ev[3]))
+            elif ev[0] == "stopv":
+                syn.stop_voice(ev[1], ev[2], ev[3])
+            elif ev[0] == "enable":
+                syn.set_bus_enabled(ev[1], ev[2])
+            else:
+                raise AssertionError(ev[0])
         if k in pause_at:
             time.sleep(0.35)                                                    # longer than the kernel's idle timeout (200 ms)
         if k in edit_at:
@@ -337,6 +345,10 @@ def test_kernel_leaving_while_a_cycle_is_posted(built, rt_env):
             elif ev[0] == "clip":
                 ev[2](ref.lib, ref.clips[ev[1]])
                 syn.set_clip_params(ev[1], snapshot_clip(ref.clips[ev[1]]))
+            elif ev[0] == "enable":
+                syn.set_bus_enabled(ev[1], ev[2])
+            else:
+                raise AssertionError(ev[0])
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < gaps[k]:                                  # (a spin: sleep() is far coarser than the timeout)
             pass

@@ -580,3 +580,15 @@ def test_moving_playhead_across_plan_windows(Engine, window):
         bus, rep, syn, _ = run_backend(es, Engine, batch=1 << 30, plan_window_blocks=window * 8)
         compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, es.num_buses * es.voices_per_bus)
         syn.close()
+
+
+@pytest.mark.parametrize("buses,vpb", [(1, 1), (5, 3), (3, 5), (2, 7), (7, 12), (2, 20), (1, 9), (13, 2), (3, 33)])
+@pytest.mark.parametrize("batch", [1, 1 << 30])
+def test_engines_of_any_shape(Engine, buses, vpb, batch):
+    """Bus widths that are no multiple of the kernel's chunk of 8 voices, a single bus, a single voice, 13 buses of 2: the shapes the
+    narrow-bus packing (whole buses of a multiple of 8 voices per workgroup) and the wide-bus split do not take."""
+    sc = random_scene(7600 + 10 * buses + vpb, num_buses=buses, voices_per_bus=vpb, nclips=max(3, buses * vpb // 2), nframes=128, nblocks=12, events=True)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=batch)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, buses * vpb)
+    syn.close()

@@ -622,6 +622,123 @@ class SyncTimerModel:
 
 
 # ---------------------------------------------------------------- AudioLevels (AudioLevels.cpp:330-412)
+# ---------------------------------------------------------------- ClipAudioSourcePositionsModel + the per-clip level / progress chain
+# Written from /root/reference/lib/ClipAudioSourcePositionsModel.cpp and ClipAudioSource.cpp:88-113,225-240, independently of
+# oracle/zl_oracle.c's zlo_positions_* / zlo_sync_*: rows are dicts, the wall clock is passed in (QDateTime::currentMSecsSinceEpoch()).
+POSITION_COUNT = 32               # ClipAudioSourcePositionsModel.cpp:5
+
+
+class PositionsModel:
+    def __init__(self):                                                   # :7-21
+        self.rows = [dict(id=-1, progress=f32(0), gain=f32(0), updated=0) for _ in range(POSITION_COUNT)]
+        self.update_peak = False
+        self.peak = f32(0)
+
+    def clean_up(self, now):                                              # :191-209: rows not updated for a second are orphans
+        for r in self.rows:
+            if r["id"] > -1 and r["updated"] < now - 1000:
+                r["id"] = -1; r["gain"] = f32(0); r["progress"] = f32(0)
+
+    def create(self, initial_progress, now):                              # :78-100
+        row = -1
+        found = None
+        for r in self.rows:
+            row += 1
+            if r["id"] == -1:
+                found = r
+                break
+        if found is not None:
+            found["id"] = row; found["progress"] = f32(initial_progress); found["updated"] = now
+            self.update_peak = True
+            self.clean_up(now)
+        return row                                                        # (all rows taken: the last row's number, though it is another voice's)
+
+    def set_gain_and_progress(self, pid, gain, progress, now):            # :126-138
+        if -1 < pid < POSITION_COUNT:
+            r = self.rows[pid]
+            r["gain"] = f32(gain); r["progress"] = f32(progress); r["updated"] = now
+            self.update_peak = True
+
+    def remove(self, pid, now):                                           # :140-153
+        if -1 < pid < POSITION_COUNT:
+            r = self.rows[pid]
+            r["id"] = -1; r["gain"] = f32(0); r["progress"] = f32(0)
+            self.update_peak = True
+        self.clean_up(now)
+
+    def peak_gain(self):                                                  # :160-173
+        if self.update_peak:
+            peak = f32(0)
+            for r in self.rows:
+                peak = max(peak, r["gain"])
+            if abs(f64(f32(self.peak - peak))) > 0.01:                    # abs(float) > 0.01: a double comparison
+                self.peak = peak
+            self.update_peak = False
+        return self.peak
+
+    def first_progress(self):                                             # :175-185
+        for r in self.rows:
+            if r["id"] > -1:
+                return f64(r["progress"])
+        return f64(-1.0)
+
+
+def _log10f(x):
+    """std::log10(float): the C library's log10f -- its last bit is the platform's (glibc here, as for the C oracle and the product's host
+    code; numpy's float32 log10 is another implementation and differs in the last place now and then)"""
+    import ctypes
+    global _libm
+    if _libm is None:
+        _libm = ctypes.CDLL("libm.so.6")
+        _libm.log10f.restype = ctypes.c_float; _libm.log10f.argtypes = [ctypes.c_float]
+    return f32(_libm.log10f(float(x)))
+
+
+_libm = None
+
+
+def _gain_to_db(gain, T):                                                 # juce::Decibels::gainToDecibels<T>, floor -100
+    if not gain > 0:
+        return T(-100.0)
+    d = T(T(math.log10(gain) if T is f64 else _log10f(gain)) * T(20.0))
+    return d if d > T(-100.0) else T(-100.0)
+
+
+class ClipMeter:
+    """ClipAudioSource::syncAudioLevel / syncProgress (ClipAudioSource.cpp:88-113,225-240) with the state of :68-69,84-87."""
+
+    def __init__(self):
+        self.current_db = f64(-400.0); self.prev_db = f64(-400.0)
+        self.first_progress = f64(0.0)
+        self.next_position_update = 0; self.next_gain_update = 0
+
+    def sync_audio_level(self, model: PositionsModel, now):               # -> the callback's float argument, or None
+        fired = None
+        if self.next_gain_update < now:                                   # :89
+            self.prev_db = self.current_db                                # :90
+            self.current_db = f64(_gain_to_db(model.peak_gain(), f32))    # :92 (the tracktion level client reads its -100 dB floor)
+            prev_level = f64(math.pow(10.0, float(self.prev_db) * 0.05)) if self.prev_db > -100.0 else f64(0.0)   # :98
+            if self.prev_db > self.current_db:                            # :100-101
+                self.current_db = _gain_to_db(f64(prev_level * f64(0.94)), f64)
+            if abs(self.current_db - self.prev_db) > 0.1:                 # :104
+                fired = f32(self.current_db)                              # :108
+            self.next_gain_update = now + 30                              # :111
+        return fired
+
+    def sync_progress(self, model: PositionsModel, start_sec, duration, has_callback, now):
+        fired = None
+        if self.next_position_update < now:                               # :226
+            new_position = f64(f32(f32(start_sec) / f32(duration)))       # :227 (float / float)
+            if has_callback and model.first_progress() > f64(f32(-1.0)):  # :228
+                new_position = model.first_progress()
+            if abs(self.first_progress - new_position) > 0.001:           # :231
+                self.first_progress = new_position
+                if has_callback:
+                    fired = f32(self.first_progress * f64(f32(duration)))  # :234: double * float -> the callback's float
+                self.next_position_update = now + 100                     # :238
+        return fired
+
+
 def sample_to_peak_int(x) -> int:
     v = abs(float(f32(f32(131072.0) * f32(x))))
     return int(v)

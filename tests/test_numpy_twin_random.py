@@ -93,3 +93,54 @@ def test_c_oracle_equals_the_numpy_restatement_on_random_scenes(seed, mode, kw):
                     continue
                 valid, gain, prog, _ = nrep[(b, i)]
                 assert bool(r.valid) == bool(valid) and r.gain == gain and r.progress == prog, (b, i)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_positions_model_and_meter_chain_twins_agree(seed):
+    """ClipAudioSourcePositionsModel (32 rows, the reused row 31, the one-second orphan clean-up, the 0.01 peak hysteresis) and the
+    per-clip level / progress chain (ClipAudioSource.cpp:88-113,225-240: -100 dB floor, x0.94 fade, 30 / 100 ms gates, 0.1 dB and 0.001
+    thresholds): random sequences of create / update / remove / idle gaps on the C oracle and on its numpy twin -- every row, every return
+    value and every callback value with the tick it fired in."""
+    from oracle import zl_oracle as zo
+    lib = zo.load()
+    rng = np.random.default_rng(8800 + seed)
+    oc = zo.Clip(); lib.zlo_clip_init(C.byref(oc), C.c_float(2.5), 48000.0)
+    lib.zlo_clip_set_start_position(C.byref(oc), C.c_float(float(rng.uniform(0, 1))))
+    om = zo.ClipMeter(); lib.zlo_clip_meter_init(C.byref(om))
+    nm, nmeter = nr.PositionsModel(), nr.ClipMeter()
+    val = C.c_float()
+    now = 10_000_000
+    held = []                                                     # ids handed out and not yet removed (duplicates of 31 included)
+    has_cb = bool(seed % 3)
+    fired = 0
+    for step in range(700):
+        now += int(rng.choice([1, 3, 3, 5, 17, 31, 31, 120, 1500 if rng.random() < 0.05 else 40]))
+        a = rng.random()
+        if a < 0.25 or not held:
+            o = lib.zlo_positions_create(C.byref(oc.positions), C.c_float(0.0), now)
+            n = nm.create(0.0, now)
+            assert o == n
+            held.append(o)
+        elif a < 0.8:
+            for pid in held if rng.random() < 0.5 else held[:1]:
+                g, p = float(np.float32(rng.uniform(0, 1.5) if rng.random() < 0.9 else 0.0)), float(np.float32(rng.uniform(0, 1)))
+                lib.zlo_positions_set_gain_and_progress(C.byref(oc.positions), pid, C.c_float(g), C.c_float(p), now)
+                nm.set_gain_and_progress(pid, g, p, now)
+        else:
+            pid = held.pop(int(rng.integers(0, len(held))))
+            lib.zlo_positions_remove(C.byref(oc.positions), pid, now)
+            nm.remove(pid, now)
+        for i in range(32):
+            r = oc.positions.pos[i]
+            assert (r.id, r.progress, r.gain, r.lastUpdated) == (nm.rows[i]["id"], nm.rows[i]["progress"], nm.rows[i]["gain"], nm.rows[i]["updated"]) or \
+                (r.id == -1 and nm.rows[i]["id"] == -1 and r.gain == nm.rows[i]["gain"]), (step, i)
+        want = lib.zlo_sync_audio_level(C.byref(om), C.byref(oc), now, C.byref(val))
+        got = nmeter.sync_audio_level(nm, now)
+        assert (got is not None) == bool(want) and (not want or val.value == got), (step, val.value, got)
+        fired += int(bool(want))
+        want = lib.zlo_sync_progress(C.byref(om), C.byref(oc), 1 if has_cb else 0, now, C.byref(val))
+        got = nmeter.sync_progress(nm, oc.startPositionInSeconds, oc.duration, has_cb, now)
+        assert (got is not None) == bool(want) and (not want or val.value == got), (step, val.value, got)
+        assert lib.zlo_positions_peak_gain(C.byref(oc.positions)) == nm.peak_gain()
+        assert lib.zlo_positions_first_progress(C.byref(oc.positions)) == nm.first_progress()
+    assert fired > 20 and len(held) >= 0

@@ -279,6 +279,24 @@ class Voice:
         self.adsr.set_parameters(*clip.adsr)
         self.adsr.note_on()
 
+    def set_current_command(self, cmd):                                   # :58-100, on a voice that HAS a command: a patch
+        if cmd.change_looping:
+            self.cmd.looping = cmd.looping; self.cmd.change_looping = True
+        if cmd.change_pitch:
+            self.cmd.pitch_change = cmd.pitch_change; self.cmd.change_pitch = True
+        if cmd.change_speed:
+            self.cmd.speed_ratio = cmd.speed_ratio; self.cmd.change_speed = True
+        if cmd.change_gain_db:
+            self.cmd.gain_db = cmd.gain_db; self.cmd.change_gain_db = True
+        if cmd.change_volume:
+            self.cmd.volume = cmd.volume; self.cmd.change_volume = True
+            self.lgain = f32(cmd.volume)
+            self.rgain = f32(cmd.volume)
+        if cmd.change_slice:
+            self.cmd.slice = cmd.slice
+        if cmd.start and self.sound is not None:                          # "restart playback": back to the start of the voice's slice (:86-91)
+            self.P = f64(int(f64(self.clip.get_start(self.cmd.slice)) * f64(self.sound.sample_rate)))
+
     def stop_note(self, tail):                                            # :146-169
         if tail:
             self.adsr.note_off()
@@ -424,14 +442,34 @@ class Synth:
         else:
             for v in voices:
                 if v.sound is snd and v.cmd is not None and v.cmd.equivalent(cmd):
-                    if cmd.change_looping:
-                        v.cmd.looping = cmd.looping
-                    if cmd.change_volume:
-                        v.cmd.volume = cmd.volume
-                        v.lgain = f32(cmd.volume)
-                        v.rgain = f32(cmd.volume)
-                    if cmd.change_slice:
-                        v.cmd.slice = cmd.slice
+                    v.set_current_command(cmd)
+
+    # the voice-level surface (juce::SynthesiserVoice calls the sampler makes on ONE voice): bus / slot address a voice directly
+    def update_voice(self, bus, slot, cmd: Command):
+        v = self.voices[bus][slot]
+        if v.is_playing:
+            v.set_current_command(cmd)
+
+    def stop_voice(self, bus, slot, tail):
+        v = self.voices[bus][slot]
+        if v.is_playing:
+            v.stop_note(tail)
+
+    def start_voice(self, bus, slot, cmd: Command, tick=0):
+        """the engine's zlhip_start_voice: handleCommand's start with the slot given (stop handling as handleCommand)"""
+        if not (0 <= cmd.clip < len(self.clips)):
+            return
+        snd = self.sounds[cmd.clip]
+        if cmd.stop:
+            for v in self.voices[bus]:
+                if v.sound is snd and v.cmd is not None and v.cmd.equivalent(cmd):
+                    v.stop_note(True)
+        v = self.voices[bus][slot]
+        if cmd.start and not v.is_playing:
+            v.cmd = Command(**cmd.__dict__)
+            v.is_playing = True
+            v.start_tick = tick
+            v.start_note(cmd.midi_note, cmd.volume, snd, self.clips[cmd.clip], self.fs)
 
     def process(self, nframes, clk: Clock):                               # SamplerSynth.cpp:116-148
         L = np.zeros((self.B, nframes), dtype=np.float32)

@@ -58,6 +58,12 @@ def run_numpy(scene):
                 _copy_clip(ref.clips[ev[1]], syn.clips[ev[1]])
             elif ev[0] == "enable":
                 syn.enabled[ev[1]] = bool(ev[2])
+            elif ev[0] == "start":
+                syn.start_voice(ev[1], ev[2], _np_command(ev[3]), ev[4])
+            elif ev[0] == "update":
+                syn.update_voice(ev[1], ev[2], _np_command(ev[3]))
+            elif ev[0] == "stopv":
+                syn.stop_voice(ev[1], ev[2], bool(ev[3]))
             else:
                 raise AssertionError(ev[0])
         ck = scene.make_clocks(k, 1)[0]
@@ -144,3 +150,37 @@ def test_positions_model_and_meter_chain_twins_agree(seed):
         assert lib.zlo_positions_peak_gain(C.byref(oc.positions)) == nm.peak_gain()
         assert lib.zlo_positions_first_progress(C.byref(oc.positions)) == nm.first_progress()
     assert fired > 20 and len(held) >= 0
+
+
+def _compare(sc):
+    obus, orep, osyn = run_oracle(sc)
+    nbus, nrep, nsyn = run_numpy(sc)
+    assert np.abs(obus).max() > 0
+    assert np.array_equal(obus.view(np.int32), nbus.view(np.int32)), f"first difference at {np.argwhere(obus != nbus)[:2].tolist()}"
+    VPB = sc.voices_per_bus
+    for b in range(sc.num_buses):
+        for i, v in enumerate(nsyn.voices[b]):
+            ov = osyn.voices[b * VPB + i]
+            assert bool(ov.isPlaying) == bool(v.is_playing), (b, i)
+            if v.is_playing:
+                assert ov.sourceSamplePosition == float(v.P), (b, i)
+
+
+def _edge_names():
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from edge_scenes import SCENES
+    return sorted(SCENES)
+
+
+@pytest.mark.parametrize("name", _edge_names())
+def test_edge_scenes_on_the_numpy_twin(name):
+    """The hand-made edge scenes (tests/edge_scenes.py) that the engine and the host harness are held to the C oracle with -- here the C
+    oracle itself against its numpy twin: the voice-level calls (setCurrentCommand with restart, stopNote with and without a tail),
+    disabled channels, clip edits under playing loops, slices, envelope limits, the moving playhead."""
+    from edge_scenes import SCENES
+    sc = SCENES[name]()
+    if sc.nblocks * sc.nframes > 40000:
+        sc.nblocks = 40000 // sc.nframes                          # (the twin steps frame by frame in Python)
+        sc.events = {k: v for k, v in sc.events.items() if k < sc.nblocks}
+    _compare(sc)

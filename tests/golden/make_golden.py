@@ -59,7 +59,21 @@ def run_scene(name, *, B, VPB, fs, mode, nframes, nblocks, sounds, clips, events
         for ev in events.get(k, []):
             ev = dict(ev)
             tick = ev.pop("tick", 0)
-            syn.handle(nr.Command(**{kk: (f32(vv) if kk == "volume" else vv) for kk, vv in ev.items()}), tick)
+            kind = ev.pop("kind", "cmd")                            # "cmd" (SamplerSynth::handleClipCommand) | "start" / "update" / "stopv" (one voice) | "enable"
+            if kind == "enable":
+                syn.enabled[ev["bus"]] = bool(ev["on"])
+                continue
+            if kind == "stopv":
+                syn.stop_voice(ev["bus"], ev["slot"], bool(ev["tail"]))
+                continue
+            bus, slot = ev.pop("bus", None), ev.pop("slot", None)
+            cmd = nr.Command(**{kk: (f32(vv) if kk in ("volume", "pitch_change", "speed_ratio", "gain_db") else vv) for kk, vv in ev.items()})
+            if kind == "start":
+                syn.start_voice(bus, slot, cmd, tick)
+            elif kind == "update":
+                syn.update_voice(bus, slot, cmd)
+            else:
+                syn.handle(cmd, tick)
         clk = clocks_for(k, nframes, fs, bpm, playhead, block0)
         clock_rows.append([clk.current_usecs, clk.next_usecs, clk.playhead, clk.playhead_usecs, clk.subbeat_usecs])
         L, R, reports = syn.process(nframes, clk)
@@ -298,7 +312,51 @@ def command_patch_goldens():
                   sounds=[(a[0], a[1], 48000.0), (b[0], b[1], 44100.0), (c[0], None, 48000.0)], clips=clips, events=events)
 
 
+def voice_level_goldens():
+    """g11: the voice-level calls and SamplerSynth::setChannelEnabled, which no other golden has -- setCurrentCommand on one playing voice
+    with every patch, among them startPlayback = restart at the start of the voice's slice and changeSlice + startPlayback = jump to
+    another slice (SamplerSynthVoice.cpp:58-100); stopNote with a tail and without (:146-169); a channel switched off while a loop, an
+    envelope in its attack and a beat-locked loop play on it, a voice started on it meanwhile, a stop that releases an envelope which
+    stands still, and everything going on when the channel comes back (SamplerSynth.cpp:116-123,343-351)."""
+    rng = np.random.default_rng(0x611)
+
+    def src(n, stereo=True):
+        L = rng.uniform(-1, 1, n).astype(np.float32)
+        return (L, rng.uniform(-1, 1, n).astype(np.float32) if stereo else None)
+
+    play = lambda clip, ch=-2, loop=True, note=60, vol=1.0, **kw: dict(clip=clip, midi_channel=ch, midi_note=note, start=True, stop=loop,
+                                                                      looping=loop, change_volume=True, volume=vol, **kw)
+    a, b, c = src(3100), src(2700, stereo=False), src(3500)
+    tbl = nr.Clip()
+    for n in (16, 4):
+        tbl.set_slices(n)
+    clips = [dict(length_beats=0.37, length_sec=0.05, volume_abs=0.8, pan=-0.2, adsr=(0.0, 0.1, 1.0, 0.004), slice_pos=tbl.slice_pos),
+             dict(length_beats=1.0, length_sec=0.04, volume_abs=0.9, pan=0.3, adsr=(0.0, 0.1, 1.0, 0.006)),            # beat-locked
+             dict(length_beats=0.29, length_sec=0.06, volume_abs=0.7, pan=0.0, adsr=(0.012, 0.01, 0.6, 0.006))]
+    ev = {
+        0: [dict(play(0, ch=-2, note=60, vol=0.8), kind="start", bus=0, slot=0), dict(play(0, ch=-2, note=64, vol=0.7, change_slice=True, slice=1), kind="start", bus=0, slot=2),
+            dict(play(1, ch=-1, note=62, vol=0.7), kind="cmd"), dict(play(2, ch=-1, loop=False, note=57, vol=0.9), kind="cmd"), dict(play(2, ch=0, note=66, vol=0.5), kind="cmd")],
+        4: [dict(kind="update", bus=0, slot=0, clip=0, midi_channel=-2, midi_note=60, start=True),                                      # restart from the top
+            dict(kind="update", bus=0, slot=1, clip=0, midi_channel=-2, midi_note=60, change_volume=True, volume=0.1)],                   # slot 1 does not play
+        5: [dict(kind="enable", bus=1, on=False)],
+        7: [dict(kind="update", bus=0, slot=2, clip=0, midi_channel=-2, midi_note=64, change_slice=True, slice=3, start=True, change_volume=True, volume=0.4)],
+        8: [dict(play(0, ch=-1, note=67, vol=0.5), kind="cmd"), dict(kind="cmd", clip=1, midi_channel=-1, midi_note=62, change_volume=True, volume=0.2)],
+        11: [dict(kind="stopv", bus=2, slot=0, tail=False), dict(kind="stopv", bus=0, slot=3, tail=True)],                               # hard stop mid-loop; slot 3 does not play
+        14: [dict(kind="cmd", clip=2, midi_channel=-1, midi_note=57, stop=True)],                                                         # releases an envelope that stands still
+        16: [dict(kind="stopv", bus=0, slot=0, tail=True), dict(play(1, ch=0, note=55, vol=0.6), kind="start", bus=2, slot=0)],           # the freed slot is taken again
+        30: [dict(kind="enable", bus=1, on=True)],
+        40: [dict(kind="enable", bus=0, on=False), dict(kind="enable", bus=2, on=False)],
+        44: [dict(kind="enable", bus=0, on=True), dict(kind="update", bus=2, slot=0, clip=1, midi_channel=0, midi_note=55, change_looping=True, looping=False)],
+        50: [dict(kind="enable", bus=2, on=True)],
+    }
+    for mode, nm in ((0, "g11_voice_level_and_channels"), (4, "g11_voice_level_and_channels_hermite")):
+        run_scene(nm, B=3, VPB=4, fs=48000.0, mode=mode, nframes=128, nblocks=60, bpm=200,
+                  sounds=[(a[0], a[1], 48000.0), (b[0], None, 44100.0), (c[0], c[1], 48000.0)], clips=clips, events=ev)
+
+
 def main():
+    if "--voice-level" in sys.argv:
+        return voice_level_goldens()
     if "--config1" in sys.argv:
         return config1_full_shape()
     if "--patches" in sys.argv:

@@ -49,8 +49,21 @@ def load_golden(name):
         for ev in evs:
             ev = dict(ev)
             tick = ev.pop("tick", 0)
+            kind = ev.pop("kind", "cmd")
+            if kind == "enable":
+                lst.append(("enable", ev["bus"], bool(ev["on"])))
+                continue
+            if kind == "stopv":
+                lst.append(("stopv", ev["bus"], ev["slot"], bool(ev["tail"])))
+                continue
+            bus, slot = ev.pop("bus", None), ev.pop("slot", None)
             fields = {_MAP[a]: (1 if b is True else 0 if b is False else b) for a, b in ev.items()}
-            lst.append(("cmd", fields, tick))
+            if kind == "start":
+                lst.append(("start", bus, slot, fields, tick))
+            elif kind == "update":
+                lst.append(("update", bus, slot, fields))
+            else:
+                lst.append(("cmd", fields, tick))
         sc.events[int(k)] = lst
     clocks = z["clocks"]
 

@@ -70,6 +70,25 @@ SOURCE_DEPS = {
 }
 
 
+def _write_kernel_resources(remarks: str, path: str) -> None:
+    """The compiler's per-kernel resource remarks, one line per kernel: name, VGPRs, scratch bytes per lane, waves per SIMD, LDS bytes.
+    tests/test_kernel_resources.py holds the kernels to what DESIGN.md states (the resident kernel without scratch memory, K2 without spills)."""
+    import re
+    rows, cur = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = {"name": m.group(1)}
+            rows.append(cur)
+            continue
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|VGPRs Spill): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0] + ("Spill" if "Spill" in m.group(1) else "")] = int(m.group(2))
+    with open(path, "w") as f:
+        for r in rows:
+            f.write(f"{r['name']} vgprs={r.get('VGPRs', -1)} scratch={r.get('ScratchSize', -1)} waves={r.get('Occupancy', -1)} lds={r.get('LDS', -1)} vgpr_spill={r.get('VGPRsSpill', -1)}\n")
+
+
 def _build_engine(force: bool, verbose: bool, extra: list) -> str:
     """One object per source (cached under lib/obj/<library name>/), then one link: editing the host code does not recompile
     the kernels (two minutes)."""
@@ -98,13 +117,18 @@ def _build_engine(force: bool, verbose: bool, extra: list) -> str:
         deps = [src, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in SOURCE_DEPS.get(name, HEADERS)]
         if force or _stale(obj, deps):
             cmd = common + ["-x", "hip", "-c", src, "-o", obj]
+            kernels = name.endswith(".hip")
+            if kernels:
+                cmd.append("-Rpass-analysis=kernel-resource-usage")      # registers / scratch / occupancy of every kernel -> kernel_resources.txt
             if verbose:
                 print(" ".join(cmd), flush=True)
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 sys.stderr.write(res.stdout + res.stderr)
                 raise RuntimeError(f"hipcc failed compiling {name}")
-            if verbose and res.stderr:
+            if kernels:
+                _write_kernel_resources(res.stderr, os.path.join(os.path.dirname(LIB), os.path.splitext(os.path.basename(LIB))[0] + "_kernel_resources.txt"))
+            elif verbose and res.stderr:
                 sys.stderr.write(res.stderr)
             rebuilt = True
         objs.append(obj)

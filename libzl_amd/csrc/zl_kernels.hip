@@ -1326,9 +1326,10 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         // ---- K1: one lane per voice of the workgroup, the single block of this cycle
         for (int v = vbeg + tid; v < vend; v += (int)blockDim.x) {
             ZlPlanner pl;
-            pl.begin(A, v, 0);
-            while (pl.t < A.N) pl.iterate(A, 1, &s_clk0, 0, 0);
-            pl.end(A);
+            // (inlined here: as calls, the planner object and the cycle's ZlBatch live in scratch memory, 1 KB per lane)
+            [[clang::always_inline]] pl.begin(A, v, 0);
+            while (pl.t < A.N) { [[clang::always_inline]] pl.iterate(A, 1, &s_clk0, 0, 0); }
+            [[clang::always_inline]] pl.end(A);
         }
         __threadfence_block();
         __syncthreads();
@@ -1338,7 +1339,7 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
             const int v = v0 + tid;
             const bool mine = v < vend;
             ZlAssembler as;
-            as.begin(A, mine ? v : vbeg, 0, mine ? 1 : 0);
+            [[clang::always_inline]] as.begin(A, mine ? v : vbeg, 0, mine ? 1 : 0);
             zl_k1c_block(A, as, v, lane, 0);
         }
         __threadfence_block();

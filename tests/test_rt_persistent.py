@@ -388,3 +388,35 @@ def test_more_voice_operations_in_a_cycle_than_the_mapped_buffers_hold(built, rt
     for v in range(96):
         assert bool(ref_syn.voices[v].isPlaying) == bool(rep[v].playing)
     assert cycles == 16 and starts >= 2                            # (the kernel was restarted by the growth)
+
+
+def test_the_period_changes_between_cycles(built, rt_env):
+    """JACK renegotiates its buffer size: cycles of 256, 100, 32, 17 ... frames on ONE engine, in any order.  The resident kernel is started
+    again whenever the period changes (its workgroup size is the period rounded up to whole waves); every cycle is the oracle's."""
+    from libzl_amd import SamplerSynth
+    from libzl_amd._abi import Clock
+    from oracle import zl_oracle as zo
+    sc = random_scene(431, num_buses=4, voices_per_bus=8, nclips=12, nframes=64, nblocks=1, events=False)
+    ref = zo.OracleSynth(1, 1, sc.fs, sc.mode, max_sounds=16)
+    osyn = zo.OracleSynth(4, 8, sc.fs, sc.mode, max_sounds=16)
+    syn = SamplerSynth(num_buses=4, voices_per_bus=8, max_frames=256, max_batch_blocks=4, max_sounds=16, sound_arena_bytes=1 << 21)
+    for i, (L, R, sr) in enumerate(sc.sounds):
+        assert ref.register_clip(L, R, sr) == i and syn.register_clip(L, R, sr) == i and osyn.register_clip(L, R, sr) == i
+        sc.clip_setup[i](ref.lib, ref.clips[i]); sc.clip_setup[i](osyn.lib, osyn.clips[i])
+        syn.set_clip_params(i, snapshot_clip(ref.clips[i]))
+    from scenario import oracle_cmd
+    for ev in sc.events[0]:
+        syn.handle_clip_command(engine_cmd(**ev[1]), ev[2]); osyn.handle_clip_command(oracle_cmd(**ev[1]), ev[2])
+    periods = [256, 100, 100, 32, 17, 256, 64, 1, 200, 32, 32, 255, 128, 100, 256, 48] * 3
+    t = 0
+    for k, N in enumerate(periods):
+        per = int(round(1e6 * N / sc.fs))
+        clk = Clock(); clk.current_usecs = t; clk.next_usecs = t + per; clk.jack_playhead = 0; clk.jack_playhead_usecs = 0
+        clk.jack_subbeat_length_usecs = ((60000000000) // (sc.bpm * 96)) // 1000
+        t += per
+        L, R = syn.process(N, clk)
+        bus, _ = osyn.render_batch(1, N, [clk])
+        assert np.array_equal(L.view(np.int32), bus[:, 0].view(np.int32)) and np.array_equal(R.view(np.int32), bus[:, 1].view(np.int32)), (k, N)
+    starts, cycles = syn.rt_stats()
+    syn.close()
+    assert cycles == len(periods) and starts >= 30                 # one start per change of period

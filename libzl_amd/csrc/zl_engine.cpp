@@ -143,7 +143,7 @@ struct zlhip_engine {
 
     // resident real-time kernel (zl_k_rt_loop): the mailbox in mapped host memory, its stream, what it was launched for
     struct Rt {
-        bool enabled = false, running = false, wide = false;
+        bool enabled = false, running = false; int wide = -1;    // wide: 1 always, 0 never, -1 only with one voice per workgroup
         ZlRtShared *h = nullptr, *d = nullptr;
         ZlRtDev *dev = nullptr;                            // the kernel's own hand-off words in HBM
         ZlOpRange *devRanges = nullptr;                    // wide buses: workgroup 0's copy of a block's operation ranges
@@ -557,11 +557,14 @@ int zlhip_engine_create(const zlhip_config *cfg_in, zlhip_engine **out)
         // ZL_RT_PERSISTENT=0 keeps the launched path
         const char *rp = std::getenv("ZL_RT_PERSISTENT");
         e->rt.enabled = !(rp && std::atoi(rp) == 0);
-        // ZL_RT_WIDE=1: wide buses (32 voices and more) through the resident kernel too, a workgroup per few voices.  Built, exact,
-        // and measured SLOWER than launches (1024 voices on 8 buses: 100 against 53 us; 256 voices: 66 against 44) -- every resident
-        // workgroup walks the K0..K2 latency chain of its voices alone, where a launch runs a thousand of them side by side: opt-in
+        // Wide buses (32 voices and more) through the resident kernel too, a workgroup per few voices.  With ONE voice per workgroup
+        // (engines of up to ~384 voices) it equals the launched path's median and has a far shorter tail (256 voices: 46 / 50 us p50 / p99
+        // against 45 / 80): the default there.  With 2-8 voices per workgroup (1024 voices = 256 workgroups of 4) every workgroup walks
+        // the K2 chain of its voices one after the other: 73 / 77 us against 55 / 84 -- a better tail, a worse median: opt-in.
+        // ZL_RT_WIDE=1: whenever the device holds the workgroups; =0: never; unset: one voice per workgroup only.
+        // (profiles/round3_rt_inline_ab.txt; before the kernel lost its scratch memory the figures were 100 against 53 and 66 against 44.)
         const char *rw = std::getenv("ZL_RT_WIDE");
-        e->rt.wide = rw && std::atoi(rw) == 1;
+        e->rt.wide = rw ? (std::atoi(rw) == 1 ? 1 : 0) : -1;
         e->rt.stampsOn = std::getenv("ZL_RT_STAMPS") != nullptr;
         if (cfg->rt_idle_timeout_us > 0) e->rt.idleTicks = (unsigned long long)cfg->rt_idle_timeout_us * 100ull;   // 100 MHz counter
     }
@@ -1274,7 +1277,7 @@ static bool rt_eligible(zlhip_engine *e, int nframes)
     // no debug trace
     if (!(e->rt.enabled && nframes <= 256 && e->cfg.voices_per_task <= 0 && !e->trace)) return false;
     const bool wide = rt_wide(e);
-    if (wide && !e->rt.wide) return false;                         // opt-in (ZL_RT_WIDE=1): measured slower than launches
+    if (wide && e->rt.wide == 0) return false;
     if (e->cfg.num_buses > (wide ? ZL_RT_MAX_BUSES : 64)) return false;
     int &cap = e->rt.capacity[wide ? 1 : 0];
     if (cap < 0) cap = zl_rt_loop_capacity(e->cfg.mode, wide ? 1 : 0, 256, e->device);
@@ -1286,7 +1289,7 @@ static bool rt_eligible(zlhip_engine *e, int nframes)
         for (int vw = 1; vw <= 8; vw *= 2)
             if (e->cfg.voices_per_bus % vw == 0 && (long long)(e->V / vw) * 4 <= (long long)cap * 3) { e->rt.vw = vw; break; }
     }
-    return e->rt.vw > 0;
+    return e->rt.vw > 0 && (e->rt.wide == 1 || e->rt.vw == 1);     // (several voices per workgroup: opt-in, see zlhip_engine_create)
 }
 
 #define ZL_RT_BUSY 1     // rt_start / rt_render: a device-synchronising call is in progress somewhere in the process -- render this cycle with launches

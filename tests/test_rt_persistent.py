@@ -420,3 +420,22 @@ def test_the_period_changes_between_cycles(built, rt_env):
     starts, cycles = syn.rt_stats()
     syn.close()
     assert cycles == len(periods) and starts >= 30                 # one start per change of period
+
+
+def test_wide_buses_with_one_voice_per_workgroup_are_resident_by_default(built, rt_env):
+    """No ZL_RT_WIDE: an engine whose voices each get a resident workgroup of their own (4 buses x 32 voices here) renders its cycles through
+    the resident kernel -- same median as the launched path, a far shorter tail --; one that would need several voices per workgroup
+    (8 x 128) keeps the launched path.  Exact either way."""
+    old = os.environ.pop("ZL_RT_WIDE", None)
+    try:
+        for buses, vpb, resident in ((4, 32, True), (8, 128, False)):
+            sc = random_scene(440 + vpb, num_buses=buses, voices_per_bus=vpb, nclips=min(buses * vpb, 120), nframes=128, nblocks=14)
+            ref_bus, ref_rep, ref_syn = run_oracle(sc, threads=8)
+            bus, rep, syn = _play_blockwise(sc)
+            starts, cycles = syn.rt_stats()
+            syn.close()
+            assert np.array_equal(bus.view(np.int32), ref_bus.view(np.int32)), (buses, vpb)
+            assert (cycles == sc.nblocks and starts >= 1) if resident else (cycles == 0 and starts == 0), (buses, vpb, starts, cycles)
+    finally:
+        if old is not None:
+            os.environ["ZL_RT_WIDE"] = old

@@ -241,7 +241,7 @@ int zlsim_reports(ZlSim *S, zlhip_voice_report *out)
 {
     for (int v = 0; v < S->V; ++v) {
         const ZlReport &r = S->reports[(size_t)v];
-        out[v].playing = r.playing; out[v].valid = r.valid;
+        out[v].playing = r.playing ? 1 : 0; out[v].valid = r.valid;
         out[v].gain = r.valid ? __builtin_bit_cast(float, r.peak_bits) * 0.5f : 0.0f;
         out[v].progress = r.progress; out[v].clip = r.clip; out[v].reserved = 0; out[v].source_sample_position = r.P;
     }

@@ -1480,7 +1480,8 @@ int zlhip_voice_reports(zlhip_engine *e, zlhip_voice_report *out, int32_t count)
     for (int v = 0; v < e->V; ++v) {
         const ZlReport &r = e->latest->hReports[v];
         zlhip_voice_report &o = out[v];
-        o.playing = r.playing ? 1 : 0; o.valid = r.valid;       // (2 inside the engine: playing on a disabled bus) o.gain = r.valid ? e->latest->hGain[v] : 0.0f; o.progress = r.progress;
+        // (playing is 2 inside the engine for a voice on a disabled bus)
+        o.playing = r.playing ? 1 : 0; o.valid = r.valid; o.gain = r.valid ? e->latest->hGain[v] : 0.0f; o.progress = r.progress;
         o.clip = r.clip; o.reserved = 0; o.source_sample_position = r.P;
     }
     return ZLHIP_OK;

@@ -39,6 +39,17 @@ def test_every_declared_symbol_is_exported(lib):
     assert total >= 30
 
 
+def test_headers_are_strict_c_and_cpp(tmp_path):
+    """the boundary is a C ABI: both headers compile as pedantic C99 / C11 and as C++11 (what a cgo / JNI / ctypes-less host would include)"""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "p.c"
+    src.write_text('#include "zlhip.h"\n#include "libzl_hotpath.h"\nint main(void) { return zlhip_abi_version() == 0 && libzl_hotpath_status() == 12345; }\n')
+    for cmd in (["gcc", "-std=c99"], ["gcc", "-std=c11"], ["g++", "-std=c++11", "-x", "c++"]):
+        res = subprocess.run(cmd + ["-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
+        assert res.returncode == 0, " ".join(cmd) + "\n" + res.stderr
+
+
 def test_binding_table_covers_zlhip_header(lib):
     declared = set(declared_functions(os.path.join(ROOT, "include", "zlhip.h")))
     assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)

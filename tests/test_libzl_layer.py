@@ -469,8 +469,19 @@ def test_the_librarys_own_transport_matches_the_oracle_sync_timer(zl):
             if k == 250:
                 zl.SyncTimer_queueClipToStopOnChannel(clips[3][0], 4); st.queue_stop(clips[3][1], 4)
                 zl.ClipAudioSource_play(clips[0][0], True); st.schedule(host.play(clips[0][1], True), 0)
+            if k == 60:                                               # one more tick of the timer thread (it has caught up already: no new beats)
+                zl.libzl_hotpath_timer_tick(); st.timer_callback()
+            if k == 300:                                              # the wrappers without a channel: channel -1 (SyncTimer.cpp:862-868)
+                zl.SyncTimer_queueClipToStart(clips[1][0]); st.queue_start(clips[1][1], -1)
+            if k == 322:
+                zl.SyncTimer_queueClipToStop(clips[1][0]); st.queue_stop(clips[1][1], -1)
             if k == 330:
                 zl.SyncTimer_stopTimer(); st.stop()
+            if k == 400:                                              # libzl.h stopClips: ClipAudioSource::stop on each (libzl.cpp:87-94)
+                arr = (C.c_void_p * 2)(clips[0][0], clips[2][0])
+                zl.stopClips(2, arr)
+                for _, oid in (clips[0], clips[2]):
+                    [st.schedule(c, 0) for c in host.stop(oid)]
             cu, nx = t0 + k * per, t0 + (k + 1) * per
             for cm, tick in st.process(N, cu, nx):
                 host.osyn.handle_clip_command(cm, tick)
@@ -489,7 +500,7 @@ def test_the_librarys_own_transport_matches_the_oracle_sync_timer(zl):
             if k == 200:
                 zl.SyncTimer_deregisterTimerCallback(tcb)
                 n200 = len(want_beats)
-        assert ndisp >= 6 and host.voices_playing(clips[0][1]) >= 1
+        assert ndisp >= 6
         assert got_beats == want_beats[:n200] and len(got_beats) > 150
         st.close()
         for c, _ in clips:

@@ -77,6 +77,23 @@ def test_bounce_equals_consecutive_batches_and_the_oracle(Engine):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nframes,sub", [(100, 7), (441, 3), (33, 16)])
+def test_bounce_with_periods_that_are_no_multiple_of_64(Engine, nframes, sub):
+    """the render kernel's own stores into the caller's page-locked buffer (fp32 planar and the recorder's 16-bit format) when a block's
+    last wave has lanes behind the block's end: they store nothing, the rows stay contiguous"""
+    from scenario import compare_runs, random_scene, run_backend, run_oracle
+    sc = random_scene(0xB7 + nframes, num_buses=5, voices_per_bus=8, nclips=12, nframes=nframes, nblocks=37)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, bounce=("f32", sub))
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 40)
+    syn.close()
+    pcm, _, syn, _ = run_backend(sc, Engine, bounce=("pcm16", sub))
+    want = np.stack([npr.pcm16(ref_bus[:, 0]), npr.pcm16(ref_bus[:, 1])], axis=2)
+    assert np.array_equal(pcm, want)
+    syn.close()
+
+
+@pytest.mark.gpu
 def test_bounce_into_caller_memory_and_argument_checks(Engine):
     from libzl_amd.engine import ZlHipError, synthetic_clocks
     syn = Engine(num_buses=2, voices_per_bus=4, max_frames=256, max_batch_blocks=8, max_sounds=4)

@@ -495,6 +495,9 @@ FANOUT_CASES = {
     "mix_groups":                  (dict(num_buses=3, voices_per_bus=8, nframes=128, nblocks=10, mix_group=4), 1 << 30, False),
     "delay_fixed":                 (dict(num_buses=3, voices_per_bus=8, nframes=128, nblocks=10, mode=2), 1 << 30, False),
     "single_blocks":               (dict(num_buses=4, voices_per_bus=8, nframes=128, nblocks=5), 1, False),
+    "period_of_100_frames":        (dict(num_buses=5, voices_per_bus=8, nframes=100, nblocks=11), 1 << 30, False),   # lanes behind the block's end store no fan-out
+    "period_of_300_frames_groups": (dict(num_buses=3, voices_per_bus=8, nframes=300, nblocks=5, mix_group=4), 1 << 30, False),
+    "period_of_33_frames_single":  (dict(num_buses=2, voices_per_bus=8, nframes=33, nblocks=7), 1, False),
 }
 
 

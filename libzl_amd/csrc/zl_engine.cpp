@@ -1579,7 +1579,7 @@ int zlhip_block_peaks(zlhip_engine *e, int32_t *out, size_t out_ints)
 
 int zlhip_levels_scan_device(zlhip_engine *e, const float *bus_dev, int32_t nblocks, int32_t nframes, void *stream)
 {
-    if (!e || !bus_dev || nblocks < 1 || nblocks > e->cfg.max_batch_blocks || nframes < 64 || nframes > e->cfg.max_frames) return ZLHIP_ERR_INVALID;
+    if (!e || !bus_dev || nblocks < 1 || nblocks > e->cfg.max_batch_blocks || nframes < 1 || nframes > e->cfg.max_frames) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     ZlBatch A; std::memset(&A, 0, sizeof A);
@@ -1597,7 +1597,7 @@ int zlhip_bus_reduce_sum_scan(zlhip_engine *e, const float *pieces_dev, int32_t 
                               int32_t nframes, float *sum_out_dev, zlhip_unit_levels *levels_out_dev, void *stream)
 {
     static_assert(sizeof(zlhip_unit_levels) == sizeof(ZlUnitLevels), "ABI mirror");
-    if (!e || !pieces_dev || !sum_out_dev || !levels_out_dev || npieces < 1 || units < 1 || nframes < 64 || (nframes % 64) != 0
+    if (!e || !pieces_dev || !sum_out_dev || !levels_out_dev || npieces < 1 || units < 1 || nframes < 1
         || piece_stride_floats < units * (int64_t)nframes) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
@@ -1611,7 +1611,7 @@ int zlhip_bus_reduce_sum_scan(zlhip_engine *e, const float *pieces_dev, int32_t 
 
 int zlhip_levels_import_units(zlhip_engine *e, const zlhip_unit_levels *units_dev, int32_t nblocks, int32_t nframes, void *stream)
 {
-    if (!e || !units_dev || nblocks < 1 || nblocks > e->cfg.max_batch_blocks || nframes < 64 || nframes > e->cfg.max_frames) return ZLHIP_ERR_INVALID;
+    if (!e || !units_dev || nblocks < 1 || nblocks > e->cfg.max_batch_blocks || nframes < 1 || nframes > e->cfg.max_frames) return ZLHIP_ERR_INVALID;
     ZL_HIP(e, hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     ZL_KERNEL(e, zl_launch_levels_import(reinterpret_cast<const ZlUnitLevels *>(units_dev), e->dLevels, e->cfg.num_buses, nblocks, s));

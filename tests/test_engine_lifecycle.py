@@ -144,7 +144,7 @@ def test_device_upload_is_ordered_behind_its_producer(Engine):
     syn.close()
 
 
-@pytest.mark.parametrize("npieces,nframes,mode", [(2, 128, 0), (8, 256, 0), (3, 64, 2), (11, 512, 0)])
+@pytest.mark.parametrize("npieces,nframes,mode", [(2, 128, 0), (8, 256, 0), (3, 64, 2), (11, 512, 0), (4, 100, 0), (3, 33, 2), (2, 441, 0)])
 def test_bus_reduce_sum_scan_kernel(Engine, npieces, nframes, mode):
     """zlhip_bus_reduce_sum_scan: the rank-order sum of received pieces and the level scan of every unit in one kernel, and
     zlhip_levels_import_units on the root -- against the defined arithmetic: ((0 + p0) + p1) + ... in fp32, integer peaks,

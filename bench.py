@@ -230,6 +230,129 @@ def cpu_baseline(args, seed):
     }
 
 
+def span_buses_leg(args, torch, dist, sharding, syn, dev, stream, clock_sets, rank, world, log):
+    """The job seen as --buses buses that each SPAN all ranks (BASELINE configs[3]: one stereo bus over 8 GPUs): every rank's
+    rendered bus is a partial bus, the partial buses are exchanged and summed -- the path's only coupling, SamplerSynth.cpp:134-140
+    -- once with the mesh exchange (RCCL all-to-all over the point-to-point xGMI links, zlhip_bus_reduce_sum_scan in rank order on
+    every rank's piece, gather on rank 0) and once with one plain RCCL reduce; the exchange of step i overlaps the rendering of
+    step i + 1 (OverlappedBusReduce).  Per algorithm: K steps timed like the headline (barrier + synchronize both sides, max
+    over ranks), the exchange alone (no rendering), and an output check on rank 0: the reduced rows of one more step against the
+    rank-order sum of every rank's partial rows (gathered), bit for bit for the mesh exchange, within 1e-6 of the summed
+    magnitudes for RCCL's own order.  (Every rank's partial rows are what the headline's output check holds against the oracle.)"""
+    V, B, N, KB = args.voices, args.buses, args.frames, args.blocks_per_step
+    steps = args.span_steps or args.steps
+    nccl = args.dist_backend == "nccl"
+    sptr = stream.cuda_stream
+    bus_bytes = B * 2 * KB * N * 4
+    rec = {"what": f"{B} buses spanning all {world} ranks ({V * world} voices, {V} per rank): partial buses of {bus_bytes / 1e6:.0f} MB per rank and step "
+                   "exchanged and summed on rank 0, exchange of step i overlapped with the rendering of step i+1",
+           "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "steps": steps, "warmup": args.warmup,
+           "partial_bus_bytes_per_rank": bus_bytes}
+    rng = np.random.default_rng(0xB05 + world)                        # the same rows on every rank
+    picks = sorted((int(rng.integers(0, B)), int(rng.integers(0, KB))) for _ in range(3))
+
+    def region_time(fn, after=None):
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        if after is not None:
+            after()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def host_exchange(algo, b):
+        # rehearsal backends (gloo): the exchange runs on a host copy of the partial bus
+        torch.cuda.synchronize()
+        host = b.cpu()
+        (sharding.reduce_bus_mesh if algo == "mesh" else sharding.reduce_bus)(host, dst=0)
+        if rank == 0:
+            b.copy_(host)
+            syn.levels_scan_device(b.data_ptr(), KB, N, stream=sptr)
+
+    def one(algo):
+        r = {"algorithm": algo}
+        make = lambda: torch.zeros((B, 2, KB * N), device=dev, dtype=torch.float32)
+        if nccl:
+            ov = sharding.OverlappedBusReduce(syn, make, dst=0, algorithm=algo)
+            for i in range(max(1, args.warmup)):
+                _, ov = ov.step_or_fall_back(KB, N, clock_sets[i % len(clock_sets)], stream=sptr, log=log)
+            ov.flush(stream=sptr)
+            r["algorithm"] = ov.algorithm                              # "reduce" if this RCCL build refused the mesh exchange's collectives
+            dt = region_time(lambda i: ov.step(KB, N, clock_sets[i % len(clock_sets)], stream=sptr), after=lambda: ov.flush(stream=sptr))
+            work = ov.bus[0]
+            if ov.algorithm == "mesh":
+                xfn = lambda i: sharding.exchange_bus_mesh(syn, work, KB, N, dst=0, scratch=ov.scratch[0])
+            else:
+                def xfn(i):
+                    dist.reduce(work, dst=0, op=dist.ReduceOp.SUM)
+                    if rank == 0:
+                        syn.levels_scan_device(work.data_ptr(), KB, N, stream=sptr)
+            xfn(0)
+            dx = region_time(xfn)
+        else:
+            work = make()
+            def full(i):
+                syn.render_batch(KB, N, clock_sets[i % len(clock_sets)], bus_out_dev=work.data_ptr(), stream=sptr)
+                host_exchange(algo, work)
+            full(0)
+            dt = region_time(full)
+            dx = region_time(lambda i: host_exchange(algo, work))
+        r["ms_per_step"] = dt / steps * 1e3
+        r["value"] = float(V) * world * KB * N * steps / dt
+        r["exchange_alone_ms_per_step"] = dx / steps * 1e3
+        if r["algorithm"] == "mesh":
+            r["bytes_per_link_per_step"] = {"all_to_all_each_direction": bus_bytes // world, "gather_into_rank_0": bus_bytes // world + (B * 2 * KB // world) * 8,
+                                            "note": "every rank sends 1/N of its partial bus to every peer over that pair's own xGMI link, then its reduced 1/N piece (+ unit levels) to rank 0"}
+        else:
+            r["bytes_per_link_per_step"] = {"whole_partial_bus": bus_bytes, "note": "one RCCL reduce: schedule and order are RCCL's (a ring carries about the whole bus over every link of the ring)"}
+        # ---- output check: one more step, exchange not overlapped
+        chk = make()
+        syn.render_batch(KB, N, clock_sets[-1], bus_out_dev=chk.data_ptr(), stream=sptr)
+        syn.synchronize(); torch.cuda.synchronize()
+        rows = torch.stack([chk[b, :, k * N:(k + 1) * N] for (b, k) in picks]).clone()     # this rank's partial rows
+        if nccl:
+            if r["algorithm"] == "mesh":
+                sharding.exchange_bus_mesh(syn, chk, KB, N, dst=0)
+            else:
+                dist.reduce(chk, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            host_exchange(algo, chk)
+        torch.cuda.synchronize()
+        rows_c = rows if nccl else rows.cpu()
+        parts = [torch.empty_like(rows_c) for _ in range(world)] if rank == 0 else None
+        if world > 1:
+            dist.gather(rows_c, gather_list=parts, dst=0)
+        else:
+            parts = [rows_c]
+        if rank == 0:
+            got = torch.stack([chk[b, :, k * N:(k + 1) * N] for (b, k) in picks]).cpu().numpy()
+            ps = [p.cpu().numpy() for p in parts]
+            acc = np.zeros_like(ps[0])
+            mag = np.zeros_like(ps[0])
+            for p_ in ps:
+                acc = acc + p_                                         # ((0 + p0) + p1) + ... : the kernel's and the oracle's grouped order
+                mag = mag + np.abs(p_)
+            exact = bool(np.array_equal(acc.view(np.int32), got.view(np.int32)))
+            close = bool((np.abs(acc - got) <= 1e-6 * np.maximum(mag, 1.0)).all())
+            r["output_check"] = {"rows": [[int(b), int(k)] for (b, k) in picks], "bit_exact_vs_rank_order_sum": exact, "within_1e-6_of_magnitude": close,
+                                 "max_abs_diff": float(np.abs(acc - got).max()), "peak": float(np.abs(got).max()),
+                                 "ok": exact if r["algorithm"] in ("mesh", "rank-order") else close}
+        del chk
+        return r
+
+    for algo in ("mesh", "reduce"):
+        try:
+            rec[algo] = one(algo)
+        except Exception as err:                                       # (a refusal is synchronous and the same on every rank)
+            rec[algo] = {"algorithm": algo, "error": repr(err)[:400]}
+            if log:
+                log(f"span_buses leg '{algo}' failed: {err!r}")
+    return rec
+
+
 def kernel_source_digest():
     """SHA-256 over the engine's kernel sources: PMC traffic collected for one build is only quoted for the same sources."""
     import hashlib
@@ -241,12 +364,7 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def main():
-    # stdout carries exactly ONE line, the JSON result: whatever native libraries print meanwhile (RCCL's version banner
-    # at communicator creation, for one) goes to stderr
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -278,13 +396,82 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the measured path) or gloo (rehearsal: exchange through host memory)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--span-buses", action="store_true",
-                    help="N > 1 variant: the job has only --buses buses and each spans all ranks (BASELINE configs[3]: one stereo bus over 8 GPUs): "
-                         "every rank renders a partial bus and the pieces are exchanged over xGMI and summed in rank order.  Default for N > 1 is the "
-                         "bus-aligned partition (N x --buses buses, whole buses per GPU): no data-path collective at all (SURVEY 8e)")
+                    help="N > 1 variant: make the spanning-bus exchange the HEADLINE value (the job has only --buses buses and each spans all ranks, "
+                         "BASELINE configs[3]).  By default the headline of an N > 1 run is the bus-aligned partition (N x --buses buses, whole buses "
+                         "per GPU: no data-path collective, SURVEY 8e) and the spanning-bus exchange is measured next to it (`span_buses` sub-record)")
     ap.add_argument("--reduce-algo", default="mesh", choices=["mesh", "reduce", "rank-order"],
                     help="--span-buses: mesh = all-to-all + rank-order sum kernel + gather over the xGMI mesh (default), reduce = one RCCL reduce")
-    ap.add_argument("--rehearse-collectives", action="store_true", help="rehearsal only: run the --span-buses code path with one rank")
-    args = ap.parse_args()
+    ap.add_argument("--no-span-leg", action="store_true", help="N > 1: skip the `span_buses` sub-record (the exchange of buses that span all ranks)")
+    ap.add_argument("--span-steps", type=int, default=0, help="timed steps of each `span_buses` leg (default: --steps)")
+    ap.add_argument("--span-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the `span_buses` legs may take in all; after that the line is printed with what is there and the ranks leave")
+    ap.add_argument("--rehearse-collectives", action="store_true", help="rehearsal only: run the spanning-bus code path with one rank")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU, no engine: start the ranks, form the process group, push a small bus through the exchange's collectives and "
+                         "print a line with n_gpus (CPU-tier check that `bench.py --gpus N` becomes N ranks by itself)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher.  Runs BEFORE torch is imported or
+    HIP is touched in this process (a process that has initialised the GPU must never start or replace GPU programs): N fresh
+    rank processes through `python -m torch.distributed.run` (one per GPU, rendezvous on 127.0.0.1), rank 0's one JSON line is
+    forwarded to this process's stdout, the exit code is the children's."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write(f"bench: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}\n")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in p.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+        elif ln.strip():
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    elif p.returncode == 0:
+        sys.stderr.write("bench: the ranks printed no result line\n")
+        return 4
+    return p.returncode
+
+
+def launch_check(args, dist, rank, world):
+    """--launch-check: the ranks exist, the group forms, and the spanning-bus exchange's collectives (all-to-all + gather of the
+    mesh exchange, the plain reduce) carry a small bus on host tensors.  No engine, no GPU."""
+    import torch
+    from libzl_amd import sharding
+    n = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(n)
+    part = torch.full((2, 2, 16 * world), float(rank + 1), dtype=torch.float32)
+    want = float(world * (world + 1) // 2)
+    a = sharding.reduce_bus_mesh(part.clone(), dst=0)
+    b = sharding.reduce_bus(part.clone(), dst=0)
+    ok = bool(int(n.item()) == world and (rank != 0 or (bool((a == want).all()) and bool((b == want).all()))))
+    return {"metric": "voice-samples/sec at 1024 voices x 256-frame blocks; % HBM roofline", "value": None, "unit": "voice-samples/s",
+            "n_gpus": world, "launch_check": True, "ranks_counted": int(n.item()), "backend": dist.get_backend(),
+            "exchange_ok": ok, "steps": 0, "warmup": 0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "data": "none (launch check: no engine ran)"}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.rehearse_collectives:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    # stdout carries exactly ONE line, the JSON result: whatever native libraries print meanwhile (RCCL's version banner
+    # at communicator creation, for one) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -294,6 +481,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         args.gpus = world
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29562")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        line = launch_check(args, dist, rank, world)
+        if rank == 0:
+            os.dup2(real_stdout, 1)
+            print(json.dumps(line), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        if not line["exchange_ok"]:
+            raise SystemExit(5)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU render path")
     if args.same_device:
@@ -302,8 +501,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or args.rehearse_collectives
     if args.rehearse_collectives:
-        args.span_buses = True
-        os.environ["ZL_FORCE_COLLECTIVES"] = "1"
+        os.environ["ZL_FORCE_COLLECTIVES"] = "1"                      # the exchange runs its collectives with one rank too
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if distributed:
@@ -515,6 +713,7 @@ def main():
                 traffic_src = f"{os.path.relpath(pmc_file, ROOT)}: rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE per launch; the factor 2 calibrated on the no-reuse workload, where every source byte must come from HBM) / algorithmic bytes, collected for this kernel build (digest {digest})"
                 break
 
+    out = None
     if rank == 0:
         out = {
             "metric": "voice-samples/sec at 1024 voices x 256-frame blocks; % HBM roofline",
@@ -561,10 +760,39 @@ def main():
         if not args.no_cpu_baseline:
             # the CPU leg is timed on rank 0 at N = 1 only (a reported baseline of the same workload, not part of the scaling curve)
             out["cpu_baseline"] = cpu_baseline(args, seed) if world == 1 else None
+
+    def emit():
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+
+    # ---- N > 1: the spanning-bus exchange next to the collective-free headline (same engine, same voices).  A watchdog bounds
+    #      it: should a collective never complete on this node, rank 0 prints the line with what is there and every rank leaves.
+    if distributed and not exchange and not args.no_span_leg and args.fanout == "none":
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["span_buses"] = {"error": f"not finished after {args.span_timeout:.0f} s (--span-timeout): a collective did not complete"}
+                emit()
+            else:
+                time.sleep(2.0)
+            os._exit(0)
+        dog = threading.Timer(args.span_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        span = span_buses_leg(args, torch, dist, sharding, syn, dev, stream, clock_sets, rank, world,
+                              (lambda m: sys.stderr.write(f"bench: {m}\n")) if rank == 0 else None)
+        dog.cancel()
+        if rank == 0:
+            out["span_buses"] = span
+            bad = [a for a in ("mesh", "reduce") if isinstance(span.get(a), dict) and span[a].get("output_check") and not span[a]["output_check"]["ok"]]
+            if bad:
+                sys.stderr.write(f"bench: SPAN-BUSES OUTPUT CHECK FAILED: {[span[a]['output_check'] for a in bad]}\n")
+                raise SystemExit(3)
+    if rank == 0:
+        emit()
     syn.close()
     if distributed:
         dist.barrier()                       # rank 0 is still timing the CPU baseline: leave the group together

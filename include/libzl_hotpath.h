@@ -127,12 +127,24 @@ ClipAudioSource *ClipAudioSource_newFromBuffer(const float *left, const float *r
  * out_left / out_right: [num_buses][nframes].  Afterwards the per-clip positions models are updated from
  * the voice reports and the progress / audio-level callbacks fire (ClipAudioSource.cpp:88-113,225-240). */
 int  libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right);
+/* The same cycle with the JackPassthrough clients behind the channels (JackPassthroughPrivate::process, JackPassthrough.cpp:45-115; clients
+ * and their channels: MidiRouter.cpp:876-883 -- "GlobalPlayback" behind channel -1 = bus 1, "FXPassthrough-Channel<n>" behind channel n-1 = bus
+ * n+1; a bus without a client in the reference gets one at its defaults): fan_out [num_buses][6][nframes] = dryL, dryR, fx1L, fx1R, fx2L, fx2R of
+ * every bus, with the dry / wet / pan amounts and mute flags the JackPassthrough_set* calls stored -- read per cycle, no lock, no HIP call;
+ * on the real-time cycle the resident kernel writes the rows from the registers that hold the mix.  fan_out == NULL: libzl_hotpath_process. */
+int  libzl_hotpath_process_fanout(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right, float *fan_out);
 /* The same cycle with this library's own transport: SyncTimerPrivate::process (SyncTimer.cpp:452-702) for the JACK cycle
  * [current_usecs, next_usecs) -- the steps of the 32768-step ring that fall due are played, their ClipCommands dispatched
  * with the playhead (:553-558), SetBpm commands applied, playhead and step clock rolled -- then every channel is rendered
  * with the clock SyncTimer's getters return (:990-1009), and, while the timer runs, the timer thread's tick
  * (hiResTimerCallback, :391-418) is taken once.  Arguments as jack_get_cycle_times returns them (SamplerSynth.cpp:128). */
 int  libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, float *out_left, float *out_right);
+int  libzl_hotpath_cycle_fanout(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, float *out_left, float *out_right,
+                                float *fan_out /* as libzl_hotpath_process_fanout */);
+/* play / stop / queue / timer calls are handed to the cycle through a bounded queue (4096 requests, FreshCommandStashSize of SyncTimer.cpp:252;
+ * ClipAudioSource_stop(-3) alone is 12 of them) that only a cycle drains: how many requests were LOST because it was full -- no cycle ran
+ * (before JACK starts, during libzl_hotpath_bounce_to_wav).  The callers return void as in libzl.h; a host that floods the queue reads this. */
+uint64_t libzl_hotpath_dropped_requests(void);
 /* Offline bounce of the running session to WAV files (BASELINE configs[4] from / to real files): what nblocks calls of
  * libzl_hotpath_cycle would render -- the library's own transport, JACK time start_usecs + k * round(1e6 * nframes / fs), commands
  * dispatched in the cycle their step falls due in -- rendered in batches through zlhip_bounce and written as one stereo WAV per sampler

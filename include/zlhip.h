@@ -33,8 +33,10 @@ extern "C" {
 /* 2: zlhip_config grew (rt_idle_timeout_us; struct_size tells the library which fields the caller knows); ZLHIP_MODE_HERMITE is
  *    the tap-weight form fixed in round 2 (it differs from the Horner form of ABI 1 in the last bits);
  *    new entry points: zlhip_bounce, zlhip_host_alloc/free, zlhip_bus_reduce_sum_scan, zlhip_levels_import_units,
- *    zlhip_sound_upload_device_on; zlhip_clip_set no longer waits for the device (the edit lands at the next render call). */
-#define ZLHIP_ABI_VERSION 2
+ *    zlhip_sound_upload_device_on; zlhip_clip_set no longer waits for the device (the edit lands at the next render call).
+ * 3: new entry points only (a caller built against 2 keeps working): zlhip_render_fanout (the JackPassthrough fan-out on the
+ *    real-time cycle), zlhip_rt_residency, zlhip_rt_last_cycle; the resident real-time kernel takes any period (blocks longer than 256 frames too). */
+#define ZLHIP_ABI_VERSION 3
 
 /* status codes */
 #define ZLHIP_OK                 0
@@ -223,6 +225,16 @@ int zlhip_voice_is_playing(zlhip_engine *e, int32_t bus, int32_t slot);
 /* One real-time block: renders nframes for every bus and copies the mix to host memory.
  * out_left/out_right: [num_buses][nframes] each (host).  Synchronous. */
 int zlhip_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right);
+/* The same cycle, and the JackPassthrough client behind every bus with it (JackPassthroughPrivate::process, JackPassthrough.cpp:45-115;
+ * the client is the next node after a SamplerSynth channel in the reference's JACK graph): the three output pairs of every bus are
+ * computed from the registers that hold the finished mix and written to host memory next to it -- by the resident real-time kernel
+ * where zlhip_render uses it, else by the launched kernels.
+ *   fan_params  host [num_buses]: this cycle's dry / wetFx1 / wetFx2 / pan amounts and mute flags.  Taken per cycle: a changed value
+ *               costs no HIP call and does not disturb the resident kernel (it re-reads the table when it differs from the last cycle's)
+ *   fan_out     host [num_buses][6][nframes] = dryL, dryR, fx1L, fx1R, fx2L, fx2R of every bus (the order of zlhip_passthrough_process)
+ * Bit-identical to zlhip_render followed by the passthrough of its output.  fan_params == fan_out == NULL: zlhip_render. */
+int zlhip_render_fanout(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right,
+                        const zlhip_passthrough_params *fan_params, float *fan_out);
 /* Throughput mode: nblocks consecutive blocks in one pass.  clocks: host [nblocks].
  * bus_out_dev: DEVICE buffer laid out [num_buses][2][nblocks*nframes] fp32, or NULL to use the
  * engine's internal buffer (readable with zlhip_read_bus).  stream: hipStream_t or NULL for the
@@ -320,8 +332,25 @@ float *zlhip_bus_device_ptr(zlhip_engine *e);                   /* internal [B][
 /* the resident real-time kernel behind zlhip_render: how many times it was launched, how many cycles it rendered (a parameter edit,
  * a command or a quiet spell shorter than the idle timeout do not relaunch it; a batch, an upload or a block-size change do) */
 int zlhip_rt_stats(zlhip_engine *e, uint64_t *kernel_starts, uint64_t *cycles_rendered);
+/* Is this engine's resident kernel on the device right now (*resident), and which share of the device's resident-workgroup capacity
+ * does it take (*share, 0..1)?  The resident kernels of ALL engines of a process together take at most three quarters of a device; an
+ * engine that does not fit next to the others renders its cycles with launches (same results) until there is room. */
+int zlhip_rt_residency(zlhip_engine *e, int32_t *resident, double *share);
 /* HBM the engine allocated at creation: everything (source arena, voice / plan records, control pool, bus, levels) and the
  * arena's share of it */
+/* Where the LAST zlhip_render / zlhip_render_fanout cycle spent its time, seen from the calling thread (engines created with ZL_RT_TRACE=1
+ * in the environment; ZL_RT_TRACE_SLOW_US=<n> also reports every cycle longer than n microseconds on stderr).  total = before_post (command
+ * upload, a restart of the resident kernel; for launches: the launch calls) + wait (for the device) + after (copies into the caller's
+ * buffers).  max_poll_gap_us: the longest time between two polls of the waiting thread -- a gap of milliseconds means the THREAD was
+ * off its core (scheduler, cgroup quota), not that the device was late; involuntary_switches: getrusage(RUSAGE_THREAD) over the cycle;
+ * device_us: the resident kernel's own stage times for the cycle (with ZL_RT_STAMPS=1, else 0). */
+typedef struct zlhip_rt_cycle_trace {
+    uint64_t cycle;
+    int32_t  resident, reserved;
+    double   total_us, before_post_us, wait_us, after_us, max_poll_gap_us, device_us;
+    int64_t  involuntary_switches;
+} zlhip_rt_cycle_trace;
+int zlhip_rt_last_cycle(zlhip_engine *e, zlhip_rt_cycle_trace *out);
 int zlhip_memory_bytes(zlhip_engine *e, uint64_t *total_device_bytes, uint64_t *arena_bytes);
 int zlhip_device_name(zlhip_engine *e, char *buf, size_t len);
 

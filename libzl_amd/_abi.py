@@ -95,6 +95,14 @@ class Timings(C.Structure):
     ]
 
 
+class RtCycleTrace(C.Structure):
+    _fields_ = [
+        ("cycle", C.c_uint64), ("resident", C.c_int32), ("reserved", C.c_int32),
+        ("total_us", C.c_double), ("before_post_us", C.c_double), ("wait_us", C.c_double), ("after_us", C.c_double),
+        ("max_poll_gap_us", C.c_double), ("device_us", C.c_double), ("involuntary_switches", C.c_int64),
+    ]
+
+
 # every symbol include/zlhip.h declares: name -> (restype, argtypes)
 _F = C.POINTER(C.c_float)
 _E = C.c_void_p
@@ -121,6 +129,7 @@ SIGNATURES = {
     "zlhip_update_voice": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(ClipCommand)]),
     "zlhip_voice_is_playing": (C.c_int, [_E, C.c_int32, C.c_int32]),
     "zlhip_render": (C.c_int, [_E, C.c_int32, C.POINTER(Clock), C.c_void_p, C.c_void_p]),
+    "zlhip_render_fanout": (C.c_int, [_E, C.c_int32, C.POINTER(Clock), C.c_void_p, C.c_void_p, C.POINTER(PassthroughParams), C.c_void_p]),
     "zlhip_render_batch": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(Clock), C.c_void_p, C.c_void_p]),
     "zlhip_render_batch_fanout": (C.c_int, [_E, C.c_int32, C.c_int32, C.POINTER(Clock), C.c_void_p, C.POINTER(PassthroughParams), C.c_void_p, C.c_void_p]),
     "zlhip_synchronize": (C.c_int, [_E]),
@@ -145,6 +154,8 @@ SIGNATURES = {
     "zlhip_bus_device_ptr": (C.c_void_p, [_E]),
     "zlhip_device_name": (C.c_int, [_E, C.c_char_p, C.c_size_t]),
     "zlhip_rt_stats": (C.c_int, [_E, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "zlhip_rt_residency": (C.c_int, [_E, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "zlhip_rt_last_cycle": (C.c_int, [_E, C.POINTER(RtCycleTrace)]),
 }
 
 # ZLHIP_LIBRARY selects another build of the same library (A/B measurements of kernel variants); never a fallback

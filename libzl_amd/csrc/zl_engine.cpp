@@ -6,6 +6,7 @@
 // SamplerSynthVoice.cpp:110-144) and launches the kernels of zl_kernels.hip.  There is no CPU
 // render path in this library: every sample is produced by the HIP kernels.
 #include <hip/hip_runtime.h>
+#include <sys/resource.h>
 
 #include <algorithm>
 #include <atomic>
@@ -69,7 +70,8 @@ struct zlhip_engine {
     // further arena segments, allocated when a source does not fit any more (clips are loaded freely; 288 GB of HBM): a source in
     // one of them is addressed like any other, by its float offset from `arena` -- taken modulo 2^64, so a segment below the first
     // one in the address space has a "negative" offset that the kernels' 64-bit address arithmetic wraps back
-    std::vector<float *> arenaSegments;
+    struct ArenaSegment { float *p; size_t off, floats; };   // off: the segment's float offset from `arena`, modulo 2^64
+    std::vector<ArenaSegment> arenaSegments;
     size_t arenaSegmentFloats = 0;       // floats in those segments (zlhip_memory_bytes)
     std::vector<size_t> soundFloats;     // per sound slot: floats it holds in the arena
     ZlSound *dSounds = nullptr; ZlClip *dClips = nullptr;
@@ -114,6 +116,7 @@ struct zlhip_engine {
         std::vector<hipEvent_t> evK2;    // [2 * max windows] start/end of every K2 launch (profiling)
         int windows = 0;
         bool inflight = false, profiled = false;
+        bool fusedDone = false;          // the call's last K2 launch published the reports and carries `done` as its stop event (no report kernel)
     } slots[2];
     unsigned callIndex = 0, setPhase = 0;
     CallSlot *latest = nullptr;          // slot of the most recent call
@@ -128,6 +131,11 @@ struct zlhip_engine {
 
     // pinned host staging
     float *hBus = nullptr, *hBusDev = nullptr;   // one real-time block, host memory mapped into the device
+    // one real-time block's JackPassthrough fan-out [B][6][max_frames] (zlhip_render_fanout), written by the kernels like hBus; the
+    // parameter table the resident kernel reads ([B], mapped host memory) and its version (never 0; moved when an entry changes)
+    float *hFan = nullptr, *hFanDev = nullptr;
+    ZlPassParams *hPassRt = nullptr, *hPassRtDev = nullptr;
+    uint32_t passSeq = 1;
     ZlLevelsState *hLevelState = nullptr;
 
     // host mirrors
@@ -149,12 +157,18 @@ struct zlhip_engine {
         ZlOpRange *devRanges = nullptr;                    // wide buses: workgroup 0's copy of a block's operation ranges
         int capacity[2] = {-1, -1};                        // workgroups of the kernel the device holds at once (narrow, wide); -1 = not asked yet
         int vw = 0;                                        // wide buses: voices per resident workgroup (a divisor of voices_per_bus)
+        double share = 0.0;                                // of the device's resident-workgroup capacity this engine's kernel takes (rt_eligible)
+        std::atomic<bool> inCycle{false};                  // a cycle is being rendered through the resident kernel (its share stays taken even if the kernel has just left)
+        int maxFrames = 4096;                              // longest period the resident kernel takes (ZL_RT_MAX_FRAMES)
         hipStream_t stream = nullptr;
         int nframes = 0;
         unsigned long long seq = 0;
         unsigned long long starts = 0, cycles = 0;        // launches of the resident kernel, cycles it rendered (zlhip_rt_stats)
         unsigned long long idleTicks = 20000000ull;       // 200 ms of the 100 MHz counter without a block: the kernel leaves
         bool stampsOn = false; double stampSum[6] = {0, 0, 0, 0, 0, 0}; unsigned long long stampN = 0;   // ZL_RT_STAMPS=1: stage times (us)
+        // where the last real-time cycle spent its time, seen from the host (zlhip_rt_last_cycle): a worst case has to be attributable
+        bool traceOn = false; double slowUs = 0.0;         // ZL_RT_TRACE=1; ZL_RT_TRACE_SLOW_US=<n>: cycles longer than that are reported on stderr
+        zlhip_rt_cycle_trace last{};
     } rt;
 
     // offline bounce (zlhip_bounce): the device bus buffers of two chunks rendered into in turn, their 16-bit versions, the copy stream.
@@ -248,13 +262,25 @@ struct ZlQuiesce {
     explicit ZlQuiesce(const zlhip_engine *self)
     {
         g_rt.quiescing.fetch_add(1, std::memory_order_acq_rel);
-        std::lock_guard<std::mutex> lk(g_rt.mu);
-        for (zlhip_engine *o : g_rt.engines) if (o != self && o->rt.h) __atomic_store_n(&o->rt.h->yield, 1u, __ATOMIC_RELEASE);
+        // The registry's lock is held in short bursts only -- to post the request and to look at the kernels' states -- never while
+        // waiting: rt_start and rt_unregister take the same lock on a JACK thread (an audio thread whose kernel had just
+        // left could sit behind this wait for up to a second).  The engine list is read afresh under the lock every round, so an
+        // engine destroyed meanwhile is simply no longer there.
         const auto t0 = std::chrono::steady_clock::now();
-        for (zlhip_engine *o : g_rt.engines) {
-            if (o == self || !o->rt.h) continue;
-            // (a kernel that was just launched reads the request at its first idle poll; one second: thousands of cycles)
-            while (__atomic_load_n(&o->rt.h->state, __ATOMIC_ACQUIRE) != 2u && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(1)) { }
+        for (;;) {
+            bool all = true;
+            {
+                std::lock_guard<std::mutex> lk(g_rt.mu);
+                for (zlhip_engine *o : g_rt.engines) {
+                    if (o == self || !o->rt.h) continue;
+                    __atomic_store_n(&o->rt.h->yield, 1u, __ATOMIC_RELEASE);
+                    // (a kernel that was just launched reads the request at its first idle poll)
+                    if (__atomic_load_n(&o->rt.h->state, __ATOMIC_ACQUIRE) != 2u) all = false;
+                }
+            }
+            // (one second: thousands of cycles)
+            if (all || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) break;
+            for (int i = 0; i < 256; ++i) __builtin_ia32_pause();
         }
     }
     ~ZlQuiesce()
@@ -340,7 +366,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->planStream) (void)hipStreamSynchronize(e->planStream);
     if (e->asmStream) (void)hipStreamSynchronize(e->asmStream);
-    for (float *seg : e->arenaSegments) if (seg) (void)hipFree(seg);
+    for (auto &seg : e->arenaSegments) if (seg.p) (void)hipFree(seg.p);
     void *dev[] = { e->arena, e->dSounds, e->dClips, e->dVoices, e->dGain, e->dBus, e->dLevels, e->dLevelState, e->dTrace, e->dPass, e->dPassCache };
     for (void *p : dev) if (p) (void)hipFree(p);
     for (auto &q : e->ps) {
@@ -368,7 +394,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
     for (hipEvent_t ev : e->bnc.winEv) if (ev) (void)hipEventDestroy(ev);
     if (e->planStream) (void)hipStreamDestroy(e->planStream);
     if (e->asmStream) (void)hipStreamDestroy(e->asmStream);
-    void *host[] = { e->hBus, e->hLevelState };
+    void *host[] = { e->hBus, e->hLevelState, e->hFan, e->hPassRt };
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (e->evJoin) (void)hipEventDestroy(e->evJoin);
     if (e->evPlanTail) (void)hipEventDestroy(e->evPlanTail);
@@ -525,6 +551,10 @@ int zlhip_engine_create(const zlhip_config *cfg_in, zlhip_engine **out)
     chk(dalloc(&e->dPass, B), "passthrough params");
     chk(hipHostMalloc((void **)&e->hBus, B * 2 * N * sizeof(float)), "hBus");
     if (rc == ZLHIP_OK) chk(hipHostGetDevicePointer((void **)&e->hBusDev, e->hBus, 0), "map hBus");
+    chk(hipHostMalloc((void **)&e->hFan, B * 6 * N * sizeof(float)), "hFan");
+    if (rc == ZLHIP_OK) chk(hipHostGetDevicePointer((void **)&e->hFanDev, e->hFan, 0), "map hFan");
+    chk(hipHostMalloc((void **)&e->hPassRt, B * sizeof(ZlPassParams)), "hPassRt");
+    if (rc == ZLHIP_OK) { chk(hipHostGetDevicePointer((void **)&e->hPassRtDev, e->hPassRt, 0), "map hPassRt"); std::memset(e->hPassRt, 0xff, B * sizeof(ZlPassParams)); }
     chk(hipHostMalloc((void **)&e->hLevelState, B * sizeof(ZlLevelsState)), "hLevelState");
     chk(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming), "hipEventCreate");
     chk(hipEventCreateWithFlags(&e->evPlanTail, hipEventDisableTiming), "hipEventCreate");
@@ -566,6 +596,9 @@ int zlhip_engine_create(const zlhip_config *cfg_in, zlhip_engine **out)
         const char *rw = std::getenv("ZL_RT_WIDE");
         e->rt.wide = rw ? (std::atoi(rw) == 1 ? 1 : 0) : -1;
         e->rt.stampsOn = std::getenv("ZL_RT_STAMPS") != nullptr;
+        if (const char *mf = std::getenv("ZL_RT_MAX_FRAMES")) e->rt.maxFrames = std::max(1, std::atoi(mf));
+        if (const char *su = std::getenv("ZL_RT_TRACE_SLOW_US")) e->rt.slowUs = std::atof(su);
+        e->rt.traceOn = std::getenv("ZL_RT_TRACE") != nullptr || e->rt.slowUs > 0.0;
         if (cfg->rt_idle_timeout_us > 0) e->rt.idleTicks = (unsigned long long)cfg->rt_idle_timeout_us * 100ull;   // 100 MHz counter
     }
     e->hc.init(cfg->num_buses, cfg->voices_per_bus, cfg->max_sounds, cfg->playback_sample_rate);
@@ -617,19 +650,20 @@ static int alloc_sound_slot(zlhip_engine *e, int32_t length, int channels, doubl
             return fail(e, ZLHIP_ERR_CAPACITY, "sound arena full");
         float *seg = nullptr;
         if (hipMalloc((void **)&seg, (segFloats + 1024) * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fail(e, ZLHIP_ERR_CAPACITY, "sound arena full (no memory for another segment)"); }
-        e->arenaSegments.push_back(seg);
         e->arenaSegmentFloats += segFloats;
         e->deviceBytes += (segFloats + 1024) * sizeof(float);
         // float offset of the segment from `arena`, modulo 2^64 (exact: both are multiples of 4 bytes)
         const int64_t diffBytes = (int64_t)((uintptr_t)seg - (uintptr_t)e->arena);
         off = (size_t)(uint64_t)(diffBytes / 4);
+        e->arenaSegments.push_back({ seg, off, segFloats });
         if (segFloats > floats) {
             const std::pair<size_t, size_t> rest(off + floats, segFloats - floats);
             e->arenaFree.insert(std::lower_bound(e->arenaFree.begin(), e->arenaFree.end(), rest), rest);
         }
     }
     ZlSound s; s.offset = off; s.length = length; s.channels = channels; s.sample_rate = sample_rate;
-    *dst = e->arena + off;
+    // (integer arithmetic: a segment below the first arena in the address space has an offset that wraps -- no pointer ever leaves its allocation)
+    *dst = reinterpret_cast<float *>((uintptr_t)e->arena + (uintptr_t)off * sizeof(float));
     e->hc.sounds[id] = s;
     e->hc.soundUsed[id] = 1;
     e->soundFloats[(size_t)id] = floats;
@@ -648,7 +682,25 @@ static void free_sound_slot(zlhip_engine *e, int id)
     auto it = std::lower_bound(e->arenaFree.begin(), e->arenaFree.end(), std::make_pair(off, (size_t)0));
     it = e->arenaFree.insert(it, {off, n});
     if (it + 1 != e->arenaFree.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; e->arenaFree.erase(it + 1); }
-    if (it != e->arenaFree.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; e->arenaFree.erase(it); }
+    if (it != e->arenaFree.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; e->arenaFree.erase(it); --it; }
+    // a later arena segment whose every float is free again goes back to the device (the first arena stays for the engine's life).  The
+    // caller has waited for the engine and stopped its resident kernel; the free waits for the device: other engines' kernels step aside.
+    for (size_t si = 0; si < e->arenaSegments.size(); ++si) {
+        const auto seg = e->arenaSegments[si];
+        if (!(it->first <= seg.off && seg.off + seg.floats <= it->first + it->second)) continue;
+        const std::pair<size_t, size_t> whole = *it;
+        e->arenaFree.erase(it);
+        if (whole.first < seg.off) { const std::pair<size_t, size_t> head(whole.first, seg.off - whole.first); e->arenaFree.insert(std::lower_bound(e->arenaFree.begin(), e->arenaFree.end(), head), head); }
+        if (seg.off + seg.floats < whole.first + whole.second) {
+            const std::pair<size_t, size_t> tail(seg.off + seg.floats, whole.first + whole.second - (seg.off + seg.floats));
+            e->arenaFree.insert(std::lower_bound(e->arenaFree.begin(), e->arenaFree.end(), tail), tail);
+        }
+        { ZlQuiesce quiet(e); (void)hipFree(seg.p); }
+        e->arenaSegmentFloats -= seg.floats;
+        e->deviceBytes -= (seg.floats + 1024) * sizeof(float);
+        e->arenaSegments.erase(e->arenaSegments.begin() + (long)si);
+        break;                                                     // (one extent, at most one whole segment: segments are separate allocations)
+    }
 }
 
 static int publish_sound(zlhip_engine *e, int id)
@@ -893,12 +945,13 @@ static int harvest_slot(zlhip_engine *e, zlhip_engine::CallSlot &c)
     if (!c.profiled) return ZLHIP_OK;
     c.profiled = false;
     zlhip_timings t; std::memset(&t, 0, sizeof t);
-    ZL_HIP(e, hipEventSynchronize(c.evEnd));
-    ZL_HIP(e, hipEventElapsedTime(&t.total_ms, c.evBegin, c.evEnd));
+    hipEvent_t evEnd = c.fusedDone ? c.done : c.evEnd;
+    ZL_HIP(e, hipEventSynchronize(evEnd));
+    ZL_HIP(e, hipEventElapsedTime(&t.total_ms, c.evBegin, evEnd));
     float k2 = 0.0f;
     for (int w = 0; w < c.windows; ++w) {
         float x = 0.0f;
-        ZL_HIP(e, hipEventElapsedTime(&x, c.evK2[2 * (size_t)w], c.evK2[2 * (size_t)w + 1]));
+        ZL_HIP(e, hipEventElapsedTime(&x, c.evK2[2 * (size_t)w], (c.fusedDone && w == c.windows - 1) ? c.done : c.evK2[2 * (size_t)w + 1]));
         k2 += x;
     }
     t.render_ms = k2;                                              // sum over the K2 launches of the call
@@ -1072,6 +1125,12 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     // the record sets alternate across calls too, so that the first window of this call is not planned into the set
     // the previous call's last window still renders from
     const unsigned phase = e->ps[1].hdr != nullptr ? e->setPhase : 0u;
+    // The call's reports come from K2 itself wherever one workgroup sums a whole bus of the last block (no mix groups, one frame tile):
+    // the workgroups of that block publish gains, reports and statistics, and the launch carries the call's completion event -- between
+    // the last render kernel of this call and the first of the next sits no report kernel any more (12 % of a 64-voice step were packets).
+    // (Not while a bounce hands windows to the copy engine: its conversion kernels and copies follow the last render kernel.)
+    const bool fusedReports = A.groups == 1 && nframes <= 256 && !(e->bnc.sink.on && !(e->bnc.sink.hostDev && A.groups == 1));
+    c.fusedDone = fusedReports;
     for (int w = 0; w < nwin; ++w) {
         zlhip_engine::PlanSet &q = e->ps[(phase + (unsigned)w) & 1u];
         ZlBatch Aw = A;
@@ -1111,9 +1170,11 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         // offline bounce, direct delivery: K2 itself also stores the finished bus into the caller's page-locked host buffer
         const bool direct = e->bnc.sink.on && e->bnc.sink.hostDev && Aw.groups == 1;
         if (direct) { Aw.host_out = e->bnc.sink.hostDev; Aw.host_fmt = e->bnc.sink.pcm ? 1 : 0; Aw.host_total = (long long)e->bnc.sink.totalFrames; Aw.host_k0 = 0; }
-        // profiling: the K2 dispatch carries its own start / stop events (hipExtLaunchKernel)
-        if (e->profiling) ZL_KERNEL(e, zl_launch_render(Aw, s, c.evK2[2 * (size_t)w], c.evK2[2 * (size_t)w + 1]));
-        else ZL_KERNEL(e, zl_launch_render(Aw, s));
+        // profiling: the K2 dispatch carries its own start / stop events (hipExtLaunchKernel); the call's last launch carries `done`
+        const bool closes = fusedReports && w == nwin - 1;
+        if (fusedReports) { Aw.fused_reports = 1; Aw.rep_gain = e->dGain; Aw.rep_host = c.hReportsDev; Aw.rep_host_gain = c.hGainDev; Aw.rep_host_stats = c.hStatsDev; }
+        hipEvent_t k2stop = closes ? c.done : (e->profiling ? c.evK2[2 * (size_t)w + 1] : nullptr);
+        ZL_KERNEL(e, zl_launch_render(Aw, s, e->profiling ? c.evK2[2 * (size_t)w] : nullptr, k2stop));
         if (k3) ZL_KERNEL(e, zl_launch_finalize(Aw, nullptr, s));
         // ... or through the copy engine, window by window: the window's columns of the bus are final now
         if (e->bnc.sink.on && !direct) { int d_ = bounce_deliver_window(e, A.bus, 0, Aw.B, Aw.k0, Aw.K, nblocks, nframes, s); if (d_ != ZLHIP_OK) return d_; }
@@ -1121,7 +1182,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         // event that closes the K2 timing doubles as the set's "rendered" event)
         // (an engine with a single record set never plans on another stream: nobody waits for "rendered")
         if (e->ps[1].hdr != nullptr) {
-            if (e->profiling && !k3) q.renderedEv = c.evK2[2 * (size_t)w + 1];
+            if (k2stop && !k3) q.renderedEv = k2stop;
             else { ZL_HIP(e, hipEventRecord(q.rendered, s)); q.renderedEv = q.rendered; }
             q.used = true;
         }
@@ -1135,8 +1196,12 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     if (e->ps[1].hdr != nullptr) e->setPhase = (phase + (unsigned)nwin) & 1u;
     // results go straight to mapped host memory (a copy command here would make the runtime wait for the stream)
     // (the report kernel is the call's last packet: its stop event is the call's completion event)
-    ZL_KERNEL(e, zl_launch_reports(c.dReports, e->V, e->dGain, c.hReportsDev, c.hGainDev, c.dStats, c.hStatsDev, s, e->profiling ? nullptr : c.done));
-    if (e->profiling) { ZL_HIP(e, hipEventRecord(c.evEnd, s)); c.profiled = true; ZL_HIP(e, hipEventRecord(c.done, s)); }
+    if (fusedReports) {
+        if (e->profiling) c.profiled = true;                      // (total = evBegin .. done, the last K2 launch's stop event)
+    } else {
+        ZL_KERNEL(e, zl_launch_reports(c.dReports, e->V, e->dGain, c.hReportsDev, c.hGainDev, c.dStats, c.hStatsDev, s, e->profiling ? nullptr : c.done));
+        if (e->profiling) { ZL_HIP(e, hipEventRecord(c.evEnd, s)); c.profiled = true; ZL_HIP(e, hipEventRecord(c.done, s)); }
+    }
     c.inflight = true;
     if (s != e->stream) e->joins[0] = c.done;                      // later engine work (levels, read-back) waits for it on the host
     e->latest = &c;
@@ -1174,7 +1239,7 @@ static int bounce_body(zlhip_engine *e, int64_t nblocks, int32_t nframes, const 
     // 16 bit 4.6 ms = 98 % of the device-resident rate (27 GB/s of stores next to the rendering: half the link) against 5.7 ms through the
     // copy engine; fp32 6.05 ms (the stores run at 40 GB/s) against 7.0 ms.  ZL_BOUNCE_DIRECT: 0 = always through the copy engine, window
     // by window; 1 = only the 16-bit format directly; 2 (default) = both.
-    static const int directMode = [] { const char *v = std::getenv("ZL_BOUNCE_DIRECT"); return v ? std::atoi(v) : 2; }();
+    const int directMode = [] { const char *v = std::getenv("ZL_BOUNCE_DIRECT"); return v ? std::atoi(v) : 2; }();   // (read per bounce: tests switch it)
     void *hostDev = nullptr;
     if (directMode >= (pcm ? 1 : 2)) {
         if (hipHostGetDevicePointer(&hostDev, host_out, 0) != hipSuccess) { hostDev = nullptr; (void)hipGetLastError(); }   // pageable memory: copies
@@ -1273,30 +1338,52 @@ static bool rt_wide(const zlhip_engine *e) { return e->cfg.voices_per_bus >= ZL_
 static bool rt_eligible(zlhip_engine *e, int nframes)
 {
     // the workgroups of one cycle are all resident: buses summed whole by one workgroup each (narrow) or one workgroup per voice and
-    // the ordered sum by the bus's last arrival (wide); the reference's summation order either way (no mix groups), one frame tile,
-    // no debug trace
-    if (!(e->rt.enabled && nframes <= 256 && e->cfg.voices_per_task <= 0 && !e->trace)) return false;
+    // the ordered sum by the bus's last arrival (wide); the reference's summation order either way (no mix groups), any period (a
+    // workgroup walks the 256-frame tiles of a longer block one after the other), no debug trace
+    if (!(e->rt.enabled && nframes <= e->rt.maxFrames && e->cfg.voices_per_task <= 0 && !e->trace)) return false;
     const bool wide = rt_wide(e);
     if (wide && e->rt.wide == 0) return false;
     if (e->cfg.num_buses > (wide ? ZL_RT_MAX_BUSES : 64)) return false;
     int &cap = e->rt.capacity[wide ? 1 : 0];
     if (cap < 0) cap = zl_rt_loop_capacity(e->cfg.mode, wide ? 1 : 0, 256, e->device);
-    // (room is left for the level-tick and upload kernels of the same process: three quarters of the device at most)
-    if (!wide) return (long long)e->cfg.num_buses * 4 <= (long long)cap * 3;
+    if (cap <= 0) return false;
+    // (room is left for the level-tick and upload kernels of the same process: three quarters of the device at most -- for ALL the
+    // resident kernels of the process together: rt_start adds up the shares of the engines that are resident, rt_fits below)
+    if (!wide) {
+        e->rt.share = (double)e->cfg.num_buses / (double)cap;
+        return (long long)e->cfg.num_buses * 4 <= (long long)cap * 3;
+    }
     // wide: as few voices per workgroup as the device holds (their K2 bodies run one after the other), never across a bus
     if (e->rt.vw == 0) {
         e->rt.vw = -1;
         for (int vw = 1; vw <= 8; vw *= 2)
             if (e->cfg.voices_per_bus % vw == 0 && (long long)(e->V / vw) * 4 <= (long long)cap * 3) { e->rt.vw = vw; break; }
     }
+    if (e->rt.vw > 0) e->rt.share = (double)(e->V / e->rt.vw) / (double)cap;
     return e->rt.vw > 0 && (e->rt.wide == 1 || e->rt.vw == 1);     // (several voices per workgroup: opt-in, see zlhip_engine_create)
 }
 
 #define ZL_RT_BUSY 1     // rt_start / rt_render: a device-synchronising call is in progress somewhere in the process -- render this cycle with launches
+#define ZL_RT_NOFIT 2    // rt_start: the resident kernels of the process's other engines leave no room on the device for this one -- render with launches
+
+// Every workgroup of a resident kernel must be ON the device for a cycle to complete (the last arrival reports it): two engines
+// that each fit alone may not fit together -- the second kernel's workgroups would wait for slots the first one's spinners hold, and
+// its host would give up after two seconds.  So the shares of all engines whose kernel is (or is about to be) resident on this
+// device are added up, and an engine that does not fit next to them renders with launches (same results).  Call with g_rt.mu held.
+static bool rt_fits(const zlhip_engine *e)
+{
+    double used = 0.0;
+    for (const zlhip_engine *o : g_rt.engines) {
+        if (o == e || o->device != e->device || !o->rt.h) continue;
+        if (__atomic_load_n(&o->rt.h->state, __ATOMIC_ACQUIRE) != 2u || o->rt.inCycle.load(std::memory_order_acquire)) used += o->rt.share;
+    }
+    return used + e->rt.share <= 0.75;
+}
 
 static int rt_start(zlhip_engine *e, int nframes)
 {
     if (g_rt.quiescing.load(std::memory_order_acquire) > 0) return ZL_RT_BUSY;
+    { std::lock_guard<std::mutex> lk(g_rt.mu); if (!rt_fits(e)) return ZL_RT_NOFIT; }   // (asked again below, where the kernel is launched)
     { int w_ = engine_wait(e); if (w_ != ZLHIP_OK) return w_; }
     for (auto &c : e->slots) if (c.inflight) { ZL_HIP(e, hipEventSynchronize(c.done)); c.inflight = false; int h_ = harvest_slot(e, c); if (h_ != ZLHIP_OK) return h_; }
     if (e->planStream) ZL_HIP(e, hipStreamSynchronize(e->planStream));
@@ -1326,6 +1413,7 @@ static int rt_start(zlhip_engine *e, int nframes)
     A.mode = e->cfg.mode;
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena; A.voices = e->dVoices; A.reports = c.dReports; A.pass_cache = e->dPassCache;
     A.bus = e->hBusDev; A.stats = nullptr; A.levels = e->dLevels;
+    A.fan = e->hFanDev; A.pass = e->hPassRtDev;                     // a cycle says whether it wants the fan-out (ZlRtShared::fan_seq)
     A.vconst = q.vconst; A.runs = q.runs; A.tsegs = q.tsegs; A.plan_hdr = q.hdr; A.plan_seg0 = q.seg0; A.plan_seg1 = q.seg1;
     A.ctl_P = q.ctlP; A.ctl_env = q.ctlEnv; A.partials = q.partials; A.ctl_next = q.ctlNext; A.sim_const = q.simConst;
     A.ctl_slots = e->ctlSlotsOverride >= 0 ? std::min<int>(e->ctlSlotsOverride, (int)(e->ctlPoolFrames / (size_t)nframes)) : (int)std::min<size_t>(e->ctlPoolFrames / (size_t)nframes, 0x7fffffff);
@@ -1334,6 +1422,7 @@ static int rt_start(zlhip_engine *e, int nframes)
     // in the registry (and its kernel will read the request), or this thread sees its request and does not launch
     std::lock_guard<std::mutex> lk(g_rt.mu);
     if (g_rt.quiescing.load(std::memory_order_acquire) > 0) return ZL_RT_BUSY;
+    if (!rt_fits(e)) return ZL_RT_NOFIT;
     __atomic_store_n(&e->rt.h->state, 0u, __ATOMIC_RELEASE);
     __atomic_store_n(&e->rt.h->yield, 0u, __ATOMIC_RELEASE);
     ZL_KERNEL(e, zl_launch_rt_loop(A, e->rt.d, e->rt.dev, e->rt.seq, e->rt.idleTicks, e->dGain, c.hReportsDev, c.hGainDev, e->rt.devRanges, std::max(e->rt.vw, 1), std::min(256, (nframes + 63) & ~63), e->rt.stream));
@@ -1342,11 +1431,36 @@ static int rt_start(zlhip_engine *e, int nframes)
     return ZLHIP_OK;
 }
 
+// ---- where a cycle's time went (ZL_RT_TRACE / zlhip_rt_last_cycle) ---------------------------------------------------------------
+// A real-time engine is judged by its worst cycle, and a worst cycle has to be attributable: to the host before the cycle is posted
+// (command upload, a kernel restart), to the wait for the device, or to the host afterwards -- and inside the wait, to the device or
+// to the waiting THREAD having been taken off its core (the longest gap between two polls of the spin, or between the start and the
+// end of the blocking wait; the thread's involuntary context switches).
+namespace {
+inline double us_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
+inline long thread_nivcsw() { struct rusage ru; return getrusage(RUSAGE_THREAD, &ru) == 0 ? ru.ru_nivcsw : 0; }
+void rt_trace_report(const zlhip_engine *e, const zlhip_rt_cycle_trace &t)
+{
+    if (e->rt.slowUs > 0.0 && t.total_us > e->rt.slowUs)
+        std::fprintf(stderr, "zlhip slow real-time cycle %llu (%s): %.0f us = host before the post %.0f + wait for the device %.0f + host after %.0f; "
+                             "longest gap between two polls of the waiting thread %.0f us, its involuntary context switches in the cycle: %ld; "
+                             "device stages (ZL_RT_STAMPS) %.1f us\n",
+                     (unsigned long long)t.cycle, t.resident ? "resident kernel" : "launches", t.total_us, t.before_post_us, t.wait_us, t.after_us,
+                     t.max_poll_gap_us, (long)t.involuntary_switches, t.device_us);
+}
+}  // namespace
+
 // One real-time block through the resident kernel: post the block in the mailbox, spin until the kernel has published it.
-static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right)
+static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right,
+                     const zlhip_passthrough_params *fan_params, float *fan_out)
 {
     zlhip_engine::CallSlot &c = e->slots[0];
     zlhip_engine::PlanSet &q = e->ps[0];
+    // from here to the end of the cycle this engine's share of the device counts as taken (rt_fits), whatever its kernel does meanwhile
+    struct InCycle { std::atomic<bool> &f; explicit InCycle(std::atomic<bool> &x) : f(x) { f.store(true, std::memory_order_release); } ~InCycle() { f.store(false, std::memory_order_release); } } inCycle(e->rt.inCycle);
+    const bool tr = e->rt.traceOn;
+    const auto tEnter = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    const long sw0 = tr ? thread_nivcsw() : 0;
     if (e->rt.running && (e->rt.nframes != nframes || __atomic_load_n(&e->rt.h->state, __ATOMIC_ACQUIRE) == 2u)) {
         int rc = rt_stop(e);                                       // another block size, or the kernel left after an idle spell
         if (rc != ZLHIP_OK) return rc;
@@ -1385,13 +1499,28 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
     sh->nframes = nframes; sh->n_op_ranges = A.n_op_ranges; sh->ops = A.ops; sh->op_ranges = A.op_ranges;
     sh->n_clip_edits = A.n_clip_edits; sh->clip_edits = A.clip_edits;
     sh->ctl_base = q.ctlBase; q.ctlBase += (unsigned long long)e->V + 1ull;
+    sh->fan_seq = 0u;
+    if (fan_out) {
+        // the JackPassthrough parameters: a table in mapped host memory and its version.  A workgroup keeps its bus's entry across cycles
+        // and reads the table again only when the version moved, so a quiet cycle makes no extra trip over PCIe
+        bool moved = false;
+        for (int b = 0; b < e->cfg.num_buses; ++b) {
+            const ZlPassParams pp = pass_params(fan_params[b]);
+            if (std::memcmp(&pp, &e->hPassRt[b], sizeof pp) != 0) { e->hPassRt[b] = pp; moved = true; }
+        }
+        if (moved && ++e->passSeq == 0u) e->passSeq = 1u;
+        sh->fan_seq = e->passSeq;
+    }
     const unsigned long long seq = ++e->rt.seq;
+    const auto tPost = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    auto tPoll = tPost; double maxGap = 0.0;
     __atomic_store_n(&sh->cmd_seq, seq, __ATOMIC_RELEASE);
     // spin: a block takes some tens of microseconds.  The kernel may have left (idle timeout) just before the post: then start
     // it again -- it picks the posted block up at once (first_seq = the last block it saw finished).
     const auto spin0 = std::chrono::steady_clock::now();
     for (unsigned long long spins = 0;; ++spins) {
         if (__atomic_load_n(&sh->done_seq, __ATOMIC_ACQUIRE) == seq) break;
+        if (tr) { const auto n_ = std::chrono::steady_clock::now(); const double g = us_between(tPoll, n_); if (g > maxGap) maxGap = g; tPoll = n_; }
         if ((spins & 0xfffu) == 0xfffu) {
             if (__atomic_load_n(&sh->state, __ATOMIC_ACQUIRE) == 2u) {
                 ZL_HIP(e, hipStreamSynchronize(e->rt.stream));
@@ -1401,9 +1530,10 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
                 e->rt.seq = seq - 1;                               // the restarted kernel must see `seq` as new
                 // (a device-synchronising call somewhere in the process made the kernel leave with this cycle posted but not taken:
                 // wait for that call to end -- it is a one-off of some milliseconds -- the cycle's inputs are in the mailbox already)
-                while ((rc = rt_start(e, nframes)) == ZL_RT_BUSY && std::chrono::steady_clock::now() - spin0 < std::chrono::seconds(2)) { }
+                // (this engine's share of the device stayed taken through the cycle, so the kernel still fits)
+                while (((rc = rt_start(e, nframes)) == ZL_RT_BUSY || rc == ZL_RT_NOFIT) && std::chrono::steady_clock::now() - spin0 < std::chrono::seconds(2)) { }
                 e->rt.seq = seq;
-                if (rc != ZLHIP_OK) return rc == ZL_RT_BUSY ? fail(e, ZLHIP_ERR_STATE, "resident real-time kernel kept out by a device-wide wait") : rc;
+                if (rc != ZLHIP_OK) return (rc == ZL_RT_BUSY || rc == ZL_RT_NOFIT) ? fail(e, ZLHIP_ERR_STATE, "resident real-time kernel kept out by a device-wide wait") : rc;
             }
             // (two seconds: hundreds of block periods)
             if (std::chrono::steady_clock::now() - spin0 > std::chrono::seconds(2)) {
@@ -1422,9 +1552,20 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
         std::memcpy(out_left + b * N, e->hBus + (b * 2) * N, N * sizeof(float));
         std::memcpy(out_right + b * N, e->hBus + (b * 2 + 1) * N, N * sizeof(float));
     }
+    const auto tDone = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    if (fan_out) std::memcpy(fan_out, e->hFan, B * 6 * N * sizeof(float));
+    double devUs = 0.0;
     if (e->rt.stampsOn) {                                          // (workgroup 0's last stamp may still be in flight when another workgroup finishes the block)
-        for (int i = 0; i < 5; ++i) { const long long d = (long long)(sh->stamps[i + 1] - sh->stamps[i]); if (d >= 0 && d < 100000000ll) e->rt.stampSum[i] += (double)d * 0.01; }
+        for (int i = 0; i < 5; ++i) { const long long d = (long long)(sh->stamps[i + 1] - sh->stamps[i]); if (d >= 0 && d < 100000000ll) { e->rt.stampSum[i] += (double)d * 0.01; devUs += (double)d * 0.01; } }
         e->rt.stampN += 1;
+    }
+    if (tr) {
+        const auto tExit = std::chrono::steady_clock::now();
+        zlhip_rt_cycle_trace &t = e->rt.last;
+        t.cycle = e->rt.cycles; t.resident = 1; t.total_us = us_between(tEnter, tExit); t.before_post_us = us_between(tEnter, tPost);
+        t.wait_us = us_between(tPost, tDone); t.after_us = us_between(tDone, tExit); t.max_poll_gap_us = maxGap;
+        t.involuntary_switches = (int64_t)(thread_nivcsw() - sw0); t.device_us = devUs;
+        rt_trace_report(e, t);
     }
     e->latest = &c;
     e->lastK = 1; e->lastN = nframes; e->lastBus = e->hBusDev; e->lastWindows = 1;
@@ -1435,25 +1576,54 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
 
 int zlhip_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right)
 {
-    if (!e || !clock || !out_left || !out_right) return ZLHIP_ERR_INVALID;
+    return zlhip_render_fanout(e, nframes, clock, out_left, out_right, nullptr, nullptr);
+}
+
+int zlhip_render_fanout(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right,
+                        const zlhip_passthrough_params *fan_params, float *fan_out)
+{
+    if (!e || !clock || !out_left || !out_right || ((fan_params == nullptr) != (fan_out == nullptr))) return ZLHIP_ERR_INVALID;
     if (e->failed) return fail(e, ZLHIP_ERR_STATE, "engine failed (the resident kernel stopped answering in the middle of a cycle): destroy it");
     if (nframes >= 1 && nframes <= e->cfg.max_frames && rt_eligible(e, nframes)) {
         ZL_HIP(e, hipSetDevice(e->device));
-        const int rc = rt_render(e, nframes, clock, out_left, out_right);
-        if (rc != ZL_RT_BUSY) return rc;
-        // a device-synchronising call is in progress in the process: this cycle is rendered with launches (same results)
+        const int rc = rt_render(e, nframes, clock, out_left, out_right, fan_params, fan_out);
+        if (rc != ZL_RT_BUSY && rc != ZL_RT_NOFIT) return rc;
+        // a device-synchronising call is in progress in the process, or other engines' resident kernels fill the device: this cycle is
+        // rendered with launches (same results)
     }
-    // the block's mix is written by the kernels straight into mapped host memory (24 KB for 12 buses x 256 frames):
+    // the block's mix (and fan-out) is written by the kernels straight into mapped host memory (24 KB for 12 buses x 256 frames):
     // no copy command after the render, one wait for the call's completion event
-    int rc = zlhip_render_batch(e, 1, nframes, clock, e->hBusDev, nullptr);
+    const bool tr = e->rt.traceOn;
+    const auto tEnter = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    const long sw0 = tr ? thread_nivcsw() : 0;
+    int rc = zlhip_render_batch_fanout(e, 1, nframes, clock, e->hBusDev, fan_params, fan_out ? e->hFanDev : nullptr, nullptr);
     if (rc != ZLHIP_OK) return rc;
     const size_t B = (size_t)e->cfg.num_buses, N = (size_t)nframes;
+    const auto tPost = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     ZL_HIP(e, hipEventSynchronize(e->latest->done));
+    const auto tDone = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     e->outstanding = false;
     for (size_t b = 0; b < B; ++b) {
         std::memcpy(out_left + b * N, e->hBus + (b * 2) * N, N * sizeof(float));
         std::memcpy(out_right + b * N, e->hBus + (b * 2 + 1) * N, N * sizeof(float));
     }
+    if (fan_out) std::memcpy(fan_out, e->hFan, B * 6 * N * sizeof(float));
+    if (tr) {
+        const auto tExit = std::chrono::steady_clock::now();
+        zlhip_rt_cycle_trace &t = e->rt.last;
+        t.cycle = e->callIndex; t.resident = 0; t.total_us = us_between(tEnter, tExit); t.before_post_us = us_between(tEnter, tPost);
+        t.wait_us = us_between(tPost, tDone); t.after_us = us_between(tDone, tExit); t.max_poll_gap_us = t.wait_us;   // (a blocking wait: one "poll")
+        t.involuntary_switches = (int64_t)(thread_nivcsw() - sw0); t.device_us = 0.0;
+        rt_trace_report(e, t);
+    }
+    return ZLHIP_OK;
+}
+
+int zlhip_rt_last_cycle(zlhip_engine *e, zlhip_rt_cycle_trace *out)
+{
+    if (!e || !out) return ZLHIP_ERR_INVALID;
+    if (!e->rt.traceOn) return fail(e, ZLHIP_ERR_STATE, "cycle tracing is off (ZL_RT_TRACE=1 at engine creation)");
+    *out = e->rt.last;
     return ZLHIP_OK;
 }
 
@@ -1688,6 +1858,14 @@ int zlhip_rt_stats(zlhip_engine *e, uint64_t *kernel_starts, uint64_t *cycles_re
     if (!e) return ZLHIP_ERR_INVALID;
     if (kernel_starts) *kernel_starts = e->rt.starts;
     if (cycles_rendered) *cycles_rendered = e->rt.cycles;
+    return ZLHIP_OK;
+}
+
+int zlhip_rt_residency(zlhip_engine *e, int32_t *resident, double *share)
+{
+    if (!e) return ZLHIP_ERR_INVALID;
+    if (resident) *resident = (e->rt.running && e->rt.h && __atomic_load_n(&e->rt.h->state, __ATOMIC_ACQUIRE) != 2u) ? 1 : 0;
+    if (share) *share = e->rt.share;
     return ZLHIP_OK;
 }
 

@@ -796,7 +796,8 @@ static __device__ __forceinline__ void zl_k2_chunk(const ZlBatch &A, const ZlBlo
 // workgroups per CU), so it may take the registers of 3 waves per SIMD.
 // (the body is a device function so that the persistent real-time kernel below can run it too: bx / by / bz / gdx / gdy stand for
 // blockIdx.x / .y / .z and gridDim.x / .y of the batch launch)
-template <uint32_t MODE, int BPW, bool ST>
+// REPORTS: the workgroups of a call's last block also publish its per-voice reports (batch launches; the resident kernel has its own)
+template <uint32_t MODE, int BPW, bool ST, bool REPORTS = true>
 static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsigned bx, const unsigned by, const unsigned bz, const unsigned gdx, const unsigned gdy)
 {
     constexpr int U = (MODE & ZL_MODE_HERMITE) ? ZL_K2_U_HERMITE : ZL_K2_U;
@@ -894,7 +895,7 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
                 // fused JackPassthrough fan-out of the finished bus (JackPassthrough.cpp:45-115): three more stereo pairs
                 // written from the registers that hold the mix -- no second pass over the bus
                 const size_t KN = (size_t)A.Ktot * N;
-                const ZlPassParams pp = A.pass[bus];
+                const ZlPassParams pp = A.pass_inline ? A.pass0 : A.pass[bus];
                 float *o = A.fan + ((size_t)bus * 6) * KN + (size_t)(A.k0 + k) * N;
                 float lm, rm; zl_pass_pan(pp, lm, rm);
                 const float amounts[3] = { pp.dry, pp.fx1, pp.fx2 };
@@ -913,7 +914,7 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
         }
         // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of its
         //      whole block(s) (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
-        if (A.groups == 1 && gdx == 1 && A.levels) {
+        if (A.groups == 1 && (gdx == 1 || A.tile_accum) && A.levels) {
             int pkL = written ? zl_sample_to_peak_int(accL) : 0, pkR = written ? zl_sample_to_peak_int(accR) : 0;
             float sqL = written ? accL * accL : 0.0f, sqR = written ? accR * accR : 0.0f;
             pkL = zl_wave_max_nonneg(pkL); pkR = zl_wave_max_nonneg(pkR);
@@ -925,7 +926,7 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
     };
     // the block levels of the workgroup's buses from the per-wave partial results: one lane per (bus, block)
     auto combine_levels = [&](int nbus) {
-        if (!(A.groups == 1 && gdx == 1 && A.levels)) return;
+        if (!(A.groups == 1 && (gdx == 1 || A.tile_accum) && A.levels)) return;
         __syncthreads();
         for (int idx = threadIdx.x; idx < nbus * BPW; idx += blockDim.x) {
             const int bi = idx / BPW, b = idx - bi * BPW;
@@ -935,6 +936,15 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
             const int w0 = (BPW > 1) ? b * (N >> 6) : 0;
             const int nw = (BPW > 1) ? (N >> 6) : (int)((blockDim.x + 63) >> 6);
             ZlBlockLevels lv; lv.peak_l = 0; lv.peak_r = 0; lv.sumsq_l = 0.0f; lv.sumsq_r = 0.0f;
+            // a later frame tile of a block this workgroup walks tile by tile: carry on from what this very lane stored after the tile before
+            // (read past the vector L1: agent-scope loads)
+            if (bx > 0) {
+                ZlBlockLevels *pl = &A.levels[(size_t)kk * A.B + bus0 + bi];
+                lv.peak_l = __hip_atomic_load(&pl->peak_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lv.peak_r = __hip_atomic_load(&pl->peak_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lv.sumsq_l = __hip_atomic_load(&pl->sumsq_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lv.sumsq_r = __hip_atomic_load(&pl->sumsq_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             for (int i = w0; i < w0 + nw; ++i) {
                 lv.peak_l = s_pk[0][bi][i] > lv.peak_l ? s_pk[0][bi][i] : lv.peak_l;
                 lv.peak_r = s_pk[1][bi][i] > lv.peak_r ? s_pk[1][bi][i] : lv.peak_r;
@@ -1172,6 +1182,30 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
 #endif
     if (NB == 1) { store_bus(bus0); combine_levels(1); }
     else combine_levels(curBus - bus0);
+
+    // ---- the call's reports (zl_k_reports' work), by the workgroups that hold the call's last block: this workgroup summed its buses
+    //      whole, so its voices' peaks are complete once its own waves have issued their atomics (the barrier waits for them)
+    if (REPORTS && A.fused_reports) {
+        const int klast = A.Ktot - 1 - A.k0;                      // the call's last block in this window's numbering (uniform)
+        if (klast >= 0 && klast < A.K && klast >= yb * BPW && klast < yb * BPW + BPW) {
+            __syncthreads();
+            for (int v = v0 + (int)threadIdx.x; v < v1; v += (int)blockDim.x) {
+                // (a report is two 16-byte words: {playing, valid, peak bits, progress} {clip, pad, position}; the peak is read past the vector L1)
+                const uint4 *src = reinterpret_cast<const uint4 *>(&A.reports[v]);
+                uint4 a = src[0];
+                const uint4 b = src[1];
+                a.z = __hip_atomic_load(&A.reports[v].peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float gn = __uint_as_float(a.z) * 0.5f;
+                A.rep_gain[v] = gn;
+                if (A.rep_host) { uint4 *dst = reinterpret_cast<uint4 *>(&A.rep_host[v]); dst[0] = a; dst[1] = b; A.rep_host_gain[v] = gn; }
+            }
+            if (bz == 0 && threadIdx.x == 0 && A.rep_host_stats) {
+                const unsigned long long sb = A.stats->source_bytes, sl = A.stats->slow_blocks, af = A.stats->active_frames;
+                A.rep_host_stats->source_bytes = sb; A.rep_host_stats->slow_blocks = sl; A.rep_host_stats->active_frames = af;
+                A.stats->source_bytes = 0; A.stats->slow_blocks = 0; A.stats->active_frames = 0;   // cleared for the call that reuses this slot
+            }
+        }
+    }
 }
 
 // the kernel: one workgroup = one (bus or group of narrow buses, mix group, block or BPW short blocks, frame tile)
@@ -1202,14 +1236,19 @@ __global__ void __launch_bounds__(256, ST ? 3 : (MODE & (ZL_MODE_HERMITE | ZL_MO
 // are copied from host memory into HBM once, by workgroup 0 before it publishes the block (a thousand workgroups reading the
 // same host memory would queue on PCIe).  Hand-offs between workgroups on different XCDs use agent-scope release / acquire fences.
 static __device__ __forceinline__ void zl_k3_body(const ZlBatch &A, const float *bus_in, int k, int bus);
+// (two waves per SIMD = two resident workgroups per CU: the budget the capacity rule of zl_engine.cpp rt_eligible counts on -- 256
+// registers per lane, accumulation registers included)
 template <uint32_t MODE, bool WIDE>
-__global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared *sh, ZlRtDev *dev, unsigned long long first_seq, unsigned long long idle_ticks,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) zl_k_rt_loop(const ZlBatch A0, ZlRtShared *sh, ZlRtDev *dev, unsigned long long first_seq, unsigned long long idle_ticks,
                                                     float *gain_out, ZlReport *host_reports, float *host_gain, ZlOpRange *dev_ranges, int vw)
 {
     __shared__ unsigned long long s_cmd[ZL_RT_CMD_WORDS + 1];     // [0] = the block's sequence number (0 with s_go = 0: leave)
     __shared__ int s_go, s_last;
     __shared__ ZlClock s_clk0;
+    __shared__ ZlPassParams s_pass;                               // JackPassthrough parameters of this workgroup's bus, as of version s_pass_seq
+    __shared__ uint32_t s_pass_seq;
     const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_pass_seq = 0u;
     const int z = blockIdx.x, W = gridDim.x;                       // one workgroup per bus (WIDE: per vw voices of one bus; vw divides VPB)
     const int vbeg = WIDE ? z * vw : z * A0.VPB, vend = WIDE ? vbeg + vw : vbeg + A0.VPB;
     unsigned long long last = first_seq;
@@ -1230,7 +1269,8 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
                         w[0] = (unsigned long long)(uint32_t)sh->nframes | ((unsigned long long)(uint32_t)sh->n_op_ranges << 32);
                         w[1] = (unsigned long long)(uintptr_t)sh->ops; w[2] = (unsigned long long)(uintptr_t)sh->op_ranges; w[3] = sh->ctl_base;
                         w[4] = sh->clock.current_usecs; w[5] = sh->clock.next_usecs; w[6] = sh->clock.playhead; w[7] = sh->clock.playhead_usecs;
-                        w[8] = sh->clock.subbeat_usecs; w[9] = sh->clock.usecs_per_frame; w[10] = (unsigned long long)(uint32_t)sh->n_clip_edits; w[11] = (unsigned long long)(uintptr_t)sh->clip_edits;
+                        w[8] = sh->clock.subbeat_usecs; w[9] = sh->clock.usecs_per_frame;
+                        w[10] = (unsigned long long)(uint32_t)sh->n_clip_edits | ((unsigned long long)sh->fan_seq << 32); w[11] = (unsigned long long)(uintptr_t)sh->clip_edits;
                         {
                             static_assert(sizeof(sh->inline_edits) == ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS * 8, "inline edits are whole words");
                             const unsigned long long *ie = reinterpret_cast<const unsigned long long *>(&sh->inline_edits[0]);
@@ -1279,6 +1319,22 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         A.clock0.subbeat_usecs = s_cmd[9]; A.clock0.usecs_per_frame = s_cmd[10];
         A.n_clip_edits = (int)(uint32_t)s_cmd[11]; A.clip_edits = reinterpret_cast<const ZlClipEdit *>((uintptr_t)s_cmd[12]);
         A.inline_clock = 1; A.fuse_assemble = 1;
+        // ---- JackPassthrough fan-out of this cycle (JackPassthrough.cpp:45-115): asked for per cycle; the parameters of the workgroup's
+        //      bus are kept in LDS across cycles and read again from the host's table (mapped memory: a trip over PCIe, issued here and
+        //      needed at the store, after planning) only when the host moved the table's version -- a knob turned while playing
+        const uint32_t fan_seq = (uint32_t)(s_cmd[11] >> 32);
+        if (fan_seq == 0u) A.fan = nullptr;
+        else if (tid == 0 && fan_seq != s_pass_seq) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            const int pb = (WIDE ? vbeg / A0.VPB : z);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(A0.pass + pb);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&s_pass);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(ZlPassParams) / 4); ++i) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s_pass_seq = fan_seq;
+        }
+        A.pass_inline = 1;
+        A.tile_accum = 1;                                          // this workgroup walks every frame tile of its block (below)
         if (WIDE && z == 0) {
             // workgroup 0: the block's operation ranges host memory -> HBM (behind a system-scope acquire: the host reuses its buffers
             // every block and plain loads may hit stale cached lines), then the block is published for the other workgroups
@@ -1345,11 +1401,16 @@ __global__ void __launch_bounds__(256) zl_k_rt_loop(const ZlBatch A0, ZlRtShared
         __threadfence_block();
         __syncthreads();
         if (A0.rt_stamps && z == 0 && tid == 0) sh->stamps[3] = __builtin_amdgcn_s_memrealtime();
-        // ---- K2: this bus (WIDE: each of this workgroup's voices into its own partial row: A.groups = voices per bus, one voice per group)
-        if (WIDE) { for (int v = vbeg; v < vend; ++v) zl_k2_body<MODE, 1, false>(A, 0u, 0u, (unsigned)v, 1u, 1u); }
-        else zl_k2_body<MODE, 1, false>(A, 0u, 0u, (unsigned)z, 1u, 1u);
-        __threadfence_block();
-        __syncthreads();
+        // ---- K2: this bus (WIDE: each of this workgroup's voices into its own partial row: A.groups = voices per bus, one voice per group).
+        //      A block longer than the workgroup (JACK periods of 512, 1024 ... frames) is walked tile by tile.
+        if (A.fan) A.pass0 = s_pass;                               // (written before the barriers above)
+        const unsigned tiles = ((unsigned)A.N + blockDim.x - 1u) / blockDim.x;
+        for (unsigned bx = 0; bx < tiles; ++bx) {
+            if (WIDE) { for (int v = vbeg; v < vend; ++v) zl_k2_body<MODE, 1, false, false>(A, bx, 0u, (unsigned)v, tiles, 1u); }
+            else zl_k2_body<MODE, 1, false, false>(A, bx, 0u, (unsigned)z, tiles, 1u);
+            __threadfence_block();
+            __syncthreads();
+        }
         if (WIDE) {
             // ---- the bus: the last of its workgroups to get here sums the partial rows in voice order, writes the mix, scans the levels
             const int bus = vbeg / A.VPB;
@@ -1451,7 +1512,7 @@ static __device__ __forceinline__ void zl_k3_body(const ZlBatch &A, const float 
             for (; g < A.groups; ++g) { l += p[f]; r += p[N + f]; p += 2 * (size_t)N; }
             outL[f] = l; outR[f] = r;
             if (A.fan) {                                           // fused JackPassthrough fan-out, as in K2
-                const ZlPassParams pp = A.pass[bus];
+                const ZlPassParams pp = A.pass_inline ? A.pass0 : A.pass[bus];
                 float *o = A.fan + ((size_t)bus * 6) * KN + (size_t)(A.k0 + k) * N;
                 float lm, rm; zl_pass_pan(pp, lm, rm);
                 const float amounts[3] = { pp.dry, pp.fx1, pp.fx2 };
@@ -1630,23 +1691,34 @@ __global__ void __launch_bounds__(256) zl_k_passthrough(const ZlPassParams *para
 // buffer, whose rows are `total` frames long.  PCM = the recorder's 16-bit format (zl_render.h, zl_pcm16), [B][total][2]; otherwise
 // the floats as they are, [B][2][total].  Four frames per lane: 16-byte loads, one (PCM) or two 16-byte stores.  The engine uses it
 // for the 16-bit conversion into a device staging buffer (total = frames); the copy engine moves the rows to the host.
-template <bool PCM>
+// VEC = 4: four frames per lane where rows, offset and length allow 16-byte accesses, and a per-frame tail for the last frames % 4 frames;
+// VEC = 1: every frame on its own (rows or offsets that are no multiple of four frames: periods of 441 or 33 frames with odd windows).
+template <bool PCM, int VEC>
 __global__ void __launch_bounds__(256) zl_k_deliver(const float *bus, void *out, long long in_stride, long long off, long long frames, long long total)
 {
     // frames [off, off + frames) of every bus row (rows are in_stride floats apart) -> the same frames of the output (rows of `total` frames)
     const int b = blockIdx.y;
-    const float4 *L = reinterpret_cast<const float4 *>(bus + (size_t)b * 2 * in_stride + off), *R = reinterpret_cast<const float4 *>(bus + ((size_t)b * 2 + 1) * in_stride + off);
-    const long long nvec = frames / 4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const float4 l = L[i], r = R[i];
-        if (PCM) {
-            auto pair = [](float a, float c) { return (uint32_t)(uint16_t)zl_pcm16(a) | ((uint32_t)(uint16_t)zl_pcm16(c) << 16); };
-            reinterpret_cast<uint4 *>(static_cast<int16_t *>(out) + ((size_t)b * total + off) * 2)[i] = make_uint4(pair(l.x, r.x), pair(l.y, r.y), pair(l.z, r.z), pair(l.w, r.w));
-        } else {
-            float *o = static_cast<float *>(out) + (size_t)b * 2 * total + off;
-            reinterpret_cast<float4 *>(o)[i] = l;
-            reinterpret_cast<float4 *>(o + total)[i] = r;
+    const float *Ls = bus + (size_t)b * 2 * in_stride + off, *Rs = bus + ((size_t)b * 2 + 1) * in_stride + off;
+    auto pair = [](float a, float c) { return (uint32_t)(uint16_t)zl_pcm16(a) | ((uint32_t)(uint16_t)zl_pcm16(c) << 16); };
+    const long long nvec = VEC == 4 ? frames / 4 : 0;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    if (VEC == 4) {
+        const float4 *L = reinterpret_cast<const float4 *>(Ls), *R = reinterpret_cast<const float4 *>(Rs);
+        for (long long i = tid; i < nvec; i += nth) {
+            const float4 l = L[i], r = R[i];
+            if (PCM) {
+                reinterpret_cast<uint4 *>(static_cast<int16_t *>(out) + ((size_t)b * total + off) * 2)[i] = make_uint4(pair(l.x, r.x), pair(l.y, r.y), pair(l.z, r.z), pair(l.w, r.w));
+            } else {
+                float *o = static_cast<float *>(out) + (size_t)b * 2 * total + off;
+                reinterpret_cast<float4 *>(o)[i] = l;
+                reinterpret_cast<float4 *>(o + total)[i] = r;
+            }
         }
+    }
+    for (long long i = nvec * 4 + tid; i < frames; i += nth) {     // the tail (VEC = 4: at most three frames), or everything (VEC = 1)
+        const float l = Ls[i], r = Rs[i];
+        if (PCM) reinterpret_cast<uint32_t *>(static_cast<int16_t *>(out) + ((size_t)b * total + off) * 2)[i] = pair(l, r);
+        else { float *o = static_cast<float *>(out) + (size_t)b * 2 * total + off; o[i] = l; o[total + i] = r; }
     }
 }
 
@@ -1820,11 +1892,15 @@ int zl_launch_passthrough(const void *params_dev, const float *in, float *out, i
 
 int zl_launch_deliver(const float *bus, void *out, int pcm16, int B, long long in_stride, long long off, long long frames, long long total, hipStream_t s)
 {
-    long long nb = (frames / 4 + 255) / 256;
+    // 16-byte accesses need rows, offset and the output rows to start on multiples of four frames (the base pointers are allocations)
+    const bool vec = ((in_stride | off | total) & 3) == 0 && (reinterpret_cast<uintptr_t>(bus) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    long long nb = ((vec ? frames / 4 : frames) + 255) / 256;
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
-    if (pcm16) hipLaunchKernelGGL(zl_k_deliver<true>, dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, in_stride, off, frames, total);
-    else       hipLaunchKernelGGL(zl_k_deliver<false>, dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, in_stride, off, frames, total);
+    if (pcm16) { if (vec) hipLaunchKernelGGL((zl_k_deliver<true, 4>), dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, in_stride, off, frames, total);
+                 else     hipLaunchKernelGGL((zl_k_deliver<true, 1>), dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, in_stride, off, frames, total); }
+    else       { if (vec) hipLaunchKernelGGL((zl_k_deliver<false, 4>), dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, in_stride, off, frames, total);
+                 else     hipLaunchKernelGGL((zl_k_deliver<false, 1>), dim3((unsigned)nb, B), dim3(256), 0, s, bus, out, in_stride, off, frames, total); }
     ZL_LAUNCH_CHECK();
     return 0;
 }

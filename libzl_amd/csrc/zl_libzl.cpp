@@ -93,7 +93,9 @@ struct PositionsModel {
     }
 };
 
-struct PassState { float dry = 1.0f, fx1 = 1.0f, fx2 = 1.0f, pan = 0.0f; bool muted = false; };   // JackPassthrough.cpp:27-31
+// JackPassthrough.cpp:27-31.  Written by the host's setters on any thread, read by the cycle (libzl_hotpath_*_fanout) field by field,
+// as the reference's process() reads the members its setters store: relaxed atomics, no lock on either side.
+struct PassState { std::atomic<float> dry{1.0f}, fx1{1.0f}, fx2{1.0f}, pan{0.0f}; std::atomic<bool> muted{false}; };
 
 }  // namespace
 
@@ -164,6 +166,7 @@ struct Global {
     void (*timerCallbacks[16])(int) = {};      // CallbackSpaces, SyncTimer.cpp:249
     std::vector<int> beats;                    // beats the timer ticked through in this cycle (hiResTimerCallback, :397-399)
     PassState pass[11];                        // [0] GlobalPlayback (channel -1), [1..10] channels 0..9 (MidiRouter.cpp:876-883)
+    std::vector<zlhip_passthrough_params> passNow;   // per bus: the passthrough parameters of the cycle being rendered
 } G;
 
 struct PendingCallback { void (*fn)(float); float value; };
@@ -364,6 +367,8 @@ PassState *pass_for(int channel)                                   // libzl.cpp:
     return nullptr;
 }
 
+bool bpm_usable(uint64_t bpm) { return bpm > 0 && bpm * (uint64_t)ZLHIP_BEAT_SUBDIVISIONS <= 60000000000ULL; }
+
 // the requests posted since the last cycle, in arrival order, into the scheduler that serves this cycle (call with G.mu held)
 void drain_requests(bool internalTransport)
 {
@@ -394,9 +399,12 @@ void drain_requests(bool internalTransport)
                 G.ext.steps[i].clipCommands.push_back(c);          // appended, not merged (SyncTimer.cpp:858-859)
             }
             break;
-        case Request::TimerStart: if (internalTransport) G.seq.start(r.a); break;
+        // (a bpm of 0 -- or one so large that a subbeat has no nanoseconds, 60e9 / (bpm * 96) == 0 -- divides by zero in the step clock,
+        // here on the audio thread where the reference would fault on the caller's: such a request is ignored.  Every other value is
+        // taken as it is, as the reference does -- it clamps to 50..200 only when the SetBpm timer command plays, SyncTimer.cpp:606-612)
+        case Request::TimerStart: if (internalTransport && bpm_usable((uint64_t)(uint32_t)r.a)) G.seq.start(r.a); break;
         case Request::TimerStop:  if (internalTransport) G.seq.stop(); break;
-        case Request::SetBpm:     if (internalTransport) G.seq.setBpm((uint64_t)(uint32_t)r.a); break;
+        case Request::SetBpm:     if (internalTransport && bpm_usable((uint64_t)(uint32_t)r.a)) G.seq.setBpm((uint64_t)(uint32_t)r.a); break;
         case Request::TimerTick:  if (internalTransport) { G.seq.beatSink = &G.beats; G.seq.hi_res_timer_callback(); } break;
         case Request::ChannelEnabled: if (G.engine) (void)zlhip_bus_set_enabled(G.engine, r.a + 2, r.b); break;   // (an unknown channel is ignored, SamplerSynth.cpp:345)
         }
@@ -434,9 +442,34 @@ int dispatch_due(bool trackPositions = true)   // (false: the offline bounce, wh
 }
 
 // everything of a cycle behind the command dispatch: render, positions models, level / progress chains (call with G.mu held)
-int render_and_report(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right, std::vector<PendingCallback> &cbs)
+// The JackPassthrough client behind sampler channel `bus` (MidiRouter.cpp:876-883: "GlobalPlayback" behind channel -1 = bus 1,
+// "FXPassthrough-Channel1..10" behind channels 0..9 = buses 2..11), as this cycle finds its members.  Bus 0 (channel -2, the
+// un-effected global channel) and buses beyond 11 have no client in the reference: they get a client at its defaults (every pair = the bus).
+zlhip_passthrough_params pass_of_bus(int bus)
 {
-    int rc = zlhip_render(G.engine, (int32_t)nframes, clock, out_left, out_right);
+    zlhip_passthrough_params p;
+    zlhip_passthrough_params_default(&p);
+    if (bus >= 1 && bus <= 11) {
+        const PassState &q = G.pass[bus - 1];
+        p.dry_amount = q.dry.load(std::memory_order_relaxed); p.wet_fx1_amount = q.fx1.load(std::memory_order_relaxed);
+        p.wet_fx2_amount = q.fx2.load(std::memory_order_relaxed); p.pan_amount = q.pan.load(std::memory_order_relaxed);
+        p.muted = q.muted.load(std::memory_order_relaxed) ? 1 : 0;
+    }
+    return p;
+}
+
+int render_and_report(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right, std::vector<PendingCallback> &cbs, float *fan_out = nullptr)
+{
+    int rc;
+    if (fan_out) {
+        // the passthrough clients' members as of this cycle (the setters are plain stores on the host's threads: no lock, no HIP call,
+        // the resident kernel stays where it is)
+        G.passNow.resize(G.reports.size() ? (size_t)(G.cfgSet ? G.cfg.num_buses : 12) : 0);
+        for (size_t b = 0; b < G.passNow.size(); ++b) G.passNow[b] = pass_of_bus((int)b);
+        rc = zlhip_render_fanout(G.engine, (int32_t)nframes, clock, out_left, out_right, G.passNow.data(), fan_out);
+    } else {
+        rc = zlhip_render(G.engine, (int32_t)nframes, clock, out_left, out_right);
+    }
     if (rc != ZLHIP_OK) return rc;
     const int V = (int)G.reports.size();
     rc = zlhip_voice_reports(G.engine, G.reports.data(), V);
@@ -811,6 +844,11 @@ static void fire(std::vector<PendingCallback> &cbs)
 // host-owned transport: the host's SyncTimer getters arrive in `clock`
 int libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right)
 {
+    return libzl_hotpath_process_fanout(nframes, clock, out_left, out_right, nullptr);
+}
+
+int libzl_hotpath_process_fanout(uint32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right, float *fan_out)
+{
     static thread_local std::vector<PendingCallback> cbs;
     int rc;
     {
@@ -822,7 +860,7 @@ int libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out
         for (ClipAudioSource *c : G.clips) if (c->id >= 0) apply_params(c);
         G.ext.process(clock->jack_playhead, G.due);                 // currentTick = the host's jackPlayhead (SyncTimer.cpp:553-558)
         rc = dispatch_due();
-        if (rc == ZLHIP_OK) rc = render_and_report(nframes, clock, out_left, out_right, cbs);
+        if (rc == ZLHIP_OK) rc = render_and_report(nframes, clock, out_left, out_right, cbs, fan_out);
     }
     fire(cbs);
     return rc;
@@ -831,6 +869,11 @@ int libzl_hotpath_process(uint32_t nframes, const zlhip_clock *clock, float *out
 // the library's own transport: SyncTimerPrivate::process for this JACK cycle, then every SamplerChannel (the order in which the two
 // JACK clients run inside a cycle is not defined in the reference; here the commands of a cycle reach the channels in the same cycle)
 int libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, float *out_left, float *out_right)
+{
+    return libzl_hotpath_cycle_fanout(nframes, current_usecs, next_usecs, period_usecs, out_left, out_right, nullptr);
+}
+
+int libzl_hotpath_cycle_fanout(uint32_t nframes, uint64_t current_usecs, uint64_t next_usecs, float period_usecs, float *out_left, float *out_right, float *fan_out)
 {
     static thread_local std::vector<PendingCallback> cbs;
     static thread_local std::vector<int> beats;
@@ -850,7 +893,7 @@ int libzl_hotpath_cycle(uint32_t nframes, uint64_t current_usecs, uint64_t next_
             clk.jack_playhead = G.seq.jackPlayheadGetter();                         // SamplerSynthVoice.cpp:179-182,232-237 read these getters
             clk.jack_playhead_usecs = G.seq.jackPlayheadUsecsGetter();
             clk.jack_subbeat_length_usecs = G.seq.jackSubbeatLengthInMicroseconds;
-            rc = render_and_report(nframes, &clk, out_left, out_right, cbs);
+            rc = render_and_report(nframes, &clk, out_left, out_right, cbs, fan_out);
         }
         // the timer thread ticks once per subbeat while it runs (SyncTimer.cpp:117-163): modelled as one tick between two cycles
         G.seq.beatSink = &G.beats;
@@ -944,23 +987,27 @@ int libzl_hotpath_bounce_to_wav(const char *prefix, int64_t nblocks, uint32_t nf
 }
 
 // ---- JackPassthrough bridge (libzl.cpp:476-575) ------------------------------------------------------------
-void  JackPassthrough_setPanAmount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->pan = amount; }
-float JackPassthrough_getPanAmount(int channel) { PassState *p = pass_for(channel); return p ? p->pan : 0.0f; }
-float JackPassthrough_getWetFx1Amount(int channel) { PassState *p = pass_for(channel); return p ? p->fx1 : 0.0f; }
-void  JackPassthrough_setWetFx1Amount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->fx1 = amount; }
-float JackPassthrough_getWetFx2Amount(int channel) { PassState *p = pass_for(channel); return p ? p->fx2 : 0.0f; }
-void  JackPassthrough_setWetFx2Amount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->fx2 = amount; }
-float JackPassthrough_getDryAmount(int channel) { PassState *p = pass_for(channel); return p ? p->dry : 0.0f; }
-void  JackPassthrough_setDryAmount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->dry = amount; }
-float JackPassthrough_getMuted(int channel) { PassState *p = pass_for(channel); return p ? (p->muted ? 1.0f : 0.0f) : 0.0f; }
-void  JackPassthrough_setMuted(int channel, bool muted) { if (PassState *p = pass_for(channel)) p->muted = muted; }
+void  JackPassthrough_setPanAmount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->pan.store(amount, std::memory_order_relaxed); }
+float JackPassthrough_getPanAmount(int channel) { PassState *p = pass_for(channel); return p ? p->pan.load(std::memory_order_relaxed) : 0.0f; }
+float JackPassthrough_getWetFx1Amount(int channel) { PassState *p = pass_for(channel); return p ? p->fx1.load(std::memory_order_relaxed) : 0.0f; }
+void  JackPassthrough_setWetFx1Amount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->fx1.store(amount, std::memory_order_relaxed); }
+float JackPassthrough_getWetFx2Amount(int channel) { PassState *p = pass_for(channel); return p ? p->fx2.load(std::memory_order_relaxed) : 0.0f; }
+void  JackPassthrough_setWetFx2Amount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->fx2.store(amount, std::memory_order_relaxed); }
+float JackPassthrough_getDryAmount(int channel) { PassState *p = pass_for(channel); return p ? p->dry.load(std::memory_order_relaxed) : 0.0f; }
+void  JackPassthrough_setDryAmount(int channel, float amount) { if (PassState *p = pass_for(channel)) p->dry.store(amount, std::memory_order_relaxed); }
+float JackPassthrough_getMuted(int channel) { PassState *p = pass_for(channel); return p ? (p->muted.load(std::memory_order_relaxed) ? 1.0f : 0.0f) : 0.0f; }
+void  JackPassthrough_setMuted(int channel, bool muted) { if (PassState *p = pass_for(channel)) p->muted.store(muted, std::memory_order_relaxed); }
 int   JackPassthrough_getParams(int channel, zlhip_passthrough_params *out)
 {
     PassState *p = pass_for(channel);
     if (!p || !out) return ZLHIP_ERR_INVALID;
-    out->dry_amount = p->dry; out->wet_fx1_amount = p->fx1; out->wet_fx2_amount = p->fx2; out->pan_amount = p->pan; out->muted = p->muted ? 1 : 0;
+    out->dry_amount = p->dry.load(std::memory_order_relaxed); out->wet_fx1_amount = p->fx1.load(std::memory_order_relaxed);
+    out->wet_fx2_amount = p->fx2.load(std::memory_order_relaxed); out->pan_amount = p->pan.load(std::memory_order_relaxed);
+    out->muted = p->muted.load(std::memory_order_relaxed) ? 1 : 0;
     return ZLHIP_OK;
 }
+
+uint64_t libzl_hotpath_dropped_requests(void) { return G.dropped.load(std::memory_order_relaxed); }
 
 }  // extern "C"
 #endif  // ZLHIP_NO_LIBZL_NAMES

@@ -168,6 +168,8 @@ struct ZlReport {                 // device side of zlhip_voice_report
     double  P;
 };
 
+static_assert(sizeof(ZlReport) == 32, "a report is two 16-byte words (zl_k2_body publishes it that way)");
+
 struct ZlBlockLevels {            // per (block, bus)
     int32_t peak_l, peak_r;       // max over the block of (int)|131072*x|
     float   sumsq_l, sumsq_r;     // sum of squares (RMS extension)
@@ -224,6 +226,10 @@ struct ZlRtShared {
     int32_t  n_clip_edits;
     uint32_t yield;               // another thread of the process is about to make a device-synchronising HIP call (hipFree, ...):
                                   // leave after the cycle in flight (zl_engine.cpp, ZlQuiesce)
+    uint32_t fan_seq;             // 0: this cycle delivers the buses only.  Else: it also delivers the JackPassthrough fan-out of every bus
+                                  // (ZlBatch::fan, mapped host memory) and this is the version of the parameter table (ZlBatch::pass, mapped
+                                  // host memory too): a workgroup re-reads its bus's entry only when the version moved (a knob was turned)
+    uint32_t pad;
 };
 
 // Device side of the resident kernel: workgroup 0 watches the mailbox and republishes every block in HBM for the other
@@ -289,6 +295,20 @@ struct ZlBatch {
     ZlPassCache        *pass_cache; // [V] or nullptr
     const ZlPassParams *pass;     // [B] JackPassthrough parameters of the fused fan-out (with fan)
     float              *fan;      // [B][6][Ktot*N] dry L,R / wetFx1 L,R / wetFx2 L,R of every bus, or nullptr
+    ZlPassParams        pass0;    // pass_inline = 1 (resident kernel): the parameters of the workgroup's bus travel here instead of in pass[]
+    int32_t             pass_inline;
+    int32_t             tile_accum; // 1 (resident kernel, blocks longer than 256 frames): ONE workgroup walks the frame tiles of its block in
+                                    // order (bx = 0, 1, ...), and the fused level scan carries on from tile to tile (same defined order)
+    // the call's per-voice reports, published by the K2 workgroups that render its LAST block (fused_reports = 1: every bus of that
+    // block is summed whole by one workgroup, so each of them knows its voices' peaks without asking anybody): gain = peak * 0.5f
+    // (SamplerSynthVoice.cpp:266) into rep_gain, the reports and gains into mapped host memory, the call's statistics too -- the report
+    // kernel and its packet between two calls' render kernels are gone
+    float              *rep_gain;       // [V] HBM
+    ZlReport           *rep_host;       // [V] mapped host memory, or nullptr
+    float              *rep_host_gain;  // [V]
+    ZlBatchStats       *rep_host_stats; // mapped host memory, or nullptr
+    int32_t             fused_reports;
+    int32_t             pad_reports;
     ZlBlockLevels      *levels;   // [K][B]
     int32_t            *pos_trace;// [K][V][N] or null
     ZlBatchStats       *stats;

@@ -236,6 +236,17 @@ class SamplerSynth:
         self._last = (1, nframes)
         return L, R
 
+    def process_fanout(self, nframes: int, clock: Clock, fan_params: Sequence[PassthroughParams]):
+        """One real-time cycle with the JackPassthrough client behind every bus (zlhip_render_fanout): returns
+        (left[B,N], right[B,N], fan[B,6,N]) -- fan rows = dryL, dryR, fx1L, fx1R, fx2L, fx2R."""
+        L = np.empty((self.num_buses, nframes), dtype=np.float32)
+        R = np.empty((self.num_buses, nframes), dtype=np.float32)
+        fan = np.empty((self.num_buses, 6, nframes), dtype=np.float32)
+        arr = (PassthroughParams * self.num_buses)(*fan_params)
+        self._ck(self._lib.zlhip_render_fanout(self._e, nframes, C.byref(clock), L.ctypes.data, R.ctypes.data, arr, fan.ctypes.data), "render_fanout")
+        self._last = (1, nframes)
+        return L, R, fan
+
     def render_batch(self, nblocks: int, nframes: int, clocks, bus_out_dev: Optional[int] = None, stream: Optional[int] = None,
                      fan_params: Optional[Sequence[PassthroughParams]] = None, fan_out_dev: Optional[int] = None):
         """fan_params + fan_out_dev: also write the JackPassthrough fan-out [num_buses][6][nblocks*nframes] (fused)."""
@@ -346,6 +357,19 @@ class SamplerSynth:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._ck(self._lib.zlhip_rt_stats(self._e, C.byref(a), C.byref(b)), "rt_stats")
         return a.value, b.value
+
+    def rt_last_cycle(self):
+        """Where the last real-time cycle spent its time (engines created with ZL_RT_TRACE=1): an _abi.RtCycleTrace."""
+        from ._abi import RtCycleTrace
+        t = RtCycleTrace()
+        self._ck(self._lib.zlhip_rt_last_cycle(self._e, C.byref(t)), "rt_last_cycle")
+        return t
+
+    def rt_residency(self):
+        """(is the resident real-time kernel on the device right now, the share of the device's resident capacity it takes)"""
+        r, sh = C.c_int32(0), C.c_double(0.0)
+        self._ck(self._lib.zlhip_rt_residency(self._e, C.byref(r), C.byref(sh)), "rt_residency")
+        return bool(r.value), sh.value
 
     def bus_device_ptr(self) -> int:
         return self._lib.zlhip_bus_device_ptr(self._e)

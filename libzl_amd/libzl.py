@@ -59,6 +59,9 @@ SIGNATURES = {
     "SyncTimer_queueClipToStop": (None, [_P]),
     "SyncTimer_queueClipToStopOnChannel": (None, [_P, C.c_int]),
     "libzl_hotpath_cycle": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
+    "libzl_hotpath_cycle_fanout": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "libzl_hotpath_process_fanout": (C.c_int, [C.c_uint32, C.POINTER(Clock), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "libzl_hotpath_dropped_requests": (C.c_uint64, []),
     "libzl_hotpath_schedule_clip_command": (None, [C.POINTER(_abi.ClipCommand), C.c_uint64]),
     "libzl_hotpath_clip_params": (C.c_int, [C.c_void_p, C.POINTER(_abi.ClipParams)]),
     "libzl_hotpath_timer_tick": (None, []),

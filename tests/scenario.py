@@ -197,7 +197,11 @@ def run_backend(scene: Scene, factory: Callable, batch: int = 1 << 30, trace: bo
             fans.append(torch.full((scene.num_buses, 6, n * scene.nframes), 7.0, device="cuda", dtype=torch.float32))
             fan_kw = dict(fan_params=fanout, fan_out_dev=fans[-1].data_ptr())
         if bounce is not None:
-            buses.append(np.array(syn.bounce(n, scene.nframes, scene.make_clocks(k0, n), fmt=bounce[0], sub_blocks=bounce[1]), copy=True))
+            pageable = None
+            if len(bounce) > 2 and bounce[2] == "pageable":        # the caller's own (pageable) memory: the copy-engine path
+                pageable = np.full((scene.num_buses, n * scene.nframes, 2), 0x5a5a, dtype=np.int16) if bounce[0] == "pcm16" else \
+                    np.full((scene.num_buses, 2, n * scene.nframes), 9.0, dtype=np.float32)
+            buses.append(np.array(syn.bounce(n, scene.nframes, scene.make_clocks(k0, n), fmt=bounce[0], sub_blocks=bounce[1], out=pageable), copy=True))
             continue
         if pipelined:
             out = torch.zeros((scene.num_buses, 2, n * scene.nframes), device="cuda", dtype=torch.float32)

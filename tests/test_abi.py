@@ -63,9 +63,9 @@ def test_struct_sizes_match_the_c_layout(lib):
         #include <stdio.h>
         #include "zlhip.h"
         int main(void) {
-            printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(zlhip_config), sizeof(zlhip_clock), sizeof(zlhip_clip_params),
+            printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(zlhip_config), sizeof(zlhip_clock), sizeof(zlhip_clip_params),
                    sizeof(zlhip_clip_command), sizeof(zlhip_voice_report), sizeof(zlhip_levels), sizeof(zlhip_passthrough_params),
-                   sizeof(zlhip_timings));
+                   sizeof(zlhip_timings), sizeof(zlhip_rt_cycle_trace));
             return 0;
         }""")
     with tempfile.TemporaryDirectory() as d:
@@ -73,13 +73,13 @@ def test_struct_sizes_match_the_c_layout(lib):
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "p")]).split()]
     got = [C.sizeof(t) for t in (_abi.Config, _abi.Clock, _abi.ClipParams, _abi.ClipCommand, _abi.VoiceReport, _abi.Levels,
-                                 _abi.PassthroughParams, _abi.Timings)]
+                                 _abi.PassthroughParams, _abi.Timings, _abi.RtCycleTrace)]
     assert got == sizes
 
 
 def test_defaults_and_plain_helpers_work_without_a_gpu(lib):
     _abi.bind(lib)
-    assert lib.zlhip_abi_version() == 2
+    assert lib.zlhip_abi_version() == 3
     cfg = _abi.Config()
     lib.zlhip_config_default(C.byref(cfg))
     assert (cfg.num_buses, cfg.voices_per_bus) == (12, 8)      # SamplerSynth.cpp:23,258

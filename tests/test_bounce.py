@@ -94,6 +94,36 @@ def test_bounce_with_periods_that_are_no_multiple_of_64(Engine, nframes, sub):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nframes,sub", [(441, 3), (33, 7), (100, 5)])
+@pytest.mark.parametrize("how", ["pageable", "copy_engine"])
+def test_bounce_through_the_copy_engine_with_odd_periods(Engine, nframes, sub, how):
+    """The copy-engine delivery (pageable destination, or ZL_BOUNCE_DIRECT=0) converts every plan window with zl_k_deliver first: window
+    lengths K * nframes that are no multiple of four frames -- 441 x 3, 33 x 7 -- have a per-frame tail, and rows / offsets that are no
+    multiple of four take the per-frame form (the last 1-3 frames of a window used to stay unconverted)."""
+    import os
+    from scenario import compare_runs, random_scene, run_backend, run_oracle
+    sc = random_scene(0xC1 + nframes, num_buses=3, voices_per_bus=8, nclips=10, nframes=nframes, nblocks=23)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    want = np.stack([npr.pcm16(ref_bus[:, 0]), npr.pcm16(ref_bus[:, 1])], axis=2)
+    old = os.environ.get("ZL_BOUNCE_DIRECT")
+    if how == "copy_engine":
+        os.environ["ZL_BOUNCE_DIRECT"] = "0"
+    try:
+        extra = ("pageable",) if how == "pageable" else ()
+        pcm, _, syn, _ = run_backend(sc, Engine, bounce=("pcm16", sub) + extra)
+        assert np.array_equal(pcm, want), np.argwhere(pcm != want)[:4].tolist()
+        syn.close()
+        bus, rep, syn, _ = run_backend(sc, Engine, bounce=("f32", sub) + extra)
+        compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 24)
+        syn.close()
+    finally:
+        if old is None:
+            os.environ.pop("ZL_BOUNCE_DIRECT", None)
+        else:
+            os.environ["ZL_BOUNCE_DIRECT"] = old
+
+
+@pytest.mark.gpu
 def test_bounce_into_caller_memory_and_argument_checks(Engine):
     from libzl_amd.engine import ZlHipError, synthetic_clocks
     syn = Engine(num_buses=2, voices_per_bus=4, max_frames=256, max_batch_blocks=8, max_sounds=4)

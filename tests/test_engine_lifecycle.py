@@ -306,6 +306,33 @@ def test_the_source_arena_grows_in_segments(Engine):
     L1, R1 = syn.process(128, synthetic_clocks(1, 128, 48000.0, start_block=8)[0])
     ref1, _ = osyn.render_batch(1, 128, synthetic_clocks(1, 128, 48000.0, start_block=8))
     assert np.array_equal(L1.view(np.int32), ref1[:, 0].view(np.int32)) and np.array_equal(R1.view(np.int32), ref1[:, 1].view(np.int32))
+    # a segment all of whose sources are released goes back to the device (memory only ever grew): the voices are stopped,
+    # the large source -- a segment of its own -- and then everything else is released; what stays is the arena reserved at creation
+    for i in range(12):
+        syn.stop_voice(i % 2, i // 2, False)
+    syn.process(128, synthetic_clocks(1, 128, 48000.0, start_block=9)[0])
+    syn.unregister_clip(7)
+    _, a2 = syn.memory_bytes()
+    assert a2 < a1 and a2 >= arena
+    for i in range(12):
+        if i != 7:
+            syn.unregister_clip(i)
+    total3, a3 = syn.memory_bytes()
+    assert a3 == arena and total3 == total0
+    # ... and the engine goes on: new sources, same bits as the oracle
+    for i in range(3):
+        cid = syn.register_clip(*clips[i], 48000.0)
+        p = syn.default_clip_params(len(clips[i][0]) / 48000.0); p.length_in_beats = 0.41; p.length_seconds = float(np.float32(0.03)); syn.set_clip_params(cid, p)
+    o2 = zo.OracleSynth(2, 8, 48000.0, 0, max_sounds=32)
+    for i in range(3):
+        oid = o2.register_clip(*clips[i], 48000.0)
+        oc = o2.clips[oid]; oc.lengthInBeats = 0.41; oc.lengthInSeconds = float(np.float32(0.03))
+        assert syn.handle_clip_command(clip_command(clip=i, midi_note=60, midi_channel=-2, start_playback=1, looping=1, change_volume=1, volume=0.7), 0) == 1
+        o2.handle_clip_command(zo.clip_command(clip=oid, midiNote=60, midiChannel=-2, startPlayback=1, looping=1, changeVolume=1, volume=0.7), 0)
+    clk2 = synthetic_clocks(8, 128, 48000.0, start_block=10)
+    syn.render_batch(8, 128, clk2)
+    ref2, _ = o2.render_batch(8, 128, clk2)
+    assert np.array_equal(syn.read_bus().view(np.int32), ref2.view(np.int32)) and np.abs(ref2).max() > 0.3
     syn.close()
     # capped: the same uploads stop fitting
     cap = Engine(2, 8, max_frames=128, max_batch_blocks=8, max_sounds=32, sound_arena_bytes=arena, sound_arena_max_bytes=3 * arena)

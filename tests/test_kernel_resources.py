@@ -27,7 +27,9 @@ def test_resident_kernel_keeps_its_state_in_registers(built):
     assert len(rt) == 16                                           # 8 modes x narrow / wide
     for n, r in rt.items():
         assert r["scratch"] <= 64, (n, r)                          # (56 bytes: a small local array; 1 KB meant calls and +13 us per cycle)
-        assert r["vgpr_spill"] == 0, (n, r)
+        # (held to two waves per SIMD -- amdgpu_waves_per_eu(2, 2): the capacity rule counts on two resident workgroups per CU; under that
+        # budget the Hermite + FIX_DELAY wide variants park two registers in 12 bytes of scratch, everything else none)
+        assert r["vgpr_spill"] <= 2 and r["waves"] == 2, (n, r)
 
 
 def test_render_kernels_do_not_spill_where_the_design_says_so(built):

@@ -12,14 +12,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "zlhip.h"
 
 using clk = std::chrono::steady_clock;
 
-struct Row { int V, B, N; bool resident, paced, fan; };
+struct Row { int V, B, N; bool resident, paced, fan; int hogs; };   // hogs: busy threads next to the cycle thread (more than the box's CPU quota: the attribution's known answer)
 
 static int run(const Row &r, int cycles)
 {
@@ -56,6 +58,9 @@ static int run(const Row &r, int cycles)
     us.reserve((size_t)cycles);
     struct Slow { int k; double harness; zlhip_rt_cycle_trace t; };
     std::vector<Slow> slow;
+    std::atomic<bool> stopHogs{false};
+    std::vector<std::thread> hogs;
+    for (int i = 0; i < r.hogs; ++i) hogs.emplace_back([&stopHogs] { volatile unsigned long long x = 0; while (!stopHogs.load(std::memory_order_relaxed)) x = x + 1; });
     auto tNext = clk::now();
     for (int k = 0; k < cycles + 50; ++k) {
         if (r.paced) { while (clk::now() < tNext) { } tNext += periodNs; }
@@ -71,21 +76,26 @@ static int run(const Row &r, int cycles)
         us.push_back(d);
         if (d > 1000.0) { Slow s; s.k = k; s.harness = d; zlhip_rt_last_cycle(e, &s.t); slow.push_back(s); }
     }
+    stopHogs.store(true);
+    for (auto &h : hogs) h.join();
     uint64_t starts = 0, cyc = 0;
     zlhip_rt_stats(e, &starts, &cyc);
     std::vector<double> sorted = us;
     std::sort(sorted.begin(), sorted.end());
     std::printf("V=%4d B=%3d N=%4d %s %s %s: p50 %6.1f us  p99 %6.1f us  p99.9 %6.1f us  max %8.1f us  (period %5.0f us, %d cycles, resident launches %llu, cycles over 1 ms: %zu)\n",
-                r.V, r.B, r.N, r.resident ? "resident" : "launched", r.paced ? "paced    " : "back2back", r.fan ? "fan-out" : "       ",
+                r.V, r.B, r.N, r.resident ? "resident" : "launched", r.paced ? "paced    " : "back2back", r.fan ? "fan-out" : (r.hogs ? "+hogs  " : "       "),
                 sorted[sorted.size() / 2], sorted[(size_t)((double)sorted.size() * 0.99)], sorted[(size_t)((double)sorted.size() * 0.999)], sorted.back(),
                 1e6 * r.N / fs, cycles, (unsigned long long)starts, slow.size());
-    for (const Slow &s : slow)
+    for (size_t si = 0; si < slow.size(); ++si) {
+        const Slow &s = slow[si];
+        if (si == 8) { std::printf("    ... and %zu more\n", slow.size() - 8); break; }
         std::printf("    cycle %6d: %8.0f us at the caller; inside the engine %8.0f = before the post %6.0f + wait %8.0f + after %5.0f; longest poll gap of the waiting thread %8.0f us, "
                     "involuntary context switches %lld -> %s\n", s.k, s.harness, s.t.total_us, s.t.before_post_us, s.t.wait_us, s.t.after_us, s.t.max_poll_gap_us,
                     (long long)s.t.involuntary_switches,
                     s.t.max_poll_gap_us > 0.5 * s.t.total_us ? "the waiting THREAD was off its core (host scheduler / cgroup quota), not the device"
                     : s.t.before_post_us > 0.5 * s.t.total_us ? "host side, before the cycle was posted (a HIP call: kernel restart / launch)"
                     : s.t.wait_us > 0.5 * s.t.total_us ? "the device (or its runtime) took the time" : "host side, after the device was done");
+    }
     std::fflush(stdout);
     zlhip_engine_destroy(e);
     return 0;
@@ -99,18 +109,22 @@ int main(int argc, char **argv)
     if (quick) cycles = std::min(cycles, 2000);
     std::vector<Row> rows;
     for (int res = 0; res < 2; ++res) {
-        rows.push_back({96, 12, 256, res == 1, false, false});      // the reference's own shape: 12 channels x 8 voices
-        rows.push_back({64, 8, 256, res == 1, false, false});       // BASELINE configs[1]
-        rows.push_back({96, 12, 128, res == 1, false, false});
-        rows.push_back({96, 12, 512, res == 1, false, false});
-        rows.push_back({96, 12, 1024, res == 1, false, false});
-        rows.push_back({96, 12, 256, res == 1, false, true});       // with the JackPassthrough fan-out (three more pairs per bus over PCIe)
+        rows.push_back({96, 12, 256, res == 1, false, false, 0});      // the reference's own shape: 12 channels x 8 voices
+        rows.push_back({64, 8, 256, res == 1, false, false, 0});       // BASELINE configs[1]
+        rows.push_back({96, 12, 128, res == 1, false, false, 0});
+        rows.push_back({96, 12, 512, res == 1, false, false, 0});
+        rows.push_back({96, 12, 1024, res == 1, false, false, 0});
+        rows.push_back({96, 12, 256, res == 1, false, true, 0});       // with the JackPassthrough fan-out (three more pairs per bus over PCIe)
     }
     for (int res = 0; res < 2; ++res) {
-        rows.push_back({96, 12, 256, res == 1, true, false});       // paced: one cycle per JACK period, as JACK runs it (the GPU idles in between)
-        rows.push_back({96, 12, 256, res == 1, true, true});
-        if (!quick) { rows.push_back({96, 12, 512, res == 1, true, false}); rows.push_back({96, 12, 1024, res == 1, true, false}); }
+        rows.push_back({96, 12, 256, res == 1, true, false, 0});       // paced: one cycle per JACK period, as JACK runs it (the GPU idles in between)
+        rows.push_back({96, 12, 256, res == 1, true, true, 0});
+        if (!quick) { rows.push_back({96, 12, 512, res == 1, true, false, 0}); rows.push_back({96, 12, 1024, res == 1, true, false, 0}); }
     }
+    // the attribution's known answer: far more busy threads than the box grants this job CPUs (cgroup quota) -- the cycle thread loses
+    // its core every now and then, and the slow cycles must read "the waiting THREAD was off its core", not "the device"
+    const int hw = (int)std::thread::hardware_concurrency();
+    rows.push_back({96, 12, 256, true, false, false, std::max(24, std::min(hw, 64))});
     for (const Row &r : rows) {
         int n = cycles;
         if (r.paced) n = std::min(cycles, (int)(8.0 * 48000.0 / r.N));   // at most ~8 s per paced row

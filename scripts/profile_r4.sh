@@ -1,11 +1,17 @@
 #!/bin/bash
-# Round-2 evidence run on one MI355X box (gpurun).  Usage: scripts/profile_r2.sh <tag>
-# Produces under gpurun_out/<tag>/: the default bench line (with cpu_baseline), rocprofv3 kernel-trace + stats and PMC passes
-# for the timed (2 s sources) workload and for the no-reuse (10 s sources: HBM only) workload, the config sweep.
+# The round's evidence run on one MI355X box (gpurun).  Usage: scripts/profile_r4.sh <tag>   (then: python3 scripts/publish_profile.py <tag> round4_x)
+# Produces under gpurun_out/<tag>/: the default bench line (with cpu_baseline), rocprofv3 kernel-trace + stats and PMC passes (separate
+# runs) for the timed (2 s sources) workload and for the no-reuse (10 s sources: HBM only) workload, the config sweep with the binding
+# unit of every shape (its own PMC pass per shape), the real-time probes, the bounce figures, the N > 1 rehearsals.
+# (Rounds 2 and 3 collected profiles/round2_e_* and round3_f_* with the same bench / rocprofv3 commands.)
 set -o pipefail
-tag=${1:-r2p}
+# A gpurun call is at most 20 minutes: the collection runs in three parts, each its own call -- scripts/profile_r4.sh <tag> a | b | c
+#   a  bench line + kernel trace + five PMC passes, timed and HBM-only workload (~8 min)      b  config sweep with binding units (~12 min)
+#   c  real-time probes, bounce, N > 1 rehearsals (~9 min)
+tag=${1:-r4p}; part=${2:-a}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/$tag; rm -rf $O; mkdir -p $O
+O=gpurun_out/$tag; mkdir -p $O
+if [ $part = a ]; then
 B="--no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1"
 python3 bench.py > $O/bench_line.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
 for wl in "reuse:" "noreuse:--loop-seconds 10"; do
@@ -21,9 +27,14 @@ for wl in "reuse:" "noreuse:--loop-seconds 10"; do
   cat $O/${name}_trace_summary.txt $O/${name}_pmc?_summary.txt > $O/${name}_summary.txt
   rm -rf $O/${name}_trace $O/${name}_pmc?            # raw CSVs are large; the condensed summaries stay
 done
-# pitched Hermite (the kernel furthest below its roofline): counters of the gather path
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $O/herm_pmc -- python3 bench.py $B --hermite --notes 48,72 > $O/herm_pmc.log 2>&1 || echo "herm pmc failed"
-python3 scripts/summarize_prof.py $O/herm_pmc $O/herm_pmc_summary.txt; rm -rf $O/herm_pmc
-scripts/config_sweep.sh ${tag} > $O/config_sweep.txt 2>&1
 echo "cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)  nproc: $(nproc)" > $O/host.txt
+fi
+if [ $part = b ]; then
+python3 scripts/config_sweep.py ${tag} > $O/config_sweep.log 2>&1; cp gpurun_out/config_sweep_${tag}.txt $O/config_sweep.txt; cat $O/config_sweep.txt
+fi
+if [ $part = c ]; then
+bash scripts/r4_rt.sh ${tag} 3000 > $O/rt.log 2>&1
+python3 scripts/bounce_bench.py 2>&1 | grep -v amdgpu.ids > $O/bounce.txt
+bash scripts/r4_launch_rehearsal.sh ${tag} > $O/launch_rehearsal.log 2>&1
+fi
 ls -la $O | head -40

@@ -1,89 +1,97 @@
 #!/usr/bin/env python3
-"""Copies the results of scripts/final_check.sh <tag> from gpurun_out/ into profiles/<name>_* with a header that states
-what was profiled and how the figures were derived.  usage: publish_profile.py <tag> <name>   (e.g. r1h round1_d)"""
+"""Copies the results of scripts/profile_r2.sh <tag> from gpurun_out/<tag>/ into profiles/<name>_* with headers that state what
+was profiled and how every figure is derived.  usage: publish_profile_r2.py <tag> <name>   (e.g. r2c round2_c)"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 tag, name = sys.argv[1], sys.argv[2]
-G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+G, P = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+K2 = "void zl_k2_render<0u, 1, false>(ZlBatch)"
 
 
 def jline(path):
     return [l for l in open(path).read().strip().splitlines() if l.startswith("{")][-1]
 
 
-bl = jline(os.path.join(G, f"{tag}_bench_line.json"))
-d = json.loads(bl); r = d["roofline"]
-open(os.path.join(P, f"{name}_bench_line.json"), "w").write(bl + "\n")
-body = open(os.path.join(G, f"{tag}p_summary.txt")).read().splitlines()
-K2 = "void zl_k2_render<0u, 1>(ZlBatch)"
-
-
-def counter(c):
+def parse(summary):
+    body = open(summary).read().splitlines()
+    ctr = {}
     for l in body:
-        if l.startswith(f"{K2}, {c},"):
+        if l.startswith(K2 + ", ") and l.count(",") == 6:
             p = [x.strip() for x in l.split(",")]
-            return int(p[-3]), float(p[-2]), float(p[-1])
-    raise SystemExit(f"counter {c} not found")
+            try:
+                ctr[p[-4]] = (int(p[-3]), float(p[-2]), float(p[-1]))      # dispatches, mean, sum
+            except ValueError:
+                pass
+    shapes = [l.split(",") for l in body if l.startswith(K2 + ", 256x")]
+    big = max(shapes, key=lambda f: int(f[-4]))
+    return body, ctr, dict(grid=big[-5].strip(), n=int(big[-4]), avg=float(big[-3]), mn=float(big[-2]), mx=float(big[-1])), shapes
 
 
-fetch, write, valu, grbm, insts = (counter(c) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"))
-stats = [l for l in body if l.startswith(K2 + ",")][0].split(",")
-ndisp, avg_ns = int(stats[-7]), float(stats[-5])
-shapes = [l.split(",") for l in body if l.startswith(K2 + ", 256x")]
-big = max(shapes, key=lambda f: int(f[-4]))                       # the launch shape with the most dispatches: the full windows
-grid, n_big, avg_big, min_big, max_big = big[-5].strip(), int(big[-4]), float(big[-3]), float(big[-2]), float(big[-1])
-shape_list = ", ".join(f"{f[-4].strip()} x {f[-5].strip().split('x')[1]} blocks" for f in sorted(shapes, key=lambda f: -int(f[-5].strip().split('x')[1])))
-calls = 5
-alg_step = r["algorithmic_bytes_per_launch"] * r["launches_per_step"]
-alg_total = alg_step * calls
-traffic = 2 * fetch[2] * 1024 + write[2] * 1024
-ratio = traffic / alg_total
-json.dump({"kernel": "zl_k2_render<0,1>", "workload": "bench.py defaults (1024 voices, 8 buses, 256 frames, 8192 blocks per step, 2 s loops)",
-           "fetch_size_kib_sum": fetch[2], "write_size_kib_sum": write[2], "dispatches": fetch[0], "calls": calls,
-           "gfx950_fetch_correction": "FETCH_SIZE counts half of the bytes of 16-B/lane streaming loads: reads = 2 x FETCH_SIZE",
-           "traffic_bytes_total": traffic, "algorithmic_bytes_total": alg_total, "traffic_over_algorithmic": ratio,
-           "source": f"profiles/{name}_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"},
-          open(os.path.join(P, f"{name}_pmc.json"), "w"), indent=1)
-ach, lm, ab = r["achieved"], r["avg_launch_ms"] * 1e3, r["algorithmic_bytes_per_launch"] / 1e9
-busy = valu[1] * 4 / ((grbm[1] / 8) * 1024)
-nr = r.get("no_reuse_variant") or {}
-hdr = f"""# rocprofv3 summary, round 1, final state (profiles/{name}_*; written by scripts/publish_profile.py from scripts/final_check.sh)
-# commands (scripts/prof_counters.sh; raw CSVs condensed by scripts/summarize_prof.py; long torch kernel names cut):
-#   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-reuse-check
-#   rocprofv3 --pmc <counters> --output-format csv           -- same command, one pass per counter group
-# {calls} zlhip_render_batch calls of 8192 blocks x 1024 voices = {ndisp} K2 dispatches ({shape_list}).  A call that
-# follows a synchronisation (the warm-up call and the first timed call) starts with a quarter-size plan window, whose
-# planning nothing hides; calls queued behind a call that is still rendering use full windows of 2048 blocks.
-# zl_k1_plan / zl_k1c_assemble run on the planning stream(s) concurrently with zl_k2_render.  zl_k3_finalize is not
-# launched in this configuration (levels are scanned inside K2).  The torch / copyBuffer kernels in the statistics are
-# the scene set-up of bench.py (source generation, clip upload), outside the timed region.
+bl = jline(os.path.join(G, "bench_line.json"))
+d = json.loads(bl); r = d["roofline"]; nr = r["no_reuse_variant"]
+open(os.path.join(P, f"{name}_bench_line.json"), "w").write(bl + "\n")
+from bench import kernel_source_digest  # noqa: E402
+digest = kernel_source_digest()
+calls = 5                                                           # profile_r2.sh: --steps 4 --warmup 1
+out = {}
+for wl, loops in (("reuse", 2.0), ("noreuse", 10.0)):
+    body, c, big, shapes = parse(os.path.join(G, f"{wl}_summary.txt"))
+    # bytes of one FULL plan window (2048 blocks): the timed steps of the default run are 4 full windows each; both workloads have the
+    # same shape (ratio 1, 256-frame blocks), so the figure holds for both (the no-reuse leg's own per-launch average mixes in the
+    # quarter-size first window of its first call)
+    alg_launch = r["algorithmic_bytes_per_launch"]
+    alg_total = alg_launch * r["launches_per_step"] * calls        # 4 full-window-equivalents per call (2048 blocks each)
+    fetch, write = c["FETCH_SIZE"], c["WRITE_SIZE"]
+    traffic = 2 * fetch[2] * 1024 + write[2] * 1024
+    rd = c["TCC_EA0_RDREQ_sum"][2]
+    busy = c["SQ_ACTIVE_INST_VALU"][2] * 4 / ((c["GRBM_GUI_ACTIVE"][2] / 8) * 1024)
+    wait = c["SQ_WAIT_ANY"][2] / c["SQ_WAVE_CYCLES"][2]
+    ta = c["TA_BUSY_avr"][2] / (c["GRBM_GUI_ACTIVE"][2] / 8)
+    live_ms = (r if wl == "reuse" else nr)["avg_launch_ms"]
+    out[wl] = dict(loop_seconds=loops, dispatches=fetch[0], fetch_size_kib_sum=fetch[2], write_size_kib_sum=write[2],
+                   tcc_ea0_rdreq_sum=rd, tcc_ea0_rdreq_32b_sum=c["TCC_EA0_RDREQ_32B_sum"][2], tcc_hit_sum=c["TCC_HIT_sum"][2], tcc_miss_sum=c["TCC_MISS_sum"][2],
+                   traffic_bytes_total=traffic, algorithmic_bytes_total=alg_total, traffic_over_algorithmic=traffic / alg_total,
+                   rocprof_avg_launch_us=big["avg"] / 1e3, rocprof_launches=big["n"], bench_live_avg_launch_us=live_ms * 1e3,
+                   achieved_GBs_from_rocprof=alg_launch / (big["avg"] / 1e9) / 1e9, valu_busy=busy, wait_any_frac=wait, ta_busy=ta)
+    hdr = f"""# rocprofv3 summary ({name}; written by scripts/publish_profile_r2.py from scripts/profile_r2.sh {tag}), kernel-source digest {digest}
+# workload: bench.py defaults (1024 stereo voices, 8 buses x 128, 256-frame blocks, 8192 blocks per call, ratio 1, linear, faithful) with
+#   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits' if wl == 'reuse' else ' -- NO source byte is re-read inside a plan window (2048 blocks = 10.9 s): every source read comes from HBM'}
+# commands (one pass each; raw CSVs condensed by scripts/summarize_prof.py; long torch kernel names cut):
+#   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1{' --loop-seconds 10' if wl == 'noreuse' else ''}
+#   rocprofv3 --pmc <counters> --output-format csv -- same command (5 passes: FETCH_SIZE | WRITE_SIZE TCC_HIT/MISS | TCC_EA0_RDREQ/WRREQ | SQ_* | LDS / TA / TCP)
+# {calls} zlhip_render_batch calls = {fetch[0]} K2 dispatches; the full plan windows are the {big['grid']}-thread launches (2048 blocks).
 #
-# K2 zl_k2_render<0u, 1> (MODE 0 = faithful linear, 1 block per workgroup).  bench.py times the K2 launches of its timed
-#   steps with the dispatches' own start / stop events (hipExtLaunchKernel) on the launch stream: {lm:.1f} us per 2048-block launch (unprofiled run, {name}_bench_line.json):
-#   {ab:.3f} GB algorithmic / {lm:.1f} us = {ach / 1e3:.2f} TB/s = {ach / 80:.1f} % of 8 TB/s.  rocprofv3, same launch shape
-#   (section "engine kernels by grid", {grid} threads): {avg_big / 1e3:.1f} us average over {n_big} dispatches (min {min_big / 1e3:.1f},
-#   max {max_big / 1e3:.1f}) = {ab / (avg_big / 1e9) / 1e3:.2f} TB/s -- within {abs(avg_big / 1e3 - lm) / lm * 100:.1f} % of each other (kernels run a little slower under the profiler).  (The --stats average over all {ndisp} dispatches,
-#   {avg_ns / 1e3:.1f} us, mixes in the shorter windows.)
-# HBM traffic of K2 (PMC, separate passes), summed over the {fetch[0]} dispatches: FETCH_SIZE {fetch[2]:,.0f} KiB; on gfx950
-#   FETCH_SIZE counts one half of the bytes of 16-byte-per-lane streaming loads (MI355X_MICROARCH.md, HBM), so reads =
-#   2 x {fetch[2] * 1024 / 1e9:.2f} GB = {2 * fetch[2] * 1024 / 1e9:.2f} GB; WRITE_SIZE {write[2]:,.0f} KiB = {write[2] * 1024 / 1e9:.2f} GB.  Algorithmic bytes of the same {calls} calls:
-#   {calls} x {alg_step / 1e9:.2f} GB = {alg_total / 1e9:.1f} GB (8192 x 1024 voice-blocks x 2056 B + bus).  traffic / algorithmic = {ratio:.3f}.  (With
-#   launch-order block numbering the ratio was 1.061: the cache line at the common edge of two neighbouring blocks of a
-#   source was fetched by two XCDs' L2s; the XCD-aware block order lets the two blocks meet in one L2.)  Per 2048-block
-#   launch: {ab:.3f} GB algorithmic, {ab * ratio:.2f} GB traffic.  FETCH_SIZE includes Infinity-Cache hits (same guide), so it does
-#   not separate HBM from MALL service; bench.py therefore also reports the kernel on sources that are not re-read inside
-#   a window (roofline.no_reuse_variant: {nr.get('achieved', 0) / 1e3:.2f} TB/s = {nr.get('frac', 0) * 100:.0f} %).
-# VALU: SQ_INSTS_VALU {insts[2]:.4g} over the {calls} calls = {insts[2] / (calls * 8192 * 1024 * 4):.1f} per voice-wave, staging included (28.6 before
-#   the interior / unit-step chunk variants); SQ_ACTIVE_INST_VALU x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) =
-#   {busy * 100:.0f} % VALU busy.
+# K2 zl_k2_render<0u, 1, false> (faithful linear, 1 block per workgroup, register gather):
+#   rocprofv3 kernel trace, full windows: {big['avg'] / 1e3:.1f} us average over {big['n']} dispatches (min {big['mn'] / 1e3:.1f}, max {big['mx'] / 1e3:.1f}).
+#   algorithmic bytes per full window: {alg_launch / 1e9:.3f} GB (2048 x 1024 voice-blocks x (ceil(256 x ratio) + 1) x 8 B summed by K1, + the bus write)
+#   => {alg_launch / (big['avg'] / 1e9) / 1e12:.2f} TB/s = {alg_launch / (big['avg'] / 1e9) / 8e12 * 100:.1f} % of 8 TB/s under the profiler;
+#   bench.py's own HIP-event figure of the un-profiled run ({name}_bench_line.json, {'roofline.achieved' if wl == 'reuse' else 'roofline.achieved_hbm_no_reuse: 12 calls, 49 launches incl. one quarter-size window'}):
+#   {(r['achieved'] if wl == 'reuse' else nr['achieved']) / 1e3:.2f} TB/s = {(r['frac'] if wl == 'reuse' else nr['frac']) * 100:.1f} % ({abs(alg_launch / (big['avg'] / 1e9) / 1e9 / (r['achieved'] if wl == 'reuse' else nr['achieved']) - 1) * 100:.1f} % apart; kernels run a little slower under the profiler).
+# HBM-side traffic (PMC): FETCH_SIZE {fetch[2]:,.0f} KiB = TCC_EA0_RDREQ {rd:,.0f} requests x 64 B (TCC_EA0_RDREQ_32B = {c['TCC_EA0_RDREQ_32B_sum'][2]:.0f}).  On gfx950 the
+#   memory-side read requests of 16-byte-per-lane loads are 128-byte requests tallied at 64 B (MI355X_MICROARCH.md, HBM): reads = 2 x FETCH_SIZE
+#   = {2 * fetch[2] * 1024 / 1e9:.2f} GB; WRITE_SIZE {write[2]:,.0f} KiB = {write[2] * 1024 / 1e9:.2f} GB.  Algorithmic bytes of the same {calls} calls: {alg_total / 1e9:.2f} GB.
+#   traffic / algorithmic = {traffic / alg_total:.4f}.{' CALIBRATION: in this workload no source byte can come from a cache (nothing is re-read), so the true HBM traffic is >= the algorithmic bytes; 1 x FETCH_SIZE would be half of that minimum, 2 x FETCH_SIZE is 1.00 of it -- the factor 2 holds for this access pattern (8-byte-strided 16-byte gathers).' if wl == 'noreuse' else ' FETCH_SIZE counts Infinity-Cache hits too (same guide): this ratio shows that nothing is over-fetched, not that the bytes came from HBM -- for that see the no-reuse profile.'}
+#   L2: TCC_HIT {c['TCC_HIT_sum'][2]:.3g}, TCC_MISS {c['TCC_MISS_sum'][2]:.3g} (source lines always miss L2; what differs between the two workloads is who serves the miss).
+# Issue: VALU busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = {busy * 100:.0f} %; waves parked in s_waitcnt {wait * 100:.0f} % of their cycles;
+#   TA_BUSY_avr / kernel cycles = {ta * 100:.0f} %; SQ_INSTS_VALU per voice-wave = {c['SQ_INSTS_VALU'][2] / (calls * 8192 * 1024 * 4):.1f}.
 """
-open(os.path.join(P, f"{name}_rocprofv3_summary.txt"), "w").write(hdr + "\n".join(l[:260] for l in body) + "\n")
-for f in ("config_sweep", "fanout", "command_storm", "realtime"):
-    src = os.path.join(G, f"{tag}_{f}.txt")
+    open(os.path.join(P, f"{name}_{wl}_rocprofv3_summary.txt"), "w").write(hdr + "\n".join(l[:260] for l in body) + "\n")
+    print(hdr)
+json.dump({"kernel": "zl_k2_render<0,1,false>", "kernel_source_digest": digest,
+           "workload": "bench.py defaults (1024 voices, 8 buses, 256 frames, 8192 blocks per step, 2 s loops)",
+           "traffic_over_algorithmic": out["reuse"]["traffic_over_algorithmic"],
+           "gfx950_fetch_correction": "reads = 2 x FETCH_SIZE (FETCH_SIZE = TCC_EA0_RDREQ x 64 B, the requests are 128 B); calibrated on the no-reuse workload, "
+                                      "where every source byte must come from HBM and 2 x FETCH_SIZE + WRITE_SIZE = %.4f x algorithmic" % out["noreuse"]["traffic_over_algorithmic"],
+           "reuse": out["reuse"], "noreuse": out["noreuse"],
+           "source": f"profiles/{name}_reuse_rocprofv3_summary.txt, profiles/{name}_noreuse_rocprofv3_summary.txt"},
+          open(os.path.join(P, f"{name}_pmc.json"), "w"), indent=1)
+for f in ("config_sweep.txt", "herm_pmc_summary.txt", "host.txt", "realtime.txt"):
+    src = os.path.join(G, f)
     if os.path.exists(src):
-        open(os.path.join(P, f"{name}_{f}.txt"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l))
-print(hdr)
-print(f"value {d['value']:.4e}  ms/step {d['ms_per_step']:.3f}  K2 {ach:.0f} GB/s  traffic/algorithmic {ratio:.4f}  cpu {d.get('cpu_baseline', {}).get('value')}")
+        open(os.path.join(P, f"{name}_{f}"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l))
+cb = d.get("cpu_baseline", {})
+print(f"value {d['value']:.4e}  ms/step {d['ms_per_step']:.3f}  frac {r['frac']:.3f}  frac_hbm_no_reuse {r['frac_hbm_no_reuse']:.3f}  cpu {cb.get('value'):.3e} on {cb.get('cores')} threads")

@@ -1072,7 +1072,19 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     // the headline call 2..3.5 %, but a call is then a single window whose planning is hidden by nothing but the previous call's
     // launch: pitched voices -3 %, 128-frame blocks -5 %, 4096 voices -8 %, and one host-side stall of several milliseconds per
     // timed region.  The default stays the fixed number of frames per window.)
-    static const int windowMul = [] { const char *v = std::getenv("ZL_WINDOW_MUL"); const int m = v ? std::atoi(v) : 1; return m < 1 ? 1 : (m > 64 ? 64 : m); }();
+    static const int windowMulEnv = [] { const char *v = std::getenv("ZL_WINDOW_MUL"); const int m = v ? std::atoi(v) : 0; return m < 0 ? 0 : (m > 64 ? 64 : m); }();
+    // Round 4: the choice is made per call from what planning will cost.  When every playing voice runs at exactly the playback rate on
+    // a sample-space loop (libzl's common case: a clip at its own pitch and rate; the BASELINE workload) K1 plans a window of any length
+    // in a handful of exact runs, so the window may be four times as long: one K2 launch per 8192-block call instead of four.  Pitched,
+    // resampled or beat-locked voices keep the pipeline of shorter windows, whose planning hides behind rendering.  ZL_WINDOW_MUL=<n> forces n.
+    // (measured on one box, alternating runs, profiles/round4_window_ab.txt: headline +2 %, 4096 voices at 96 kHz +5.5 %, Hermite at ratio 1 +5.5 %,
+    // narrow buses +0.5..1 %; two 128-frame blocks per workgroup -3 % -- short blocks keep the fixed size)
+    int windowMul = windowMulEnv;
+    if (windowMul == 0) {
+        bool cheap = nframes >= 256;
+        for (const ZlHostVoice &hv : e->hc.voices) if (hv.isPlaying && !hv.cheapPlan) { cheap = false; break; }
+        windowMul = cheap ? 4 : 1;
+    }
     // (engines that split buses into mix groups keep the fixed size: their partial rows are sized for it)
     const size_t mul = e->maxGroups > 1 ? 1 : (size_t)windowMul;
     int W = e->windowBlocks > 0 ? e->windowBlocks : (int)std::max<size_t>(1, std::min<size_t>(mul * e->windowFrames / (size_t)nframes, (size_t)1 << 30));

@@ -30,6 +30,8 @@ struct ZlHostVoice {                     // control-plane view of one SamplerSyn
     int  sound = -1;                     // getCurrentlyPlayingSound()
     bool isPlaying = false;              // SamplerSynthVoice.h:31
     uint64_t startTick = 0;
+    bool cheapPlan = false;              // started at exactly the playback rate on a sample-space loop (or as a one-shot): K1 plans it in a handful of
+                                         // exact runs whatever the window's length (a hint for the window size, zl_engine.cpp; never for results)
 };
 
 struct ZlHostControl {
@@ -140,6 +142,7 @@ struct ZlHostControl {
         op.voice = v; op.kind = ZL_OP_START;
         ZlVoiceState &s = op.start;
         s.pitch_ratio = zl_libm_pow(2.0, (cmd.midi_note - cp.root_note) / 12.0) * sr / playback_sample_rate;   // :115-116
+        hv.cheapPlan = s.pitch_ratio == 1.0 && !(cmd.looping && truncf(cp.length_in_beats) == cp.length_in_beats);
         s.src_len = cp.duration_seconds * sr;                                                               // :120
         s.P = (int)(clip_start_position(cp, cmd.slice) * sr);                                                // :121
         s.next_loop_tick = zl_f32_to_u64_sat(tick + cp.length_in_beats * ZLHIP_BEAT_SUBDIVISIONS);           // :123 (u64 + float -> float)

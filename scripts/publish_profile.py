@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copies the results of scripts/profile_r2.sh <tag> from gpurun_out/<tag>/ into profiles/<name>_* with headers that state what
-was profiled and how every figure is derived.  usage: publish_profile_r2.py <tag> <name>   (e.g. r2c round2_c)"""
+"""Copies the results of scripts/profile_r4.sh <tag> a|b|c from gpurun_out/<tag>/ into profiles/<name>_* with headers that state what
+was profiled and how every figure is derived.  usage: publish_profile.py <tag> <name>   (e.g. r4a round4_a)"""
 import json
 import os
 import sys
@@ -36,15 +36,15 @@ d = json.loads(bl); r = d["roofline"]; nr = r["no_reuse_variant"]
 open(os.path.join(P, f"{name}_bench_line.json"), "w").write(bl + "\n")
 from bench import kernel_source_digest  # noqa: E402
 digest = kernel_source_digest()
-calls = 5                                                           # profile_r2.sh: --steps 4 --warmup 1
+calls = 5                                                           # profile_r4.sh: --steps 4 --warmup 1
 out = {}
-for wl, loops in (("reuse", 2.0), ("noreuse", 10.0)):
+BPL = d["config"]["blocks_per_step"] // max(1, r["launches_per_step"])      # blocks per K2 launch
+for wl, loops in (("reuse", 2.0), ("noreuse", 45.0)):
     body, c, big, shapes = parse(os.path.join(G, f"{wl}_summary.txt"))
-    # bytes of one FULL plan window (2048 blocks): the timed steps of the default run are 4 full windows each; both workloads have the
-    # same shape (ratio 1, 256-frame blocks), so the figure holds for both (the no-reuse leg's own per-launch average mixes in the
-    # quarter-size first window of its first call)
+    # bytes of one FULL launch (a whole 8192-block call since round 4: every voice of the workload is cheap to plan, one plan window per
+    # call); both workloads have the same shape (ratio 1, 256-frame blocks), so the figure holds for both
     alg_launch = r["algorithmic_bytes_per_launch"]
-    alg_total = alg_launch * r["launches_per_step"] * calls        # 4 full-window-equivalents per call (2048 blocks each)
+    alg_total = alg_launch * r["launches_per_step"] * calls
     fetch, write = c["FETCH_SIZE"], c["WRITE_SIZE"]
     traffic = 2 * fetch[2] * 1024 + write[2] * 1024
     rd = c["TCC_EA0_RDREQ_sum"][2]
@@ -57,19 +57,19 @@ for wl, loops in (("reuse", 2.0), ("noreuse", 10.0)):
                    traffic_bytes_total=traffic, algorithmic_bytes_total=alg_total, traffic_over_algorithmic=traffic / alg_total,
                    rocprof_avg_launch_us=big["avg"] / 1e3, rocprof_launches=big["n"], bench_live_avg_launch_us=live_ms * 1e3,
                    achieved_GBs_from_rocprof=alg_launch / (big["avg"] / 1e9) / 1e9, valu_busy=busy, wait_any_frac=wait, ta_busy=ta)
-    hdr = f"""# rocprofv3 summary ({name}; written by scripts/publish_profile_r2.py from scripts/profile_r2.sh {tag}), kernel-source digest {digest}
+    hdr = f"""# rocprofv3 summary ({name}; written by scripts/publish_profile.py from scripts/profile_r4.sh {tag} a), kernel-source digest {digest}
 # workload: bench.py defaults (1024 stereo voices, 8 buses x 128, 256-frame blocks, 8192 blocks per call, ratio 1, linear, faithful) with
-#   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits' if wl == 'reuse' else ' -- NO source byte is re-read inside a plan window (2048 blocks = 10.9 s): every source read comes from HBM'}
+#   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits' if wl == 'reuse' else ' -- NO source byte is re-read inside a launch (8192 blocks = 43.7 s): every source read comes from HBM'}
 # commands (one pass each; raw CSVs condensed by scripts/summarize_prof.py; long torch kernel names cut):
 #   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1{' --loop-seconds 10' if wl == 'noreuse' else ''}
 #   rocprofv3 --pmc <counters> --output-format csv -- same command (5 passes: FETCH_SIZE | WRITE_SIZE TCC_HIT/MISS | TCC_EA0_RDREQ/WRREQ | SQ_* | LDS / TA / TCP)
-# {calls} zlhip_render_batch calls = {fetch[0]} K2 dispatches; the full plan windows are the {big['grid']}-thread launches (2048 blocks).
+# {calls} zlhip_render_batch calls = {fetch[0]} K2 dispatches; the full launches are the {big['grid']}-thread ones ({BPL} blocks).
 #
 # K2 zl_k2_render<0u, 1, false> (faithful linear, 1 block per workgroup, register gather):
 #   rocprofv3 kernel trace, full windows: {big['avg'] / 1e3:.1f} us average over {big['n']} dispatches (min {big['mn'] / 1e3:.1f}, max {big['mx'] / 1e3:.1f}).
-#   algorithmic bytes per full window: {alg_launch / 1e9:.3f} GB (2048 x 1024 voice-blocks x (ceil(256 x ratio) + 1) x 8 B summed by K1, + the bus write)
+#   algorithmic bytes per full launch: {alg_launch / 1e9:.3f} GB ({BPL} x 1024 voice-blocks x (ceil(256 x ratio) + 1) x 8 B summed by K1, + the bus write)
 #   => {alg_launch / (big['avg'] / 1e9) / 1e12:.2f} TB/s = {alg_launch / (big['avg'] / 1e9) / 8e12 * 100:.1f} % of 8 TB/s under the profiler;
-#   bench.py's own HIP-event figure of the un-profiled run ({name}_bench_line.json, {'roofline.achieved' if wl == 'reuse' else 'roofline.achieved_hbm_no_reuse: 12 calls, 49 launches incl. one quarter-size window'}):
+#   bench.py's own HIP-event figure of the un-profiled run ({name}_bench_line.json, {'roofline.achieved' if wl == 'reuse' else 'roofline.achieved_hbm_no_reuse: 12 calls'}):
 #   {(r['achieved'] if wl == 'reuse' else nr['achieved']) / 1e3:.2f} TB/s = {(r['frac'] if wl == 'reuse' else nr['frac']) * 100:.1f} % ({abs(alg_launch / (big['avg'] / 1e9) / 1e9 / (r['achieved'] if wl == 'reuse' else nr['achieved']) - 1) * 100:.1f} % apart; kernels run a little slower under the profiler).
 # HBM-side traffic (PMC): FETCH_SIZE {fetch[2]:,.0f} KiB = TCC_EA0_RDREQ {rd:,.0f} requests x 64 B (TCC_EA0_RDREQ_32B = {c['TCC_EA0_RDREQ_32B_sum'][2]:.0f}).  On gfx950 the
 #   memory-side read requests of 16-byte-per-lane loads are 128-byte requests tallied at 64 B (MI355X_MICROARCH.md, HBM): reads = 2 x FETCH_SIZE
@@ -82,14 +82,14 @@ for wl, loops in (("reuse", 2.0), ("noreuse", 10.0)):
     open(os.path.join(P, f"{name}_{wl}_rocprofv3_summary.txt"), "w").write(hdr + "\n".join(l[:260] for l in body) + "\n")
     print(hdr)
 json.dump({"kernel": "zl_k2_render<0,1,false>", "kernel_source_digest": digest,
-           "workload": "bench.py defaults (1024 voices, 8 buses, 256 frames, 8192 blocks per step, 2 s loops)",
+           "workload": "bench.py defaults (1024 voices, 8 buses, 256 frames, 8192 blocks per step, 2 s loops; HBM-only leg: 45 s loops)",
            "traffic_over_algorithmic": out["reuse"]["traffic_over_algorithmic"],
            "gfx950_fetch_correction": "reads = 2 x FETCH_SIZE (FETCH_SIZE = TCC_EA0_RDREQ x 64 B, the requests are 128 B); calibrated on the no-reuse workload, "
                                       "where every source byte must come from HBM and 2 x FETCH_SIZE + WRITE_SIZE = %.4f x algorithmic" % out["noreuse"]["traffic_over_algorithmic"],
            "reuse": out["reuse"], "noreuse": out["noreuse"],
            "source": f"profiles/{name}_reuse_rocprofv3_summary.txt, profiles/{name}_noreuse_rocprofv3_summary.txt"},
           open(os.path.join(P, f"{name}_pmc.json"), "w"), indent=1)
-for f in ("config_sweep.txt", "herm_pmc_summary.txt", "host.txt", "realtime.txt"):
+for f in ("config_sweep.txt", "host.txt", "realtime_cpp.txt", "realtime_python.txt", "rt_setter_latency.txt", "bounce.txt", "two_ranks_one_gpu.json", "rccl_one_rank.json"):
     src = os.path.join(G, f)
     if os.path.exists(src):
         open(os.path.join(P, f"{name}_{f}"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l))

@@ -391,6 +391,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reuse-check", action="store_true", help="skip the 10 s-loop (no source re-read inside a window: HBM only) measurement")
     ap.add_argument("--no-reuse-calls", type=int, default=12)
+    ap.add_argument("--no-reuse-seconds", type=float, default=10.0,
+                    help="length of the HBM-only leg's sources; its plan windows are capped so that no launch is longer (0 = sources as long as a whole call, the headline's launch shape)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the two extra timed regions that give value_per_gpu_repeats")
     ap.add_argument("--no-spot-check", action="store_true", help="skip the output check against the oracle after the timed region")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the measured path) or gloo (rehearsal: exchange through host memory)")
@@ -661,13 +663,18 @@ def main():
     #      (a plan window), so neither L2 nor the 256 MiB Infinity Cache can serve a source read.  N = 1 only, --no-reuse-calls
     #      calls after the timed region.
     no_reuse = None
-    # (Sources as long as the longest launch: a unit-ratio scene is planned in one window per call -- 8192 blocks of 256 frames = 43.7 s.)
-    nr_seconds = max(10.0, float(int(KB * N / args.fs * 1.03) + 1))
+    # --no-reuse-seconds S: S-second sources; the leg's launches are then at most S seconds long (plan windows of that many blocks: a
+    # unit-ratio scene would otherwise be planned in ONE window per call, 8192 blocks of 256 frames = 43.7 s, and re-read a 10 s source four
+    # times inside it).  0 = sources as long as a whole call (17.7 GB at the default shape) and the headline's own launch shape.
+    nr_seconds = args.no_reuse_seconds if args.no_reuse_seconds > 0 else float(int(KB * N / args.fs * 1.03) + 1)
+    nr_window = args.plan_window or (max(1, int(nr_seconds * args.fs * 0.97) // N) if args.no_reuse_seconds > 0 else 0)
+    if nr_window:
+        nr_window = min(nr_window, max(1, min(16 << 20, max(2048 * 256, (2048 * 256 * 1024) // max(V, 1))) // N))   # (never above the engine's own fixed window size)
     if rank == 0 and not distributed and not args.no_reuse_check and args.loop_seconds < 10.0:
         lf2 = int(nr_seconds * source_rate)
         syn2 = SamplerSynth(B, vpb, max_frames=N, max_batch_blocks=KB, max_sounds=V, mode=mode,
                             playback_sample_rate=args.fs, sound_arena_bytes=(lf2 + 16) * (4 if args.mono else 8) * V + (1 << 20),
-                            voices_per_task=args.voices_per_task, plan_window_blocks=args.plan_window, device=local_rank)
+                            voices_per_task=args.voices_per_task, plan_window_blocks=nr_window, device=local_rank)
         build_scene(syn2, torch, dev, vpb, B, args.fs, lf2, seed + 7, notes=notes, source_rate=source_rate, mono=args.mono)
         syn2.set_profiling(True)
         for i in range(2):
@@ -679,7 +686,7 @@ def main():
         b2 = (t2.source_bytes + n2 * B * 2 * N * 4 * KB) / max(1, t2.render_launches)
         ms2 = t2.render_ms / max(1, t2.render_launches)
         g2 = b2 / (ms2 * 1e-3) / 1e9
-        no_reuse = {"loop_seconds": nr_seconds, "calls": n2, "launches": int(t2.render_launches), "achieved": g2, "frac": g2 / HBM_PEAK_GBS,
+        no_reuse = {"loop_seconds": nr_seconds, "plan_window_blocks": nr_window, "calls": n2, "launches": int(t2.render_launches), "achieved": g2, "frac": g2 / HBM_PEAK_GBS,
                     "avg_launch_ms": ms2, "algorithmic_bytes_per_launch": b2,
                     "value": float(V) * KB * N * n2 / (t2.total_ms * 1e-3) if t2.total_ms > 0 else None}
         syn2.close()

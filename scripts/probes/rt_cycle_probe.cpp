@@ -114,6 +114,7 @@ int main(int argc, char **argv)
         rows.push_back({96, 12, 128, res == 1, false, false, 0});
         rows.push_back({96, 12, 512, res == 1, false, false, 0});
         rows.push_back({96, 12, 1024, res == 1, false, false, 0});
+        if (!quick) { rows.push_back({96, 12, 2048, res == 1, false, false, 0}); rows.push_back({96, 12, 4096, res == 1, false, false, 0}); }
         rows.push_back({96, 12, 256, res == 1, false, true, 0});       // with the JackPassthrough fan-out (three more pairs per bus over PCIe)
     }
     for (int res = 0; res < 2; ++res) {

@@ -27,8 +27,10 @@ def parse(summary):
             except ValueError:
                 pass
     shapes = [l.split(",") for l in body if l.startswith(K2 + ", 256x")]
-    big = max(shapes, key=lambda f: int(f[-4]))
-    return body, ctr, dict(grid=big[-5].strip(), n=int(big[-4]), avg=float(big[-3]), mn=float(big[-2]), mx=float(big[-1])), shapes
+    big = max(shapes, key=lambda f: int(f[-5].strip().split("x")[1]))      # the launches with the most blocks (grid y = 256 x blocks x buses)
+    total_ns = sum(int(f[-4]) * float(f[-3]) for f in shapes)             # all K2 dispatches of the run
+    return body, ctr, dict(grid=big[-5].strip(), n=int(big[-4]), avg=float(big[-3]), mn=float(big[-2]), mx=float(big[-1]), total_ns=total_ns,
+                           dispatches=sum(int(f[-4]) for f in shapes)), shapes
 
 
 bl = jline(os.path.join(G, "bench_line.json"))
@@ -38,13 +40,15 @@ from bench import kernel_source_digest  # noqa: E402
 digest = kernel_source_digest()
 calls = 5                                                           # profile_r4.sh: --steps 4 --warmup 1
 out = {}
-BPL = d["config"]["blocks_per_step"] // max(1, r["launches_per_step"])      # blocks per K2 launch
-for wl, loops in (("reuse", 2.0), ("noreuse", 45.0)):
+for wl, loops in (("reuse", 2.0), ("noreuse", nr["loop_seconds"])):
     body, c, big, shapes = parse(os.path.join(G, f"{wl}_summary.txt"))
     # bytes of one FULL launch (a whole 8192-block call since round 4: every voice of the workload is cheap to plan, one plan window per
     # call); both workloads have the same shape (ratio 1, 256-frame blocks), so the figure holds for both
-    alg_launch = r["algorithmic_bytes_per_launch"]
-    alg_total = alg_launch * r["launches_per_step"] * calls
+    alg_call = r["algorithmic_bytes_per_launch"] * r["launches_per_step"]        # per 8192-block call: the same for both workloads (same shape)
+    alg_total = alg_call * calls
+    BPL = int(big["grid"].split("x")[1])                                         # blocks of the largest launches
+    alg_launch = alg_call * BPL / d["config"]["blocks_per_step"]
+    rocprof_gbs = alg_total / (big["total_ns"] / 1e9) / 1e9                       # every K2 dispatch of the run: bytes / time
     fetch, write = c["FETCH_SIZE"], c["WRITE_SIZE"]
     traffic = 2 * fetch[2] * 1024 + write[2] * 1024
     rd = c["TCC_EA0_RDREQ_sum"][2]
@@ -56,21 +60,21 @@ for wl, loops in (("reuse", 2.0), ("noreuse", 45.0)):
                    tcc_ea0_rdreq_sum=rd, tcc_ea0_rdreq_32b_sum=c["TCC_EA0_RDREQ_32B_sum"][2], tcc_hit_sum=c["TCC_HIT_sum"][2], tcc_miss_sum=c["TCC_MISS_sum"][2],
                    traffic_bytes_total=traffic, algorithmic_bytes_total=alg_total, traffic_over_algorithmic=traffic / alg_total,
                    rocprof_avg_launch_us=big["avg"] / 1e3, rocprof_launches=big["n"], bench_live_avg_launch_us=live_ms * 1e3,
-                   achieved_GBs_from_rocprof=alg_launch / (big["avg"] / 1e9) / 1e9, valu_busy=busy, wait_any_frac=wait, ta_busy=ta)
+                   achieved_GBs_from_rocprof=rocprof_gbs, valu_busy=busy, wait_any_frac=wait, ta_busy=ta)
     hdr = f"""# rocprofv3 summary ({name}; written by scripts/publish_profile.py from scripts/profile_r4.sh {tag} a), kernel-source digest {digest}
 # workload: bench.py defaults (1024 stereo voices, 8 buses x 128, 256-frame blocks, 8192 blocks per call, ratio 1, linear, faithful) with
-#   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits' if wl == 'reuse' else ' -- NO source byte is re-read inside a launch (8192 blocks = 43.7 s): every source read comes from HBM'}
+#   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits; one launch per 8192-block call' if wl == 'reuse' else ' and plan windows of 1818 blocks (9.7 s) -- NO source byte is re-read inside a launch: every source read comes from HBM'}
 # commands (one pass each; raw CSVs condensed by scripts/summarize_prof.py; long torch kernel names cut):
-#   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1{' --loop-seconds 10' if wl == 'noreuse' else ''}
+#   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1{' --loop-seconds 10 --plan-window 1818' if wl == 'noreuse' else ''}
 #   rocprofv3 --pmc <counters> --output-format csv -- same command (5 passes: FETCH_SIZE | WRITE_SIZE TCC_HIT/MISS | TCC_EA0_RDREQ/WRREQ | SQ_* | LDS / TA / TCP)
 # {calls} zlhip_render_batch calls = {fetch[0]} K2 dispatches; the full launches are the {big['grid']}-thread ones ({BPL} blocks).
 #
 # K2 zl_k2_render<0u, 1, false> (faithful linear, 1 block per workgroup, register gather):
 #   rocprofv3 kernel trace, full windows: {big['avg'] / 1e3:.1f} us average over {big['n']} dispatches (min {big['mn'] / 1e3:.1f}, max {big['mx'] / 1e3:.1f}).
 #   algorithmic bytes per full launch: {alg_launch / 1e9:.3f} GB ({BPL} x 1024 voice-blocks x (ceil(256 x ratio) + 1) x 8 B summed by K1, + the bus write)
-#   => {alg_launch / (big['avg'] / 1e9) / 1e12:.2f} TB/s = {alg_launch / (big['avg'] / 1e9) / 8e12 * 100:.1f} % of 8 TB/s under the profiler;
+#   => {alg_launch / (big['avg'] / 1e9) / 1e12:.2f} TB/s = {alg_launch / (big['avg'] / 1e9) / 8e12 * 100:.1f} % of 8 TB/s under the profiler (all {big['dispatches']} K2 dispatches of the run: {rocprof_gbs / 1e3:.2f} TB/s);
 #   bench.py's own HIP-event figure of the un-profiled run ({name}_bench_line.json, {'roofline.achieved' if wl == 'reuse' else 'roofline.achieved_hbm_no_reuse: 12 calls'}):
-#   {(r['achieved'] if wl == 'reuse' else nr['achieved']) / 1e3:.2f} TB/s = {(r['frac'] if wl == 'reuse' else nr['frac']) * 100:.1f} % ({abs(alg_launch / (big['avg'] / 1e9) / 1e9 / (r['achieved'] if wl == 'reuse' else nr['achieved']) - 1) * 100:.1f} % apart; kernels run a little slower under the profiler).
+#   {(r['achieved'] if wl == 'reuse' else nr['achieved']) / 1e3:.2f} TB/s = {(r['frac'] if wl == 'reuse' else nr['frac']) * 100:.1f} % ({abs(rocprof_gbs / (r['achieved'] if wl == 'reuse' else nr['achieved']) - 1) * 100:.1f} % apart; kernels run a little slower under the profiler).
 # HBM-side traffic (PMC): FETCH_SIZE {fetch[2]:,.0f} KiB = TCC_EA0_RDREQ {rd:,.0f} requests x 64 B (TCC_EA0_RDREQ_32B = {c['TCC_EA0_RDREQ_32B_sum'][2]:.0f}).  On gfx950 the
 #   memory-side read requests of 16-byte-per-lane loads are 128-byte requests tallied at 64 B (MI355X_MICROARCH.md, HBM): reads = 2 x FETCH_SIZE
 #   = {2 * fetch[2] * 1024 / 1e9:.2f} GB; WRITE_SIZE {write[2]:,.0f} KiB = {write[2] * 1024 / 1e9:.2f} GB.  Algorithmic bytes of the same {calls} calls: {alg_total / 1e9:.2f} GB.
@@ -82,7 +86,7 @@ for wl, loops in (("reuse", 2.0), ("noreuse", 45.0)):
     open(os.path.join(P, f"{name}_{wl}_rocprofv3_summary.txt"), "w").write(hdr + "\n".join(l[:260] for l in body) + "\n")
     print(hdr)
 json.dump({"kernel": "zl_k2_render<0,1,false>", "kernel_source_digest": digest,
-           "workload": "bench.py defaults (1024 voices, 8 buses, 256 frames, 8192 blocks per step, 2 s loops; HBM-only leg: 45 s loops)",
+           "workload": "bench.py defaults (1024 voices, 8 buses, 256 frames, 8192 blocks per step, 2 s loops; HBM-only leg: 10 s loops in launches of at most 10 s)",
            "traffic_over_algorithmic": out["reuse"]["traffic_over_algorithmic"],
            "gfx950_fetch_correction": "reads = 2 x FETCH_SIZE (FETCH_SIZE = TCC_EA0_RDREQ x 64 B, the requests are 128 B); calibrated on the no-reuse workload, "
                                       "where every source byte must come from HBM and 2 x FETCH_SIZE + WRITE_SIZE = %.4f x algorithmic" % out["noreuse"]["traffic_over_algorithmic"],

@@ -37,6 +37,17 @@ def main(root, out):
         lines.append("## engine kernels by grid (threads x, y, z): name, grid, calls, avg_ns, min_ns, max_ns")
         for (name, gx, gy, gz), d in sorted(shaped.items(), key=lambda kv: (kv[0][0], -len(kv[1]))):
             lines.append(f"{name[:60]}, {gx}x{gy}x{gz}, {len(d)}, {sum(d) / len(d):.0f}, {min(d)}, {max(d)}")
+        # what sits between two render kernels (packets, the planner's hand-off): end of one K2 dispatch -> start of the next
+        k2 = []
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "zl_k2_render" in row.get("Kernel_Name", ""):
+                    k2.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+        k2.sort()
+        gaps = [b[0] - a[1] for a, b in zip(k2, k2[1:]) if 0 <= b[0] - a[1] < 1_000_000]     # (gaps of a millisecond and more: between phases of the run)
+        if gaps:
+            gs = sorted(gaps)
+            lines.append(f"## gaps between consecutive K2 dispatches (end -> next start, ns; {len(gaps)} gaps under 1 ms): median {gs[len(gs) // 2]}, mean {sum(gs) / len(gs):.0f}, min {gs[0]}, max {gs[-1]}")
     for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(lambda: defaultdict(list))
         with open(f) as fh:

@@ -391,8 +391,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reuse-check", action="store_true", help="skip the 10 s-loop (no source re-read inside a window: HBM only) measurement")
     ap.add_argument("--no-reuse-calls", type=int, default=12)
-    ap.add_argument("--no-reuse-seconds", type=float, default=10.0,
-                    help="length of the HBM-only leg's sources; its plan windows are capped so that no launch is longer (0 = sources as long as a whole call, the headline's launch shape)")
+    ap.add_argument("--no-reuse-seconds", type=float, default=-1.0,
+                    help="length of the HBM-only leg's sources; its plan windows are capped so that no launch is longer (default: one standard plan window, "
+                         "12 s at the default shape; 0 = sources as long as a whole call, the headline's launch shape)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the two extra timed regions that give value_per_gpu_repeats")
     ap.add_argument("--no-spot-check", action="store_true", help="skip the output check against the oracle after the timed region")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the measured path) or gloo (rehearsal: exchange through host memory)")
@@ -663,13 +664,20 @@ def main():
     #      (a plan window), so neither L2 nor the 256 MiB Infinity Cache can serve a source read.  N = 1 only, --no-reuse-calls
     #      calls after the timed region.
     no_reuse = None
-    # --no-reuse-seconds S: S-second sources; the leg's launches are then at most S seconds long (plan windows of that many blocks: a
-    # unit-ratio scene would otherwise be planned in ONE window per call, 8192 blocks of 256 frames = 43.7 s, and re-read a 10 s source four
-    # times inside it).  0 = sources as long as a whole call (17.7 GB at the default shape) and the headline's own launch shape.
-    nr_seconds = args.no_reuse_seconds if args.no_reuse_seconds > 0 else float(int(KB * N / args.fs * 1.03) + 1)
-    nr_window = args.plan_window or (max(1, int(nr_seconds * args.fs * 0.97) // N) if args.no_reuse_seconds > 0 else 0)
-    if nr_window:
-        nr_window = min(nr_window, max(1, min(16 << 20, max(2048 * 256, (2048 * 256 * 1024) // max(V, 1))) // N))   # (never above the engine's own fixed window size)
+    # The leg's launches are the engine's standard plan windows (512 Ki voice-frames at 1024 voices = 2048 blocks of 256 frames, four per
+    # 8192-block call, as rounds 2-3 measured it) and its sources are a little longer than such a window (12 s), so no launch re-reads a
+    # byte.  (A unit-ratio scene is otherwise planned in ONE window per call -- 43.7 s -- and would re-read a 12 s source inside it.)
+    # --no-reuse-seconds S: S-second sources and launches of at most S seconds; 0: sources as long as a whole call (17.7 GB at the default
+    # shape) and the headline's own one launch per call.  profiles/round4_noreuse_ab.txt: no systematic difference between the forms.
+    std_window = max(1, min(16 << 20, max(2048 * 256, (2048 * 256 * 1024) // max(V, 1))) // N)
+    if args.no_reuse_seconds < 0:
+        nr_window = args.plan_window or min(std_window, KB)
+        nr_seconds = float(int(nr_window * N / args.fs * 1.03) + 1)
+    elif args.no_reuse_seconds > 0:
+        nr_seconds = args.no_reuse_seconds
+        nr_window = args.plan_window or min(std_window, max(1, int(nr_seconds * args.fs * 0.97) // N))
+    else:
+        nr_seconds, nr_window = float(int(KB * N / args.fs * 1.03) + 1), args.plan_window
     if rank == 0 and not distributed and not args.no_reuse_check and args.loop_seconds < 10.0:
         lf2 = int(nr_seconds * source_rate)
         syn2 = SamplerSynth(B, vpb, max_frames=N, max_batch_blocks=KB, max_sounds=V, mode=mode,

@@ -95,6 +95,7 @@ struct zlhip_engine {
     size_t ctlPoolFrames = 0;            // frames of per-frame control a record set's pool holds (slots = this / nframes)
     int ctlSlotsOverride = -1;           // ZL_CTL_POOL_SLOTS (tests of the exhausted pool)
     hipStream_t planStream = nullptr;    // K0 + K1 (sequential per voice)
+    hipStream_t lastRenderStream = nullptr;                          // the stream the previous call rendered on
     hipStream_t lastPlanStream = nullptr; hipEvent_t evPlanTail = nullptr;   // where the previous call planned (voice-state order)
     hipEvent_t lastPlanEvent = nullptr;  // marks the end of that planning: evPlanTail, or the call's `done` event when it planned on its render stream
     hipStream_t asmStream = nullptr;     // K1c of window w runs here, next to K1 of window w+1
@@ -113,6 +114,11 @@ struct zlhip_engine {
         ZlBatchStats *hStats = nullptr, *dStats = nullptr;
         ZlReport *hReportsDev = nullptr; float *hGainDev = nullptr; ZlBatchStats *hStatsDev = nullptr;   // device views of the host buffers
         hipEvent_t evBegin = nullptr, evEnd = nullptr, done = nullptr;
+        // `done` alternates between two events from one use of the slot to the next, so that the NEXT call (the other slot) can take this
+        // call's completion as the begin of its own profile -- one event-record packet fewer between two calls' render kernels -- and
+        // still find it intact when it is harvested, two calls later
+        hipEvent_t doneEv[2] = {nullptr, nullptr}; unsigned doneGen = 0;
+        hipEvent_t beginEv = nullptr;    // what this call's profile counts from: its own evBegin, or the previous call's `done`
         std::vector<hipEvent_t> evK2;    // [2 * max windows] start/end of every K2 launch (profiling)
         int windows = 0;
         bool inflight = false, profiled = false;
@@ -382,7 +388,7 @@ void zlhip_engine_destroy(zlhip_engine *e)
         void *ch[] = { c.hClocks, c.hReports, c.hGain, c.hStats, c.hPass, c.hOps, c.hRanges, c.hEdits };
         for (void *p : ch) if (p) (void)hipHostFree(p);
         for (auto &x : c.evK2) if (x) (void)hipEventDestroy(x);
-        hipEvent_t evs[] = { c.evBegin, c.evEnd, c.done };
+        hipEvent_t evs[] = { c.evBegin, c.evEnd, c.doneEv[0], c.doneEv[1] };
         for (hipEvent_t x : evs) if (x) (void)hipEventDestroy(x);
     }
     if (e->bnc.copyStream) { (void)hipStreamSynchronize(e->bnc.copyStream); (void)hipStreamDestroy(e->bnc.copyStream); }
@@ -518,7 +524,9 @@ int zlhip_engine_create(const zlhip_config *cfg_in, zlhip_engine **out)
             for (auto &x : c.evK2) chk(hipEventCreate(&x), "hipEventCreate");
             chk(hipEventCreate(&c.evBegin), "hipEventCreate");
             chk(hipEventCreate(&c.evEnd), "hipEventCreate");
-            chk(hipEventCreate(&c.done), "hipEventCreate");        // (it can ride on a kernel dispatch as its stop event)
+            chk(hipEventCreate(&c.doneEv[0]), "hipEventCreate");   // (they can ride on a kernel dispatch as its stop event)
+            chk(hipEventCreate(&c.doneEv[1]), "hipEventCreate");
+            c.done = c.doneEv[0];
 
             chk(dalloc(&c.dReports, V), "reports");
             chk(dalloc(&c.dStats, 1), "stats");
@@ -947,7 +955,7 @@ static int harvest_slot(zlhip_engine *e, zlhip_engine::CallSlot &c)
     zlhip_timings t; std::memset(&t, 0, sizeof t);
     hipEvent_t evEnd = c.fusedDone ? c.done : c.evEnd;
     ZL_HIP(e, hipEventSynchronize(evEnd));
-    ZL_HIP(e, hipEventElapsedTime(&t.total_ms, c.evBegin, evEnd));
+    ZL_HIP(e, hipEventElapsedTime(&t.total_ms, c.beginEv, evEnd));
     float k2 = 0.0f;
     for (int w = 0; w < c.windows; ++w) {
         float x = 0.0f;
@@ -956,7 +964,7 @@ static int harvest_slot(zlhip_engine *e, zlhip_engine::CallSlot &c)
     }
     t.render_ms = k2;                                              // sum over the K2 launches of the call
     float first = 0.0f;
-    ZL_HIP(e, hipEventElapsedTime(&first, c.evBegin, c.evK2[0]));
+    ZL_HIP(e, hipEventElapsedTime(&first, c.beginEv, c.evK2[0]));
     t.plan_ms = first;                                             // planning that is NOT hidden behind rendering
     t.finalize_ms = t.total_ms - k2 - first;                       // K3 + reports + gaps between launches
     t.render_launches = c.windows;
@@ -1023,6 +1031,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
         int hrc = harvest_slot(e, c);
         if (hrc != ZLHIP_OK) return hrc;
     }
+    c.doneGen ^= 1u; c.done = c.doneEv[c.doneGen];                  // (the event of this slot's previous use stays intact for the other slot's harvest)
     const auto tSlot = std::chrono::steady_clock::now();
     bool regular = true;                                           // monotone time, one period: lets K1 bisect for loop restarts
     for (int k = 0; k < nblocks; ++k) {
@@ -1133,7 +1142,12 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     int rc = upload_ops(e, c, A);
     if (rc != ZLHIP_OK) return rc;
     // (the slot's statistics were cleared by the report kernel of the call that used it before)
-    if (e->profiling) ZL_HIP(e, hipEventRecord(c.evBegin, s));
+    if (e->profiling) {
+        // the profile of a call queued behind a profiled call on the same stream counts from that call's completion event
+        if (behindPrev && prev.profiled && e->lastRenderStream == s) c.beginEv = prev.done;
+        else { ZL_HIP(e, hipEventRecord(c.evBegin, s)); c.beginEv = c.evBegin; }
+    }
+    e->lastRenderStream = s;
     // the record sets alternate across calls too, so that the first window of this call is not planned into the set
     // the previous call's last window still renders from
     const unsigned phase = e->ps[1].hdr != nullptr ? e->setPhase : 0u;
@@ -1565,6 +1579,7 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
         std::memcpy(out_right + b * N, e->hBus + (b * 2 + 1) * N, N * sizeof(float));
     }
     const auto tDone = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    if (tr) { const double g = us_between(tPoll, tDone); if (g > maxGap) maxGap = g; }   // (the thread may be taken off between the post and its first poll)
     if (fan_out) std::memcpy(fan_out, e->hFan, B * 6 * N * sizeof(float));
     double devUs = 0.0;
     if (e->rt.stampsOn) {                                          // (workgroup 0's last stamp may still be in flight when another workgroup finishes the block)

@@ -297,6 +297,7 @@ struct ZlBatch {
     float              *fan;      // [B][6][Ktot*N] dry L,R / wetFx1 L,R / wetFx2 L,R of every bus, or nullptr
     ZlPassParams        pass0;    // pass_inline = 1 (resident kernel): the parameters of the workgroup's bus travel here instead of in pass[]
     int32_t             pass_inline;
+    int32_t             pad_batch;
     int32_t             tile_accum; // 1 (resident kernel, blocks longer than 256 frames): ONE workgroup walks the frame tiles of its block in
                                     // order (bx = 0, 1, ...), and the fused level scan carries on from tile to tile (same defined order)
     // the call's per-voice reports, published by the K2 workgroups that render its LAST block (fused_reports = 1: every bus of that

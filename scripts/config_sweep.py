@@ -6,7 +6,7 @@ and one `rocprofv3 --pmc` pass of the same command, from which K2's busy fractio
     TA   = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8 XCDs)                      the texture addresser: one gather instruction per lane and tap pair
     VALU = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)  vector issue
     HBM  = algorithmic GB/s / 6300 (what this chip's HBM delivers to a pure streaming kernel, MI355X_MICROARCH.md) -- meaningful
-           on the `--loop-seconds 10 / 45` shapes only, whose sources are never re-read inside a launch (the 2 s shapes are served
+           on the `--loop-seconds 12 / 45` shapes only, whose sources are never re-read inside a launch (the 2 s shapes are served
            by the Infinity Cache to a large part and may exceed it)
 
 `bound` names the busiest of the three.  Usage (on the GPU box, from the repository root): python3 scripts/config_sweep.py <tag> [--no-pmc]
@@ -34,9 +34,9 @@ SHAPES = [
     ("(variant) 1024 voices at ratio 1, 4-tap Hermite", "--voices 1024 --buses 8 --hermite"),
     ("configs[4] share: 4096 voices @ 96 kHz, 3750-block bounce", "--voices 4096 --buses 32 --fs 96000 --loop-seconds 2 --blocks-per-step 3750"),
     ("HBM only: headline shape on 45 s sources (one launch per 43.7 s call)", "--voices 1024 --buses 8 --loop-seconds 45"),
-    ("HBM only: pitched linear", "--voices 1024 --buses 8 --notes 48,72 --loop-seconds 10"),
-    ("HBM only: pitched 4-tap Hermite", "--voices 1024 --buses 8 --notes 48,72 --hermite --loop-seconds 10"),
-    ("HBM only: 128-frame blocks", "--voices 1024 --buses 8 --frames 128 --loop-seconds 10"),
+    ("HBM only: pitched linear", "--voices 1024 --buses 8 --notes 48,72 --loop-seconds 12"),
+    ("HBM only: pitched 4-tap Hermite", "--voices 1024 --buses 8 --notes 48,72 --hermite --loop-seconds 12"),
+    ("HBM only: 128-frame blocks", "--voices 1024 --buses 8 --frames 128 --loop-seconds 12"),
 ]
 COUNTERS = ["GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "TA_BUSY_avr"]
 
@@ -85,7 +85,7 @@ def main():
             continue
         raw.append(json.dumps({"args": args, "line": d}))
         r = d["roofline"]
-        hbm_only = "--loop-seconds 10" in args or "--loop-seconds 45" in args
+        hbm_only = "--loop-seconds 12" in args or "--loop-seconds 45" in args
         chk = d.get("output_check") or {}
         ok = all(c["bit_exact"] for c in (chk.get("rows_vs_oracle") or [])) if chk else None
         head = (f"### {what}: bench.py {args}\n  value {d['value']:.3e} vs/s  {d['ms_per_step']:.3f} ms/step  K2 {r['achieved']:.0f} GB/s = {r['frac'] * 100:.1f} % of 8 TB/s "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence run on one MI355X box (gpurun).  Usage: scripts/profile_r4.sh <tag>   (then: python3 scripts/publish_profile.py <tag> round4_x)
 # Produces under gpurun_out/<tag>/: the default bench line (with cpu_baseline), rocprofv3 kernel-trace + stats and PMC passes (separate
-# runs) for the timed (2 s sources) workload and for the no-reuse workload (10 s sources, launches of at most 10 s: HBM only), the config sweep with the binding
+# runs) for the timed (2 s sources) workload and for the no-reuse workload (12 s sources, plan windows of 2048 blocks = 10.9 s: HBM only), the config sweep with the binding
 # unit of every shape (its own PMC pass per shape), the real-time probes, the bounce figures, the N > 1 rehearsals.
 # (Rounds 2 and 3 collected profiles/round2_e_* and round3_f_* with the same bench / rocprofv3 commands.)
 set -o pipefail
@@ -14,7 +14,7 @@ O=gpurun_out/$tag; mkdir -p $O
 if [ $part = a ]; then
 B="--no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1"
 python3 bench.py > $O/bench_line.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
-for wl in "reuse:" "noreuse:--loop-seconds 10 --plan-window 1818"; do      # (noreuse = the shape of bench.py's own HBM-only leg: 10 s sources, launches of at most 10 s)
+for wl in "reuse:" "noreuse:--loop-seconds 12 --plan-window 2048"; do      # (noreuse = the shape of bench.py's own HBM-only leg: 12 s sources, plan windows of 2048 blocks = 10.9 s)
   name=${wl%%:*}; args=${wl#*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${name}_trace -- python3 bench.py $B $args > $O/${name}_trace.log 2>&1 || echo "trace $name failed"
   rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/${name}_pmc1 -- python3 bench.py $B $args > $O/${name}_pmc1.log 2>&1 || echo "pmc1 $name failed"

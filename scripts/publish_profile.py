@@ -63,9 +63,9 @@ for wl, loops in (("reuse", 2.0), ("noreuse", nr["loop_seconds"])):
                    achieved_GBs_from_rocprof=rocprof_gbs, valu_busy=busy, wait_any_frac=wait, ta_busy=ta)
     hdr = f"""# rocprofv3 summary ({name}; written by scripts/publish_profile.py from scripts/profile_r4.sh {tag} a), kernel-source digest {digest}
 # workload: bench.py defaults (1024 stereo voices, 8 buses x 128, 256-frame blocks, 8192 blocks per call, ratio 1, linear, faithful) with
-#   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits; one launch per 8192-block call' if wl == 'reuse' else ' and plan windows of 1818 blocks (9.7 s) -- NO source byte is re-read inside a launch: every source read comes from HBM'}
+#   {loops:g} s sources{' -- the BASELINE workload: every source is re-read every 375 blocks, most re-reads are Infinity-Cache hits; one launch per 8192-block call' if wl == 'reuse' else ' and plan windows of 2048 blocks (10.9 s) -- NO source byte is re-read inside a launch: every source read comes from HBM'}
 # commands (one pass each; raw CSVs condensed by scripts/summarize_prof.py; long torch kernel names cut):
-#   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1{' --loop-seconds 10 --plan-window 1818' if wl == 'noreuse' else ''}
+#   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-reuse-check --no-spot-check --no-repeats --steps 4 --warmup 1{' --loop-seconds 12 --plan-window 2048' if wl == 'noreuse' else ''}
 #   rocprofv3 --pmc <counters> --output-format csv -- same command (5 passes: FETCH_SIZE | WRITE_SIZE TCC_HIT/MISS | TCC_EA0_RDREQ/WRREQ | SQ_* | LDS / TA / TCP)
 # {calls} zlhip_render_batch calls = {fetch[0]} K2 dispatches; the full launches are the {big['grid']}-thread ones ({BPL} blocks).
 #
@@ -86,7 +86,7 @@ for wl, loops in (("reuse", 2.0), ("noreuse", nr["loop_seconds"])):
     open(os.path.join(P, f"{name}_{wl}_rocprofv3_summary.txt"), "w").write(hdr + "\n".join(l[:260] for l in body) + "\n")
     print(hdr)
 json.dump({"kernel": "zl_k2_render<0,1,false>", "kernel_source_digest": digest,
-           "workload": "bench.py defaults (1024 voices, 8 buses, 256 frames, 8192 blocks per step, 2 s loops; HBM-only leg: 10 s loops in launches of at most 10 s)",
+           "workload": "bench.py defaults (1024 voices, 8 buses, 256 frames, 8192 blocks per step, 2 s loops; HBM-only leg: 12 s loops, plan windows of 2048 blocks = 10.9 s)",
            "traffic_over_algorithmic": out["reuse"]["traffic_over_algorithmic"],
            "gfx950_fetch_correction": "reads = 2 x FETCH_SIZE (FETCH_SIZE = TCC_EA0_RDREQ x 64 B, the requests are 128 B); calibrated on the no-reuse workload, "
                                       "where every source byte must come from HBM and 2 x FETCH_SIZE + WRITE_SIZE = %.4f x algorithmic" % out["noreuse"]["traffic_over_algorithmic"],

@@ -37,6 +37,19 @@ def main(root, out):
         lines.append("## engine kernels by grid (threads x, y, z): name, grid, calls, avg_ns, min_ns, max_ns")
         for (name, gx, gy, gz), d in sorted(shaped.items(), key=lambda kv: (kv[0][0], -len(kv[1]))):
             lines.append(f"{name[:60]}, {gx}x{gy}x{gz}, {len(d)}, {sum(d) / len(d):.0f}, {min(d)}, {max(d)}")
+        # the engine's dispatches of the last few calls on one time axis (what overlaps what, where the gaps are)
+        tl = []
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("Kernel_Name", "?")
+                if "zl_k" in name and "interleave" not in name:
+                    tl.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), name.split("(")[0][-28:], row.get("Grid_Size_Y")))
+        tl.sort()
+        if tl:
+            t0 = tl[-min(len(tl), 16)][0]
+            lines.append("## timeline of the last engine dispatches: start us, end us, duration us, kernel, grid y")
+            for a, b, n, gy in tl[-16:]:
+                lines.append(f"  {(a - t0) / 1e3:10.1f} {(b - t0) / 1e3:10.1f} {(b - a) / 1e3:9.1f}  {n}  y={gy}")
         # what sits between two render kernels (packets, the planner's hand-off): end of one K2 dispatch -> start of the next
         k2 = []
         with open(f) as fh:

@@ -464,7 +464,7 @@ int render_and_report(uint32_t nframes, const zlhip_clock *clock, float *out_lef
     if (fan_out) {
         // the passthrough clients' members as of this cycle (the setters are plain stores on the host's threads: no lock, no HIP call,
         // the resident kernel stays where it is)
-        G.passNow.resize(G.reports.size() ? (size_t)(G.cfgSet ? G.cfg.num_buses : 12) : 0);
+        G.passNow.resize((size_t)(G.cfgSet ? G.cfg.num_buses : 12));       // (initJuce: 12 channels unless libzl_hotpath_configure said otherwise)
         for (size_t b = 0; b < G.passNow.size(); ++b) G.passNow[b] = pass_of_bus((int)b);
         rc = zlhip_render_fanout(G.engine, (int32_t)nframes, clock, out_left, out_right, G.passNow.data(), fan_out);
     } else {

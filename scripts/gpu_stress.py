@@ -30,7 +30,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    N = int(rng.choice([64, 128, 192, 256, 512]))
+    N = int(rng.choice([64, 128, 192, 256, 512, 441, 1024, 100]))
     nb = int(rng.integers(20, 700))
     ml = int(rng.choice([300, 1500, 20000]))
     B, VPB, G = [(3, 8, 0), (5, 8, 0), (2, 16, 0), (2, 12, 0), (1, 24, 0), (3, 8, 4), (2, 16, 8), (2, 40, 0), (1, 64, 0)][int(rng.integers(0, 9))]   # buses, width, mix group

@@ -15,7 +15,7 @@ cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    N = int(rng.choice([64, 128, 256]))
+    N = int(rng.choice([64, 128, 256, 512, 1024, 441, 48]))    # (above 256 frames the resident workgroup walks several frame tiles)
     sc = random_scene(seed, num_buses=12, voices_per_bus=8, nclips=int(rng.integers(10, 24)), mode=int(rng.choice([0, 0, 3, 4])), nframes=N, nblocks=cycles,
                       min_len=3000, max_len=60000)
     # more events than random_scene's six: commands and edits sprinkled over the whole run

@@ -49,3 +49,15 @@ def test_one_gpu_never_launches():
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
     assert p.returncode != 0 and b"needs an MI355X" in p.stderr and b"without a launcher" not in p.stderr
+
+
+def test_failing_ranks_fail_the_command():
+    """The launcher forwards the ranks' verdict: without a GPU every rank stops ("needs an MI355X": no CPU render path), the command
+    prints no result line and exits non-zero -- it never invents a line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert b"needs an MI355X" in p.stderr

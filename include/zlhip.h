@@ -222,8 +222,11 @@ int zlhip_update_voice(zlhip_engine *e, int32_t bus, int32_t slot, const zlhip_c
 int zlhip_voice_is_playing(zlhip_engine *e, int32_t bus, int32_t slot);
 
 /* ---- render -------------------------------------------------------------------------------- */
-/* One real-time block: renders nframes for every bus and copies the mix to host memory.
- * out_left/out_right: [num_buses][nframes] each (host).  Synchronous. */
+/* One real-time block: renders nframes for every bus and delivers the mix to host memory.
+ * out_left/out_right: [num_buses][nframes] each (host).  Synchronous.
+ * Page-locked buffers (zlhip_host_alloc, or the caller's own hipHostMalloc / hipHostRegister -- e.g. of its JACK port area) are written by
+ * the kernels DIRECTLY: no copy on the host behind the cycle (1.6 us for 12 buses x 256 frames; 5 us more with the fan-out's 72 KB).
+ * Any other memory is served through the engine's staging rows and a copy.  (ZL_RT_DIRECT_OUT=0: always staged.) */
 int zlhip_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right);
 /* The same cycle, and the JackPassthrough client behind every bus with it (JackPassthroughPrivate::process, JackPassthrough.cpp:45-115;
  * the client is the next node after a SamplerSynth channel in the reference's JACK graph): the three output pairs of every bus are

@@ -142,6 +142,11 @@ struct zlhip_engine {
     float *hFan = nullptr, *hFanDev = nullptr;
     ZlPassParams *hPassRt = nullptr, *hPassRtDev = nullptr;
     uint32_t passSeq = 1;
+    // zero-copy delivery of a real-time cycle: when the caller's out_left / out_right (/ fan_out) are page-locked and mapped (zlhip_host_alloc,
+    // hipHostMalloc, hipHostRegister) the kernels write them directly -- no copy on the host behind the cycle (24 KB + 72 KB for 12 buses:
+    // 1.6 + 5 us of reading lines the device has just written).  The device views of the last buffers seen are kept.
+    struct OutViews { const void *hL = nullptr, *hR = nullptr, *hF = nullptr; float *dL = nullptr, *dR = nullptr, *dF = nullptr; bool ok = false; } outViews;
+    bool directOut = true;               // ZL_RT_DIRECT_OUT=0: always through the staging rows
     ZlLevelsState *hLevelState = nullptr;
 
     // host mirrors
@@ -606,6 +611,7 @@ int zlhip_engine_create(const zlhip_config *cfg_in, zlhip_engine **out)
         e->rt.stampsOn = std::getenv("ZL_RT_STAMPS") != nullptr;
         if (const char *mf = std::getenv("ZL_RT_MAX_FRAMES")) e->rt.maxFrames = std::max(1, std::atoi(mf));
         if (const char *su = std::getenv("ZL_RT_TRACE_SLOW_US")) e->rt.slowUs = std::atof(su);
+        if (const char *dz = std::getenv("ZL_RT_DIRECT_OUT")) e->directOut = std::atoi(dz) != 0;
         e->rt.traceOn = std::getenv("ZL_RT_TRACE") != nullptr || e->rt.slowUs > 0.0;
         if (cfg->rt_idle_timeout_us > 0) e->rt.idleTicks = (unsigned long long)cfg->rt_idle_timeout_us * 100ull;   // 100 MHz counter
     }
@@ -1009,8 +1015,19 @@ int zlhip_render_batch(zlhip_engine *e, int32_t nblocks, int32_t nframes, const 
     return zlhip_render_batch_fanout(e, nblocks, nframes, clocks, bus_out_dev, nullptr, nullptr, stream);
 }
 
+static int render_batch_impl(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks, float *bus_out_dev, long long bus_stride,
+                             long long ch_stride, const zlhip_passthrough_params *fan_params, float *fan_out_dev, void *stream);
+
 int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks, float *bus_out_dev,
                               const zlhip_passthrough_params *fan_params, float *fan_out_dev, void *stream)
+{
+    return render_batch_impl(e, nblocks, nframes, clocks, bus_out_dev, 0, 0, fan_params, fan_out_dev, stream);
+}
+
+// bus_stride / ch_stride: 0 = the bus buffer's own layout [B][2][nblocks * nframes]; else the rows of a single real-time block at the
+// caller's strides (zlhip_render_fanout delivering straight into page-locked out_left / out_right)
+static int render_batch_impl(zlhip_engine *e, int32_t nblocks, int32_t nframes, const zlhip_clock *clocks, float *bus_out_dev, long long bus_stride,
+                             long long ch_stride, const zlhip_passthrough_params *fan_params, float *fan_out_dev, void *stream)
 {
     if (!e || !clocks || ((fan_params == nullptr) != (fan_out_dev == nullptr))) return ZLHIP_ERR_INVALID;
     if (nblocks < 1 || nblocks > e->cfg.max_batch_blocks) return fail(e, ZLHIP_ERR_CAPACITY, "nblocks exceeds max_batch_blocks");
@@ -1055,6 +1072,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     A.sounds = e->dSounds; A.clips = e->dClips; A.arena = e->arena;
     A.voices = e->dVoices; A.reports = c.dReports; A.pass_cache = e->dPassCache;
     A.bus = bus_out_dev ? bus_out_dev : e->dBus; A.stats = c.dStats;
+    A.bus_stride = bus_stride; A.ch_stride = ch_stride;
     A.trace = 0; A.pos_trace = nullptr;
     int32_t *traceBase = nullptr;
     if (e->trace) {
@@ -1232,7 +1250,7 @@ int zlhip_render_batch_fanout(zlhip_engine *e, int32_t nblocks, int32_t nframes,
     if (s != e->stream) e->joins[0] = c.done;                      // later engine work (levels, read-back) waits for it on the host
     e->latest = &c;
     e->callIndex += 1;
-    e->lastK = nblocks; e->lastN = nframes; e->lastBus = A.bus; e->lastWindows = nwin;
+    e->lastK = nblocks; e->lastN = nframes; e->lastBus = bus_stride ? nullptr : A.bus; e->lastWindows = nwin;
     e->outstanding = true; e->reportsFresh = true;
     if (callStamps) {
         const auto tEnd = std::chrono::steady_clock::now();
@@ -1476,6 +1494,21 @@ void rt_trace_report(const zlhip_engine *e, const zlhip_rt_cycle_trace &t)
 }
 }  // namespace
 
+// The device views of the caller's output buffers, if all of them are page-locked and mapped (looked up once per set of pointers).
+static bool rt_out_views(zlhip_engine *e, float *out_left, float *out_right, float *fan_out)
+{
+    zlhip_engine::OutViews &v = e->outViews;
+    if (!e->directOut) return false;
+    if (v.hL == out_left && v.hR == out_right && v.hF == fan_out) return v.ok;
+    v.hL = out_left; v.hR = out_right; v.hF = fan_out; v.ok = false;
+    void *dL = nullptr, *dR = nullptr, *dF = nullptr;
+    if (hipHostGetDevicePointer(&dL, out_left, 0) != hipSuccess || hipHostGetDevicePointer(&dR, out_right, 0) != hipSuccess
+        || (fan_out && hipHostGetDevicePointer(&dF, fan_out, 0) != hipSuccess)) { (void)hipGetLastError(); return false; }   // pageable memory: staged
+    v.dL = (float *)dL; v.dR = (float *)dR; v.dF = (float *)dF;
+    v.ok = ((uintptr_t)dL % 4 == 0) && ((uintptr_t)dR % 4 == 0);
+    return v.ok;
+}
+
 // One real-time block through the resident kernel: post the block in the mailbox, spin until the kernel has published it.
 static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock, float *out_left, float *out_right,
                      const zlhip_passthrough_params *fan_params, float *fan_out)
@@ -1525,6 +1558,13 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
     sh->nframes = nframes; sh->n_op_ranges = A.n_op_ranges; sh->ops = A.ops; sh->op_ranges = A.op_ranges;
     sh->n_clip_edits = A.n_clip_edits; sh->clip_edits = A.clip_edits;
     sh->ctl_base = q.ctlBase; q.ctlBase += (unsigned long long)e->V + 1ull;
+    const bool direct = rt_out_views(e, out_left, out_right, fan_out);
+    if (direct) {
+        sh->out_bus = e->outViews.dL; sh->out_bus_stride = (long long)nframes; sh->out_ch_stride = (long long)(e->outViews.dR - e->outViews.dL);
+        sh->out_fan = e->outViews.dF;
+    } else {
+        sh->out_bus = e->hBusDev; sh->out_bus_stride = 2ll * nframes; sh->out_ch_stride = (long long)nframes; sh->out_fan = e->hFanDev;
+    }
     sh->fan_seq = 0u;
     if (fan_out) {
         // the JackPassthrough parameters: a table in mapped host memory and its version.  A workgroup keeps its bus's entry across cycles
@@ -1574,13 +1614,15 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
         }
     }
     const size_t B = (size_t)e->cfg.num_buses, N = (size_t)nframes;
-    for (size_t b = 0; b < B; ++b) {
-        std::memcpy(out_left + b * N, e->hBus + (b * 2) * N, N * sizeof(float));
-        std::memcpy(out_right + b * N, e->hBus + (b * 2 + 1) * N, N * sizeof(float));
-    }
     const auto tDone = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (tr) { const double g = us_between(tPoll, tDone); if (g > maxGap) maxGap = g; }   // (the thread may be taken off between the post and its first poll)
-    if (fan_out) std::memcpy(fan_out, e->hFan, B * 6 * N * sizeof(float));
+    if (!direct) {
+        for (size_t b = 0; b < B; ++b) {
+            std::memcpy(out_left + b * N, e->hBus + (b * 2) * N, N * sizeof(float));
+            std::memcpy(out_right + b * N, e->hBus + (b * 2 + 1) * N, N * sizeof(float));
+        }
+        if (fan_out) std::memcpy(fan_out, e->hFan, B * 6 * N * sizeof(float));
+    }
     double devUs = 0.0;
     if (e->rt.stampsOn) {                                          // (workgroup 0's last stamp may still be in flight when another workgroup finishes the block)
         for (int i = 0; i < 5; ++i) { const long long d = (long long)(sh->stamps[i + 1] - sh->stamps[i]); if (d >= 0 && d < 100000000ll) { e->rt.stampSum[i] += (double)d * 0.01; devUs += (double)d * 0.01; } }
@@ -1595,7 +1637,7 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
         rt_trace_report(e, t);
     }
     e->latest = &c;
-    e->lastK = 1; e->lastN = nframes; e->lastBus = e->hBusDev; e->lastWindows = 1;
+    e->lastK = 1; e->lastN = nframes; e->lastBus = direct ? nullptr : e->hBusDev; e->lastWindows = 1;   // (delivered straight to the caller: nothing to read back)
     e->outstanding = false; e->reportsFresh = true;
     e->rt.cycles += 1;
     return ZLHIP_OK;
@@ -1623,18 +1665,23 @@ int zlhip_render_fanout(zlhip_engine *e, int32_t nframes, const zlhip_clock *clo
     const bool tr = e->rt.traceOn;
     const auto tEnter = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     const long sw0 = tr ? thread_nivcsw() : 0;
-    int rc = zlhip_render_batch_fanout(e, 1, nframes, clock, e->hBusDev, fan_params, fan_out ? e->hFanDev : nullptr, nullptr);
+    const bool direct = rt_out_views(e, out_left, out_right, fan_out);
+    int rc = direct ? render_batch_impl(e, 1, nframes, clock, e->outViews.dL, (long long)nframes, (long long)(e->outViews.dR - e->outViews.dL), fan_params,
+                                        fan_out ? e->outViews.dF : nullptr, nullptr)
+                    : render_batch_impl(e, 1, nframes, clock, e->hBusDev, 0, 0, fan_params, fan_out ? e->hFanDev : nullptr, nullptr);
     if (rc != ZLHIP_OK) return rc;
     const size_t B = (size_t)e->cfg.num_buses, N = (size_t)nframes;
     const auto tPost = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     ZL_HIP(e, hipEventSynchronize(e->latest->done));
     const auto tDone = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     e->outstanding = false;
-    for (size_t b = 0; b < B; ++b) {
-        std::memcpy(out_left + b * N, e->hBus + (b * 2) * N, N * sizeof(float));
-        std::memcpy(out_right + b * N, e->hBus + (b * 2 + 1) * N, N * sizeof(float));
+    if (!direct) {
+        for (size_t b = 0; b < B; ++b) {
+            std::memcpy(out_left + b * N, e->hBus + (b * 2) * N, N * sizeof(float));
+            std::memcpy(out_right + b * N, e->hBus + (b * 2 + 1) * N, N * sizeof(float));
+        }
+        if (fan_out) std::memcpy(fan_out, e->hFan, B * 6 * N * sizeof(float));
     }
-    if (fan_out) std::memcpy(fan_out, e->hFan, B * 6 * N * sizeof(float));
     if (tr) {
         const auto tExit = std::chrono::steady_clock::now();
         zlhip_rt_cycle_trace &t = e->rt.last;
@@ -1657,7 +1704,7 @@ int zlhip_rt_last_cycle(zlhip_engine *e, zlhip_rt_cycle_trace *out)
 int zlhip_read_bus(zlhip_engine *e, float *out, size_t out_floats)
 {
     if (!e || !out) return ZLHIP_ERR_INVALID;
-    if (!e->lastBus) return fail(e, ZLHIP_ERR_STATE, "no batch rendered yet");
+    if (!e->lastBus) return fail(e, ZLHIP_ERR_STATE, "nothing to read back: no batch rendered yet, or the last real-time cycle went straight into the caller's page-locked buffers");
     const size_t need = (size_t)e->cfg.num_buses * 2 * (size_t)e->lastK * (size_t)e->lastN;
     if (out_floats < need) return fail(e, ZLHIP_ERR_INVALID, "output buffer too small");
     ZL_HIP(e, hipSetDevice(e->device));

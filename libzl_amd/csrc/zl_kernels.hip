@@ -857,9 +857,9 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
     auto store_bus = [&](int bus) {
         float *outL, *outR;
         if (A.groups == 1) {
-            const size_t KN = (size_t)A.Ktot * N;
-            outL = A.bus + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N;
-            outR = outL + KN;
+            const long long KN = (long long)A.Ktot * N;
+            outL = A.bus + (long long)bus * (A.bus_stride ? A.bus_stride : 2 * KN) + (long long)(A.k0 + k) * N;
+            outR = outL + (A.ch_stride ? A.ch_stride : KN);
         } else {
             outL = A.partials + ((((size_t)k * A.B + bus) * A.groups + g) * 2) * (size_t)N;
             outR = outL + N;
@@ -1271,11 +1271,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         w[4] = sh->clock.current_usecs; w[5] = sh->clock.next_usecs; w[6] = sh->clock.playhead; w[7] = sh->clock.playhead_usecs;
                         w[8] = sh->clock.subbeat_usecs; w[9] = sh->clock.usecs_per_frame;
                         w[10] = (unsigned long long)(uint32_t)sh->n_clip_edits | ((unsigned long long)sh->fan_seq << 32); w[11] = (unsigned long long)(uintptr_t)sh->clip_edits;
+                        w[12] = (unsigned long long)(uintptr_t)sh->out_bus; w[13] = (unsigned long long)(uintptr_t)sh->out_fan;
+                        w[14] = (unsigned long long)sh->out_bus_stride; w[15] = (unsigned long long)sh->out_ch_stride;
                         {
                             static_assert(sizeof(sh->inline_edits) == ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS * 8, "inline edits are whole words");
                             const unsigned long long *ie = reinterpret_cast<const unsigned long long *>(&sh->inline_edits[0]);
 #pragma unroll
-                            for (int i = 0; i < ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS; ++i) w[12 + i] = ie[i];
+                            for (int i = 0; i < ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS; ++i) w[ZL_RT_CMD_FIXED + i] = ie[i];
                         }
 #pragma unroll
                         for (int i = 0; i < ZL_RT_CMD_WORDS; ++i) { s_cmd[1 + i] = w[i]; __hip_atomic_store(&dev->cmd[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1322,6 +1324,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         // ---- JackPassthrough fan-out of this cycle (JackPassthrough.cpp:45-115): asked for per cycle; the parameters of the workgroup's
         //      bus are kept in LDS across cycles and read again from the host's table (mapped memory: a trip over PCIe, issued here and
         //      needed at the store, after planning) only when the host moved the table's version -- a knob turned while playing
+        // where the cycle's rows go: the engine's staging rows, or straight into the caller's page-locked buffers
+        A.bus = reinterpret_cast<float *>((uintptr_t)s_cmd[13]); A.fan = reinterpret_cast<float *>((uintptr_t)s_cmd[14]);
+        A.bus_stride = (long long)s_cmd[15]; A.ch_stride = (long long)s_cmd[16];
         const uint32_t fan_seq = (uint32_t)(s_cmd[11] >> 32);
         if (fan_seq == 0u) A.fan = nullptr;
         else if (tid == 0 && fan_seq != s_pass_seq) {
@@ -1363,7 +1368,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         // (the knob edits that came with the command: 8 words each, from LDS)
         if (tid < ZL_RT_INLINE_EDITS * (ZL_CLIP_HEAD_BYTES / 4)) {
             const int ei = tid / (ZL_CLIP_HEAD_BYTES / 4), wi = tid % (ZL_CLIP_HEAD_BYTES / 4);
-            const unsigned long long *ew = &s_cmd[1 + 12 + ei * ZL_RT_EDIT_WORDS];
+            const unsigned long long *ew = &s_cmd[1 + ZL_RT_CMD_FIXED + ei * ZL_RT_EDIT_WORDS];
             const int clip = (int)(uint32_t)ew[0];
             if (clip >= 0) reinterpret_cast<uint32_t *>(const_cast<ZlClip *>(A.clips) + clip)[wi] = reinterpret_cast<const uint32_t *>(ew + 1)[wi];
         }
@@ -1488,10 +1493,10 @@ static __device__ __forceinline__ void zl_k3_body(const ZlBatch &A, const float 
 {
     const int N = A.N;
     const size_t KN = (size_t)A.Ktot * N;
-    float *outL = A.bus ? A.bus + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N : nullptr;
-    float *outR = outL ? outL + KN : nullptr;
+    float *outL = A.bus ? A.bus + (long long)bus * (A.bus_stride ? A.bus_stride : 2 * (long long)KN) + (long long)(A.k0 + k) * N : nullptr;
+    float *outR = outL ? outL + (A.ch_stride ? A.ch_stride : (long long)KN) : nullptr;
     const float *inL = bus_in ? bus_in + ((size_t)bus * 2) * KN + (size_t)(A.k0 + k) * N : outL;
-    const float *inR = inL + KN;
+    const float *inR = bus_in ? inL + KN : outR;
 
     for (int f = threadIdx.x; f < N && A.groups > 1 && !bus_in; f += blockDim.x) {
         float l, r;
@@ -1547,9 +1552,10 @@ __global__ void __launch_bounds__(256) zl_k3_scan(const ZlBatch A, const float *
     if (pair >= (long long)A.K * A.B) return;                                     // whole waves leave
     const int k = (int)(pair / A.B), b = (int)(pair - (long long)k * A.B);
     const int lane = threadIdx.x & 63;
-    const size_t KN = (size_t)A.Ktot * N;
-    const float *inL = bus + ((size_t)b * 2) * KN + (size_t)(A.k0 + k) * N;
-    const ZlBlockLevels out = zl_scan_rows(inL, inL + KN, N, (A.mode & ZL_MODE_FIX_DELAY) ? 0 : 1, lane);
+    const long long KN = (long long)A.Ktot * N;
+    const bool own = bus == A.bus;                                 // the call's own bus may have the caller's strides
+    const float *inL = bus + (long long)b * (own && A.bus_stride ? A.bus_stride : 2 * KN) + (long long)(A.k0 + k) * N;
+    const ZlBlockLevels out = zl_scan_rows(inL, inL + (own && A.ch_stride ? A.ch_stride : KN), N, (A.mode & ZL_MODE_FIX_DELAY) ? 0 : 1, lane);
     if (lane == 0) A.levels[(size_t)k * A.B + b] = out;
 }
 

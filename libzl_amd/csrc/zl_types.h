@@ -226,6 +226,11 @@ struct ZlRtShared {
     int32_t  n_clip_edits;
     uint32_t yield;               // another thread of the process is about to make a device-synchronising HIP call (hipFree, ...):
                                   // leave after the cycle in flight (zl_engine.cpp, ZlQuiesce)
+    // where this cycle's rows go (device views): the engine's own staging rows in mapped host memory, or -- when the caller's buffers
+    // are page-locked -- straight into them (no copy on the host afterwards).  Row of (bus, channel): out_bus + bus * out_bus_stride +
+    // channel * out_ch_stride floats; the fan-out rows [B][6][nframes] at out_fan
+    float   *out_bus, *out_fan;
+    long long out_bus_stride, out_ch_stride;
     uint32_t fan_seq;             // 0: this cycle delivers the buses only.  Else: it also delivers the JackPassthrough fan-out of every bus
                                   // (ZlBatch::fan, mapped host memory) and this is the version of the parameter table (ZlBatch::pass, mapped
                                   // host memory too): a workgroup re-reads its bus's entry only when the version moved (a knob was turned)
@@ -237,11 +242,13 @@ struct ZlRtShared {
 // that have finished the block.
 #define ZL_RT_INLINE_EDITS 2
 #define ZL_RT_EDIT_WORDS (1 + ZL_CLIP_HEAD_BYTES / 8)      // clip id + the head, in 8-byte words
-#define ZL_RT_CMD_WORDS (12 + ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS)
+#define ZL_RT_CMD_FIXED 16                                 // the words in front of the inline knob edits
+#define ZL_RT_CMD_WORDS (ZL_RT_CMD_FIXED + ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS)
 #define ZL_RT_MAX_BUSES 256
 struct ZlRtDev {
     unsigned long long pub_seq;                  // the block being rendered (~0ull: leave)
-    unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words), n_clip_edits, clip_edits, the inline knob edits
+    unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words), n_clip_edits | fan_seq << 32, clip_edits,
+                                                 // out_bus, out_fan, out_bus_stride, out_ch_stride, the inline knob edits
     unsigned int arrive, pad;
     unsigned int bus_arrive[ZL_RT_MAX_BUSES];    // wide buses (one workgroup per voice): the voices of a bus that have written their partial mix
 };
@@ -291,7 +298,10 @@ struct ZlBatch {
     ZlSimConst         *sim_const;// [V]
     ZlReport           *reports;  // [V]
     float              *partials; // [K][B][groups][2][N]  (only when groups > 1)
-    float              *bus;      // [B][2][Ktot*N]
+    float              *bus;      // [B][2][Ktot*N] -- or, with the strides below, rows wherever the caller wants them
+    long long           bus_stride, ch_stride;   // floats from one bus's rows to the next / from a bus's left row to its right row; 0 = the
+                                                 // layout above (2 * Ktot * N, Ktot * N).  A real-time cycle delivered straight into the caller's
+                                                 // page-locked out_left[B][N] / out_right[B][N] has bus_stride = N, ch_stride = out_right - out_left
     ZlPassCache        *pass_cache; // [V] or nullptr
     const ZlPassParams *pass;     // [B] JackPassthrough parameters of the fused fan-out (with fan)
     float              *fan;      // [B][6][Ktot*N] dry L,R / wetFx1 L,R / wetFx2 L,R of every bus, or nullptr

@@ -236,6 +236,17 @@ class SamplerSynth:
         self._last = (1, nframes)
         return L, R
 
+    def process_into(self, nframes: int, clock: Clock, left: np.ndarray, right: np.ndarray, fan_params: Optional[Sequence[PassthroughParams]] = None,
+                     fan: Optional[np.ndarray] = None):
+        """One real-time cycle into the caller's arrays ([B, nframes] each, fan [B, 6, nframes]).  Page-locked arrays (pinned_array) are
+        written by the kernels directly -- no host copy behind the cycle."""
+        if fan is not None:
+            arr = (PassthroughParams * self.num_buses)(*fan_params)
+            self._ck(self._lib.zlhip_render_fanout(self._e, nframes, C.byref(clock), left.ctypes.data, right.ctypes.data, arr, fan.ctypes.data), "render_fanout")
+        else:
+            self._ck(self._lib.zlhip_render(self._e, nframes, C.byref(clock), left.ctypes.data, right.ctypes.data), "render")
+        self._last = (1, nframes)
+
     def process_fanout(self, nframes: int, clock: Clock, fan_params: Sequence[PassthroughParams]):
         """One real-time cycle with the JackPassthrough client behind every bus (zlhip_render_fanout): returns
         (left[B,N], right[B,N], fan[B,6,N]) -- fan rows = dryL, dryR, fx1L, fx1R, fx2L, fx2R."""

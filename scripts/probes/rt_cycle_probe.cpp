@@ -21,7 +21,7 @@
 
 using clk = std::chrono::steady_clock;
 
-struct Row { int V, B, N; bool resident, paced, fan; int hogs; };   // hogs: busy threads next to the cycle thread (more than the box's CPU quota: the attribution's known answer)
+struct Row { int V, B, N; bool resident, paced, fan; int hogs; bool pinned = false; };   // pinned: the caller's buffers are page-locked (the kernels write them directly)   // hogs: busy threads next to the cycle thread (more than the box's CPU quota: the attribution's known answer)
 
 static int run(const Row &r, int cycles)
 {
@@ -49,7 +49,13 @@ static int run(const Row &r, int cycles)
         c.clip = id; c.midi_note = 60; c.midi_channel = v / vpb - 2; c.start_playback = 1; c.looping = 1; c.change_volume = 1; c.volume = 0.5f;
         if (zlhip_start_voice(e, v / vpb, v % vpb, &c, 0) != 1) { std::fprintf(stderr, "start failed\n"); return 1; }
     }
-    std::vector<float> L((size_t)r.B * r.N), R((size_t)r.B * r.N), fan(r.fan ? (size_t)r.B * 6 * r.N : 0);
+    std::vector<float> Lv((size_t)r.B * r.N), Rv((size_t)r.B * r.N), fanv(r.fan ? (size_t)r.B * 6 * r.N : 0);
+    float *L = Lv.data(), *R = Rv.data(), *fan = fanv.data();
+    void *pin = nullptr;
+    if (r.pinned) {
+        if (zlhip_host_alloc((size_t)r.B * r.N * 8 * sizeof(float), &pin) != ZLHIP_OK) { std::fprintf(stderr, "no pinned memory\n"); return 1; }
+        L = (float *)pin; R = L + (size_t)r.B * r.N; fan = R + (size_t)r.B * r.N;
+    }
     std::vector<zlhip_passthrough_params> pp((size_t)r.B);
     for (int i = 0; i < r.B; ++i) { zlhip_passthrough_params_default(&pp[(size_t)i]); pp[(size_t)i].dry_amount = 0.9f; pp[(size_t)i].wet_fx1_amount = 0.5f; pp[(size_t)i].pan_amount = 0.1f * (float)(i % 3 - 1); }
     const uint64_t period = (uint64_t)std::llround(1e6 * r.N / fs);
@@ -68,7 +74,7 @@ static int run(const Row &r, int cycles)
         c.current_usecs = (uint64_t)k * period; c.next_usecs = (uint64_t)(k + 1) * period; c.jack_playhead = 0; c.jack_playhead_usecs = 0; c.jack_subbeat_length_usecs = 5208;
         if (r.fan && (k % 200) == 100) pp[(size_t)(k / 200 % r.B)].pan_amount += 0.01f;      // a knob now and then
         const auto t0 = clk::now();
-        const int rc = r.fan ? zlhip_render_fanout(e, r.N, &c, L.data(), R.data(), pp.data(), fan.data()) : zlhip_render(e, r.N, &c, L.data(), R.data());
+        const int rc = r.fan ? zlhip_render_fanout(e, r.N, &c, L, R, pp.data(), fan) : zlhip_render(e, r.N, &c, L, R);
         const auto t1 = clk::now();
         if (rc != ZLHIP_OK) { std::fprintf(stderr, "render failed: %d %s\n", rc, zlhip_last_error(e)); return 1; }
         if (k < 50) continue;
@@ -83,7 +89,7 @@ static int run(const Row &r, int cycles)
     std::vector<double> sorted = us;
     std::sort(sorted.begin(), sorted.end());
     std::printf("V=%4d B=%3d N=%4d %s %s %s: p50 %6.1f us  p99 %6.1f us  p99.9 %6.1f us  max %8.1f us  (period %5.0f us, %d cycles, resident launches %llu, cycles over 1 ms: %zu)\n",
-                r.V, r.B, r.N, r.resident ? "resident" : "launched", r.paced ? "paced    " : "back2back", r.fan ? "fan-out" : (r.hogs ? "+hogs  " : "       "),
+                r.V, r.B, r.N, r.resident ? "resident" : "launched", r.paced ? "paced    " : "back2back", r.fan ? (r.pinned ? "fan, pinned" : "fan-out    ") : (r.hogs ? "+hogs      " : (r.pinned ? "pinned     " : "           ")),
                 sorted[sorted.size() / 2], sorted[(size_t)((double)sorted.size() * 0.99)], sorted[(size_t)((double)sorted.size() * 0.999)], sorted.back(),
                 1e6 * r.N / fs, cycles, (unsigned long long)starts, slow.size());
     for (size_t si = 0; si < slow.size(); ++si) {
@@ -98,6 +104,7 @@ static int run(const Row &r, int cycles)
     }
     std::fflush(stdout);
     zlhip_engine_destroy(e);
+    if (pin) zlhip_host_free(pin);
     return 0;
 }
 
@@ -117,9 +124,16 @@ int main(int argc, char **argv)
         if (!quick) { rows.push_back({96, 12, 2048, res == 1, false, false, 0}); rows.push_back({96, 12, 4096, res == 1, false, false, 0}); }
         rows.push_back({96, 12, 256, res == 1, false, true, 0});       // with the JackPassthrough fan-out (three more pairs per bus over PCIe)
     }
+    // the caller's buffers page-locked: the kernels deliver straight into them (no host copy behind the cycle)
+    for (int res = 0; res < 2; ++res) {
+        Row a{96, 12, 256, res == 1, false, false, 0}; a.pinned = true; rows.push_back(a);
+        Row b{96, 12, 256, res == 1, false, true, 0}; b.pinned = true; rows.push_back(b);
+        Row c{96, 12, 1024, res == 1, false, false, 0}; c.pinned = true; rows.push_back(c);
+    }
     for (int res = 0; res < 2; ++res) {
         rows.push_back({96, 12, 256, res == 1, true, false, 0});       // paced: one cycle per JACK period, as JACK runs it (the GPU idles in between)
         rows.push_back({96, 12, 256, res == 1, true, true, 0});
+        { Row d{96, 12, 256, res == 1, true, true, 0}; d.pinned = true; rows.push_back(d); }
         if (!quick) { rows.push_back({96, 12, 512, res == 1, true, false, 0}); rows.push_back({96, 12, 1024, res == 1, true, false, 0}); }
     }
     // the attribution's known answer: far more busy threads than the box grants this job CPUs (cgroup quota) -- the cycle thread loses

@@ -300,3 +300,55 @@ def test_a_bpm_that_would_divide_by_zero_is_ignored(built):
 
     a, b = session(True), session(False)
     assert np.abs(b).max() > 0.1 and np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
+@pytest.mark.parametrize("case", ["narrow_128", "two_frame_tiles", "wide_resident", "launched", "launched_wide_512", "ragged_tiles_441"])
+def test_cycles_delivered_straight_into_page_locked_buffers(built, case):
+    """zlhip_render / zlhip_render_fanout into the caller's PAGE-LOCKED out_left / out_right / fan_out: the kernels write them directly (no
+    staging rows, no host copy behind the cycle) at the caller's strides -- separate left and right planes, each [B][nframes].  Same bits
+    as the oracle, through the resident kernel (narrow, tiled, wide) and the launched path; alternating with pageable buffers on the
+    same engine (which go through the staging rows); the planes may sit anywhere relative to each other (right BEFORE left here)."""
+    from libzl_amd.engine import pinned_array
+    kw, N, mode, env, want_starts = CASES[case]
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        sc = random_scene(1300 + N, nframes=64, nblocks=1, events=False, mode=mode, **kw)
+        syn, osyn = _engines(sc, max_frames=max(64, N), mode=mode)
+        B = sc.num_buses
+        planes = pinned_array(syn._lib, (2, B, N), np.float32)        # [0] = right, [1] = left: the channel stride is negative
+        R, L = planes[0], planes[1]
+        fan = pinned_array(syn._lib, (B, 6, N), np.float32)
+        zoo = _zoo()
+        t = 0
+        for k in range(30):
+            params = [zoo[(b + k // 4) % len(zoo)] for b in range(B)]
+            clk, t = _clock(sc, t, N)
+            bus, _ = osyn.render_batch(1, N, [clk])
+            if k % 5 == 3:                                            # a cycle into pageable arrays in between: staged
+                l2, r2, f2 = syn.process_fanout(N, clk, params)
+                got = (l2, r2, f2)
+            elif k % 5 == 1:                                          # no fan-out this cycle
+                L[:] = 7.0; R[:] = 7.0
+                syn.process_into(N, clk, L, R)
+                got = (L, R, None)
+            else:
+                L[:] = 7.0; R[:] = 7.0; fan[:] = 7.0
+                syn.process_into(N, clk, L, R, params, fan)
+                got = (L, R, fan)
+            assert np.array_equal(got[0].view(np.int32), bus[:, 0].view(np.int32)) and np.array_equal(got[1].view(np.int32), bus[:, 1].view(np.int32)), (case, k)
+            if got[2] is not None:
+                want = _oracle_fanout(bus, params)
+                assert np.array_equal(got[2].view(np.int32), want.view(np.int32)), (case, k)
+        peaks = syn.block_peaks()
+        exp = np.abs(np.float32(131072.0) * bus).astype(np.int64).max(axis=2)
+        assert np.array_equal(peaks[-1].astype(np.int64), exp), case
+        starts, done = syn.rt_stats()
+        syn.close()
+        assert starts == want_starts and done == (30 if want_starts else 0), (case, starts, done)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

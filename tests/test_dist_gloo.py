@@ -67,7 +67,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_voices_reduce_to_the_full_mix(built, world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from scenario import run_oracle

@@ -19,7 +19,7 @@ def _run(extra, env=None):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=240)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 8])
 def test_the_bare_command_starts_its_own_ranks(world):
     p = _run(["--gpus", str(world), "--launch-check"])
     assert p.returncode == 0, p.stderr.decode()[-2000:]

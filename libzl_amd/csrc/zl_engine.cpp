@@ -1387,6 +1387,7 @@ static bool rt_eligible(zlhip_engine *e, int nframes)
     if (!(e->rt.enabled && nframes <= e->rt.maxFrames && e->cfg.voices_per_task <= 0 && !e->trace)) return false;
     const bool wide = rt_wide(e);
     if (wide && e->rt.wide == 0) return false;
+    static_assert(ZL_RT_DONE_SLOTS >= 64, "one completion word per resident workgroup of a narrow engine");
     if (e->cfg.num_buses > (wide ? ZL_RT_MAX_BUSES : 64)) return false;
     int &cap = e->rt.capacity[wide ? 1 : 0];
     if (cap < 0) cap = zl_rt_loop_capacity(e->cfg.mode, wide ? 1 : 0, 256, e->device);
@@ -1469,6 +1470,7 @@ static int rt_start(zlhip_engine *e, int nframes)
     if (!rt_fits(e)) return ZL_RT_NOFIT;
     __atomic_store_n(&e->rt.h->state, 0u, __ATOMIC_RELEASE);
     __atomic_store_n(&e->rt.h->yield, 0u, __ATOMIC_RELEASE);
+    for (uint32_t &d : e->rt.h->wg_done) __atomic_store_n(&d, (uint32_t)e->rt.seq, __ATOMIC_RELAXED);   // (no workgroup has finished the cycle to come)
     ZL_KERNEL(e, zl_launch_rt_loop(A, e->rt.d, e->rt.dev, e->rt.seq, e->rt.idleTicks, e->dGain, c.hReportsDev, c.hGainDev, e->rt.devRanges, std::max(e->rt.vw, 1), std::min(256, (nframes + 63) & ~63), e->rt.stream));
     e->rt.running = true; e->rt.nframes = nframes; e->rt.starts += 1;
     if (std::find(g_rt.engines.begin(), g_rt.engines.end(), e) == g_rt.engines.end()) g_rt.engines.push_back(e);
@@ -1539,33 +1541,39 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
     // the launched path with everything still pending)
     if (!e->rt.running) { int rc = rt_start(e, nframes); if (rc != ZLHIP_OK) return rc; }
     ZlRtShared *sh = e->rt.h;
+    unsigned long long *w = sh->cmd;                                // the cycle's command words (zl_types.h, ZlRtShared)
     {
-        // knob edits (no slice table) ride in the mailbox, the first ZL_RT_INLINE_EDITS of them; the rest go through the edit buffer
+        // knob edits (no slice table) ride in the mailbox itself, the first ZL_RT_INLINE_EDITS of them; the rest go through the edit buffer
         int ni = 0;
         auto &pe = e->hc.pendingClipEdits;
         for (size_t i = 0; i < pe.size() && ni < ZL_RT_INLINE_EDITS;) {
             if (pe[i].full) { ++i; continue; }
-            sh->inline_edits[ni].clip = pe[i].clip; sh->inline_edits[ni].pad = 0;
-            std::memcpy(sh->inline_edits[ni].head, &pe[i].c, ZL_CLIP_HEAD_BYTES);
+            unsigned long long *ew = w + ZL_RT_CMD_FIXED + ni * ZL_RT_EDIT_WORDS;
+            ew[0] = (unsigned long long)(uint32_t)pe[i].clip;
+            std::memcpy(ew + 1, &pe[i].c, ZL_CLIP_HEAD_BYTES);
             ++ni;
             pe.erase(pe.begin() + (long)i);
         }
-        for (; ni < ZL_RT_INLINE_EDITS; ++ni) sh->inline_edits[ni].clip = -1;
+        for (; ni < ZL_RT_INLINE_EDITS; ++ni) w[ZL_RT_CMD_FIXED + ni * ZL_RT_EDIT_WORDS] = (unsigned long long)(uint32_t)-1;
     }
     int rc = upload_ops(e, c, A);
     if (rc != ZLHIP_OK) return rc;
-    ZlHostControl::fill_clock(sh->clock, *clock, nframes);
-    sh->nframes = nframes; sh->n_op_ranges = A.n_op_ranges; sh->ops = A.ops; sh->op_ranges = A.op_ranges;
-    sh->n_clip_edits = A.n_clip_edits; sh->clip_edits = A.clip_edits;
-    sh->ctl_base = q.ctlBase; q.ctlBase += (unsigned long long)e->V + 1ull;
+    ZlClock ck;
+    ZlHostControl::fill_clock(ck, *clock, nframes);
+    w[0] = (unsigned long long)(uint32_t)nframes | ((unsigned long long)(uint32_t)A.n_op_ranges << 32);
+    w[1] = (unsigned long long)(uintptr_t)A.ops; w[2] = (unsigned long long)(uintptr_t)A.op_ranges;
+    w[3] = q.ctlBase; q.ctlBase += (unsigned long long)e->V + 1ull;
+    w[4] = ck.current_usecs; w[5] = ck.next_usecs; w[6] = ck.playhead; w[7] = ck.playhead_usecs; w[8] = ck.subbeat_usecs; w[9] = ck.usecs_per_frame;
+    w[11] = (unsigned long long)(uintptr_t)A.clip_edits;
     const bool direct = rt_out_views(e, out_left, out_right, fan_out);
     if (direct) {
-        sh->out_bus = e->outViews.dL; sh->out_bus_stride = (long long)nframes; sh->out_ch_stride = (long long)(e->outViews.dR - e->outViews.dL);
-        sh->out_fan = e->outViews.dF;
+        w[12] = (unsigned long long)(uintptr_t)e->outViews.dL; w[13] = (unsigned long long)(uintptr_t)e->outViews.dF;
+        w[14] = (unsigned long long)(long long)nframes; w[15] = (unsigned long long)(long long)(e->outViews.dR - e->outViews.dL);
     } else {
-        sh->out_bus = e->hBusDev; sh->out_bus_stride = 2ll * nframes; sh->out_ch_stride = (long long)nframes; sh->out_fan = e->hFanDev;
+        w[12] = (unsigned long long)(uintptr_t)e->hBusDev; w[13] = (unsigned long long)(uintptr_t)e->hFanDev;
+        w[14] = (unsigned long long)(2ll * nframes); w[15] = (unsigned long long)(long long)nframes;
     }
-    sh->fan_seq = 0u;
+    uint32_t fanSeq = 0u;
     if (fan_out) {
         // the JackPassthrough parameters: a table in mapped host memory and its version.  A workgroup keeps its bus's entry across cycles
         // and reads the table again only when the version moved, so a quiet cycle makes no extra trip over PCIe
@@ -1575,8 +1583,9 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
             if (std::memcmp(&pp, &e->hPassRt[b], sizeof pp) != 0) { e->hPassRt[b] = pp; moved = true; }
         }
         if (moved && ++e->passSeq == 0u) e->passSeq = 1u;
-        sh->fan_seq = e->passSeq;
+        fanSeq = e->passSeq;
     }
+    w[10] = (unsigned long long)(uint32_t)A.n_clip_edits | ((unsigned long long)fanSeq << 32);
     const unsigned long long seq = ++e->rt.seq;
     const auto tPost = tr ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     auto tPoll = tPost; double maxGap = 0.0;
@@ -1584,14 +1593,21 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
     // spin: a block takes some tens of microseconds.  The kernel may have left (idle timeout) just before the post: then start
     // it again -- it picks the posted block up at once (first_seq = the last block it saw finished).
     const auto spin0 = std::chrono::steady_clock::now();
+    // narrow buses: every workgroup reports its own completion (wg_done); wide buses: the last arrival writes done_seq
+    const int doneSlots = rt_wide(e) ? 0 : e->cfg.num_buses;
+    auto cycle_done = [&]() -> bool {
+        if (doneSlots == 0) return __atomic_load_n(&sh->done_seq, __ATOMIC_ACQUIRE) == seq;
+        for (int z = 0; z < doneSlots; ++z) if (__atomic_load_n(&sh->wg_done[z], __ATOMIC_ACQUIRE) != (uint32_t)seq) return false;
+        return true;
+    };
     for (unsigned long long spins = 0;; ++spins) {
-        if (__atomic_load_n(&sh->done_seq, __ATOMIC_ACQUIRE) == seq) break;
+        if (cycle_done()) break;
         if (tr) { const auto n_ = std::chrono::steady_clock::now(); const double g = us_between(tPoll, n_); if (g > maxGap) maxGap = g; tPoll = n_; }
         if ((spins & 0xfffu) == 0xfffu) {
             if (__atomic_load_n(&sh->state, __ATOMIC_ACQUIRE) == 2u) {
                 ZL_HIP(e, hipStreamSynchronize(e->rt.stream));
                 e->rt.running = false;
-                if (__atomic_load_n(&sh->done_seq, __ATOMIC_ACQUIRE) == seq) break;
+                if (cycle_done()) break;
                 rt_unregister(e);
                 e->rt.seq = seq - 1;                               // the restarted kernel must see `seq` as new
                 // (a device-synchronising call somewhere in the process made the kernel leave with this cycle posted but not taken:
@@ -1605,7 +1621,7 @@ static int rt_render(zlhip_engine *e, int32_t nframes, const zlhip_clock *clock,
             if (std::chrono::steady_clock::now() - spin0 > std::chrono::seconds(2)) {
                 e->rt.enabled = false;
                 (void)rt_stop(e);
-                if (__atomic_load_n(&sh->done_seq, __ATOMIC_ACQUIRE) == seq) break;      // it did finish the cycle after all: deliver it; launches from now on
+                if (cycle_done()) break;                                   // it did finish the cycle after all: deliver it; launches from now on
                 // The cycle was posted and its voice operations were taken: some buses may have applied and rendered it, others not.
                 // The voice table no longer matches the host's control state -- not recoverable: every later render call fails.
                 e->failed = true;

@@ -1261,28 +1261,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (;;) {
                     const unsigned long long q = __hip_atomic_load(&sh->cmd_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (q != last) {
-                        // the host published the block's inputs with a release store of cmd_seq: acquire before reading them (the same
-                        // mailbox lines are read every cycle; without this a cycle may see the previous cycle's cached clock or pool base)
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-                        // the block's inputs: out of host memory once, into HBM for everybody (words first, then the sequence number)
-                        unsigned long long w[ZL_RT_CMD_WORDS];
-                        w[0] = (unsigned long long)(uint32_t)sh->nframes | ((unsigned long long)(uint32_t)sh->n_op_ranges << 32);
-                        w[1] = (unsigned long long)(uintptr_t)sh->ops; w[2] = (unsigned long long)(uintptr_t)sh->op_ranges; w[3] = sh->ctl_base;
-                        w[4] = sh->clock.current_usecs; w[5] = sh->clock.next_usecs; w[6] = sh->clock.playhead; w[7] = sh->clock.playhead_usecs;
-                        w[8] = sh->clock.subbeat_usecs; w[9] = sh->clock.usecs_per_frame;
-                        w[10] = (unsigned long long)(uint32_t)sh->n_clip_edits | ((unsigned long long)sh->fan_seq << 32); w[11] = (unsigned long long)(uintptr_t)sh->clip_edits;
-                        w[12] = (unsigned long long)(uintptr_t)sh->out_bus; w[13] = (unsigned long long)(uintptr_t)sh->out_fan;
-                        w[14] = (unsigned long long)sh->out_bus_stride; w[15] = (unsigned long long)sh->out_ch_stride;
-                        {
-                            static_assert(sizeof(sh->inline_edits) == ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS * 8, "inline edits are whole words");
-                            const unsigned long long *ie = reinterpret_cast<const unsigned long long *>(&sh->inline_edits[0]);
-#pragma unroll
-                            for (int i = 0; i < ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS; ++i) w[ZL_RT_CMD_FIXED + i] = ie[i];
-                        }
-#pragma unroll
-                        for (int i = 0; i < ZL_RT_CMD_WORDS; ++i) { s_cmd[1 + i] = w[i]; __hip_atomic_store(&dev->cmd[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        // (WIDE: published below, after the workgroup has copied the operation ranges)
+                        // (the host wrote the words, then cmd_seq with a release store.)  Narrow buses: the NUMBER goes out to the other
+                        // workgroups at once; each of them reads the words itself.  Wide buses: published below, with the words and the ranges
                         if (!WIDE) __hip_atomic_store(&dev->pub_seq, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_cmd[0] = q; go = 1;
                         break;
@@ -1298,12 +1278,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (;;) {
                     const unsigned long long q = __hip_atomic_load(&dev->pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (q == ~0ull) break;
-                    if (q != last) {
-#pragma unroll
-                        for (int i = 0; i < ZL_RT_CMD_WORDS; ++i) s_cmd[1 + i] = __hip_atomic_load(&dev->cmd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_cmd[0] = q; go = 1;
-                        break;
-                    }
+                    if (q != last) { s_cmd[0] = q; go = 1; break; }
                     if (WIDE) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);   // (a thousand pollers: longer naps)
                 }
             }
@@ -1311,6 +1286,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         __syncthreads();
         if (!s_go) break;
+        // ---- the cycle's command words, ONE WORD PER LANE (one trip, all words in flight together; a single lane's system-scope loads
+        //      would go out one after the other: 34 trips over PCIe): out of the mailbox in host memory (system scope, past the caches)
+        //      -- every workgroup of a narrow engine, workgroup 0 of a wide one, which also leaves them in HBM for the others
+        if (tid < ZL_RT_CMD_WORDS) {
+            unsigned long long wv;
+            if (!WIDE || z == 0) wv = __hip_atomic_load(&sh->cmd[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else                 wv = __hip_atomic_load(&dev->cmd[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (WIDE && z == 0) __hip_atomic_store(&dev->cmd[tid], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_cmd[1 + tid] = wv;
+        }
+        __syncthreads();
         last = s_cmd[0];
         if (A0.rt_stamps && z == 0 && tid == 0) sh->stamps[0] = __builtin_amdgcn_s_memrealtime();
         ZlBatch A = A0;
@@ -1329,14 +1315,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         A.bus_stride = (long long)s_cmd[15]; A.ch_stride = (long long)s_cmd[16];
         const uint32_t fan_seq = (uint32_t)(s_cmd[11] >> 32);
         if (fan_seq == 0u) A.fan = nullptr;
-        else if (tid == 0 && fan_seq != s_pass_seq) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        else if (tid < 64) {
+            // (wave 0 only: its lanes read the version before lane 0 writes it -- program order inside one wave; one word per lane, one trip)
+            const bool refresh = fan_seq != s_pass_seq;
             const int pb = (WIDE ? vbeg / A0.VPB : z);
             const uint32_t *src = reinterpret_cast<const uint32_t *>(A0.pass + pb);
             uint32_t *dst = reinterpret_cast<uint32_t *>(&s_pass);
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(ZlPassParams) / 4); ++i) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s_pass_seq = fan_seq;
+            if (refresh && tid < (int)(sizeof(ZlPassParams) / 4)) dst[tid] = __hip_atomic_load(src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (refresh && tid == 0) s_pass_seq = fan_seq;
         }
         A.pass_inline = 1;
         A.tile_accum = 1;                                          // this workgroup walks every frame tile of its block (below)
@@ -1447,11 +1433,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this bus's mix and reports (host memory), its levels (HBM)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (A0.rt_stamps && z == 0) sh->stamps[5] = __builtin_amdgcn_s_memrealtime();
-            const unsigned int old = __hip_atomic_fetch_add(&dev->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned int)W - 1u) {                     // the last workgroup: the block is complete
-                __hip_atomic_store(&dev->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&sh->done_seq, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!WIDE) {
+                // one workgroup per bus: each tells the host itself (the host waits for all of them) -- no counter round trip, no last-arrival store
+                __hip_atomic_store(&sh->wg_done[z], (uint32_t)last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                const unsigned int old = __hip_atomic_fetch_add(&dev->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned int)W - 1u) {                 // the last workgroup: the block is complete
+                    __hip_atomic_store(&dev->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&sh->done_seq, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
     }

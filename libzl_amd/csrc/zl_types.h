@@ -208,47 +208,45 @@ struct ZlBatchStats {
 };
 
 // Mailbox between zlhip_render and the resident real-time kernel (zl_k_rt_loop), in host memory mapped into the device.
-// The host fills in a block's inputs, then writes cmd_seq; the kernel renders the block, writes the mix and the reports into
-// host memory, then writes done_seq.  state: 0 not started, 1 resident, 2 left (stop request or idle timeout).
+// The host packs a cycle's inputs into `cmd` (8-byte words, the layout below), then writes cmd_seq; the kernel renders the cycle, writes
+// the mix and the reports into host memory and reports completion.  state: 0 not started, 1 resident, 2 left (stop request or idle timeout).
+//   Workgroup 0 alone polls cmd_seq; it republishes only the NUMBER in device memory, and every workgroup then reads the words itself,
+//   with system-scope loads (one trip over PCIe, all words in flight together, past the caches -- no fence, no L2 invalidation).
+//   Completion: one workgroup per bus (narrow buses) -- each writes its own word of wg_done, the host waits for all of them; no
+//   arrival counter, no last-arrival store.  One workgroup per voice (wide buses): the arrival counter and done_seq, as before.
+#define ZL_RT_INLINE_EDITS 2
+#define ZL_RT_EDIT_WORDS (1 + ZL_CLIP_HEAD_BYTES / 8)      // clip id + the head, in 8-byte words
+#define ZL_RT_CMD_FIXED 16                                 // the words in front of the inline knob edits
+#define ZL_RT_CMD_WORDS (ZL_RT_CMD_FIXED + ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS)
+#define ZL_RT_DONE_SLOTS 64                                // narrow buses: at most 64 resident workgroups (rt_eligible)
+// cmd[0] nframes | n_op_ranges << 32      [1] ops  [2] op_ranges (device views of the cycle's voice operations, mapped host memory)
+// cmd[3] ctl_base (base of this cycle's control-slot pool, zl_plan.h zl_ctl_alloc)        [4..9] ZlClock
+// cmd[10] n_clip_edits | fan_seq << 32     [11] clip_edits (the cycle's clip-parameter edits, mapped host memory)
+//         fan_seq: 0 = the cycle delivers the buses only; else it also delivers the JackPassthrough fan-out of every bus and this is the
+//         version of the parameter table (ZlBatch::pass, mapped host memory): a workgroup re-reads its bus's entry only when it moved
+// cmd[12] out_bus  [13] out_fan  [14] out_bus_stride  [15] out_ch_stride: where the cycle's rows go (device views) -- the engine's staging
+//         rows in mapped host memory or, when the caller's buffers are page-locked, straight into them: row of (bus, channel) =
+//         out_bus + bus * out_bus_stride + channel * out_ch_stride floats; the fan-out rows [B][6][nframes] at out_fan
+// cmd[16..] up to ZL_RT_INLINE_EDITS knob edits (clip id, then the 32 bytes in front of the slice table): a pan or volume knob turned while
+//         playing travels in the mailbox itself
 struct ZlRtShared {
     unsigned long long cmd_seq, done_seq;
     uint32_t state, stop;
-    int32_t  nframes, n_op_ranges;
-    const ZlVoiceOp   *ops;       // device views of the block's voice operations (mapped host memory)
-    const ZlOpRange   *op_ranges;
-    unsigned long long ctl_base;  // base of this cycle's control-slot pool (zl_plan.h zl_ctl_alloc)
-    ZlClock  clock;
-    unsigned long long stamps[8]; // s_memrealtime (100 MHz) at the kernel's stages of the last block (diagnostic)
-    const ZlClipEdit  *clip_edits;// the cycle's clip-parameter edits (mapped host memory), applied before the cycle is planned
-    // up to ZL_RT_INLINE_EDITS knob edits (the 32 bytes in front of the slice table) travel in the mailbox itself: workgroup 0
-    // reads them with the rest of the command -- no extra trip over PCIe for a pan or volume knob turned while playing
-    struct { int32_t clip, pad; uint32_t head[ZL_CLIP_HEAD_BYTES / 4]; } inline_edits[2];
-    int32_t  n_clip_edits;
     uint32_t yield;               // another thread of the process is about to make a device-synchronising HIP call (hipFree, ...):
                                   // leave after the cycle in flight (zl_engine.cpp, ZlQuiesce)
-    // where this cycle's rows go (device views): the engine's own staging rows in mapped host memory, or -- when the caller's buffers
-    // are page-locked -- straight into them (no copy on the host afterwards).  Row of (bus, channel): out_bus + bus * out_bus_stride +
-    // channel * out_ch_stride floats; the fan-out rows [B][6][nframes] at out_fan
-    float   *out_bus, *out_fan;
-    long long out_bus_stride, out_ch_stride;
-    uint32_t fan_seq;             // 0: this cycle delivers the buses only.  Else: it also delivers the JackPassthrough fan-out of every bus
-                                  // (ZlBatch::fan, mapped host memory) and this is the version of the parameter table (ZlBatch::pass, mapped
-                                  // host memory too): a workgroup re-reads its bus's entry only when the version moved (a knob was turned)
     uint32_t pad;
+    unsigned long long stamps[8]; // s_memrealtime (100 MHz) at the kernel's stages of the last block (diagnostic)
+    unsigned long long cmd[ZL_RT_CMD_WORDS];
+    uint32_t wg_done[ZL_RT_DONE_SLOTS];   // narrow buses: workgroup z's last finished cycle (low 32 bits of its sequence number)
 };
 
 // Device side of the resident kernel: workgroup 0 watches the mailbox and republishes every block in HBM for the other
 // workgroups (agent-scope atomics: eight-byte words, visible across XCDs without cache fences); `arrive` counts the workgroups
 // that have finished the block.
-#define ZL_RT_INLINE_EDITS 2
-#define ZL_RT_EDIT_WORDS (1 + ZL_CLIP_HEAD_BYTES / 8)      // clip id + the head, in 8-byte words
-#define ZL_RT_CMD_FIXED 16                                 // the words in front of the inline knob edits
-#define ZL_RT_CMD_WORDS (ZL_RT_CMD_FIXED + ZL_RT_INLINE_EDITS * ZL_RT_EDIT_WORDS)
 #define ZL_RT_MAX_BUSES 256
 struct ZlRtDev {
     unsigned long long pub_seq;                  // the block being rendered (~0ull: leave)
-    unsigned long long cmd[ZL_RT_CMD_WORDS];     // nframes | n_op_ranges << 32, ops, op_ranges, ctl_base, ZlClock (6 words), n_clip_edits | fan_seq << 32, clip_edits,
-                                                 // out_bus, out_fan, out_bus_stride, out_ch_stride, the inline knob edits
+    unsigned long long cmd[ZL_RT_CMD_WORDS];     // wide buses: workgroup 0's copy of the mailbox's words (a thousand readers would queue on PCIe)
     unsigned int arrive, pad;
     unsigned int bus_arrive[ZL_RT_MAX_BUSES];    // wide buses (one workgroup per voice): the voices of a bus that have written their partial mix
 };

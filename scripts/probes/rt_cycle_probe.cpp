@@ -21,7 +21,7 @@
 
 using clk = std::chrono::steady_clock;
 
-struct Row { int V, B, N; bool resident, paced, fan; int hogs; bool pinned = false; };   // pinned: the caller's buffers are page-locked (the kernels write them directly)   // hogs: busy threads next to the cycle thread (more than the box's CPU quota: the attribution's known answer)
+struct Row { int V, B, N; bool resident, paced, fan; int hogs; bool pinned = false; bool idle = false; };   // idle: no voice plays -- the cycle's floor (signalling only)   // pinned: the caller's buffers are page-locked (the kernels write them directly)   // hogs: busy threads next to the cycle thread (more than the box's CPU quota: the attribution's known answer)
 
 static int run(const Row &r, int cycles)
 {
@@ -47,7 +47,7 @@ static int run(const Row &r, int cycles)
         zlhip_clip_command c;
         zlhip_clip_command_clear(&c);
         c.clip = id; c.midi_note = 60; c.midi_channel = v / vpb - 2; c.start_playback = 1; c.looping = 1; c.change_volume = 1; c.volume = 0.5f;
-        if (zlhip_start_voice(e, v / vpb, v % vpb, &c, 0) != 1) { std::fprintf(stderr, "start failed\n"); return 1; }
+        if (!r.idle && zlhip_start_voice(e, v / vpb, v % vpb, &c, 0) != 1) { std::fprintf(stderr, "start failed\n"); return 1; }
     }
     std::vector<float> Lv((size_t)r.B * r.N), Rv((size_t)r.B * r.N), fanv(r.fan ? (size_t)r.B * 6 * r.N : 0);
     float *L = Lv.data(), *R = Rv.data(), *fan = fanv.data();
@@ -64,6 +64,7 @@ static int run(const Row &r, int cycles)
     us.reserve((size_t)cycles);
     struct Slow { int k; double harness; zlhip_rt_cycle_trace t; };
     std::vector<Slow> slow;
+    double sumBefore = 0.0, sumWait = 0.0, sumAfter = 0.0;
     std::atomic<bool> stopHogs{false};
     std::vector<std::thread> hogs;
     for (int i = 0; i < r.hogs; ++i) hogs.emplace_back([&stopHogs] { volatile unsigned long long x = 0; while (!stopHogs.load(std::memory_order_relaxed)) x = x + 1; });
@@ -80,6 +81,7 @@ static int run(const Row &r, int cycles)
         if (k < 50) continue;
         const double d = std::chrono::duration<double, std::micro>(t1 - t0).count();
         us.push_back(d);
+        { zlhip_rt_cycle_trace t; if (zlhip_rt_last_cycle(e, &t) == ZLHIP_OK) { sumBefore += t.before_post_us; sumWait += t.wait_us; sumAfter += t.after_us; } }
         if (d > 1000.0) { Slow s; s.k = k; s.harness = d; zlhip_rt_last_cycle(e, &s.t); slow.push_back(s); }
     }
     stopHogs.store(true);
@@ -89,9 +91,11 @@ static int run(const Row &r, int cycles)
     std::vector<double> sorted = us;
     std::sort(sorted.begin(), sorted.end());
     std::printf("V=%4d B=%3d N=%4d %s %s %s: p50 %6.1f us  p99 %6.1f us  p99.9 %6.1f us  max %8.1f us  (period %5.0f us, %d cycles, resident launches %llu, cycles over 1 ms: %zu)\n",
-                r.V, r.B, r.N, r.resident ? "resident" : "launched", r.paced ? "paced    " : "back2back", r.fan ? (r.pinned ? "fan, pinned" : "fan-out    ") : (r.hogs ? "+hogs      " : (r.pinned ? "pinned     " : "           ")),
+                r.V, r.B, r.N, r.resident ? "resident" : "launched", r.paced ? "paced    " : "back2back", r.fan ? (r.pinned ? "fan, pinned" : "fan-out    ") : (r.hogs ? "+hogs      " : (r.idle ? "idle voices" : (r.pinned ? "pinned     " : "           "))),
                 sorted[sorted.size() / 2], sorted[(size_t)((double)sorted.size() * 0.99)], sorted[(size_t)((double)sorted.size() * 0.999)], sorted.back(),
                 1e6 * r.N / fs, cycles, (unsigned long long)starts, slow.size());
+    if (std::getenv("ZL_PROBE_BREAKDOWN"))
+        std::printf("    mean inside the engine: host before the post %.2f us, wait for the device %.2f us, host after %.2f us\n", sumBefore / us.size(), sumWait / us.size(), sumAfter / us.size());
     for (size_t si = 0; si < slow.size(); ++si) {
         const Slow &s = slow[si];
         if (si == 8) { std::printf("    ... and %zu more\n", slow.size() - 8); break; }
@@ -130,6 +134,8 @@ int main(int argc, char **argv)
         Row b{96, 12, 256, res == 1, false, true, 0}; b.pinned = true; rows.push_back(b);
         Row c{96, 12, 1024, res == 1, false, false, 0}; c.pinned = true; rows.push_back(c);
     }
+    // the floor: no voice plays -- what a cycle costs in signalling alone (mailbox, hand-off between workgroups, completion)
+    for (int res = 0; res < 2; ++res) { Row f{96, 12, 256, res == 1, false, false, 0}; f.idle = true; f.pinned = true; rows.push_back(f); }
     for (int res = 0; res < 2; ++res) {
         rows.push_back({96, 12, 256, res == 1, true, false, 0});       // paced: one cycle per JACK period, as JACK runs it (the GPU idles in between)
         rows.push_back({96, 12, 256, res == 1, true, true, 0});

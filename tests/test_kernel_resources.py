@@ -27,9 +27,11 @@ def test_resident_kernel_keeps_its_state_in_registers(built):
     assert len(rt) == 16                                           # 8 modes x narrow / wide
     for n, r in rt.items():
         assert r["scratch"] <= 64, (n, r)                          # (56 bytes: a small local array; 1 KB meant calls and +13 us per cycle)
-        # (held to two waves per SIMD -- amdgpu_waves_per_eu(2, 2): the capacity rule counts on two resident workgroups per CU; under that
-        # budget the Hermite + FIX_DELAY wide variants park two registers in 12 bytes of scratch, everything else none)
-        assert r["vgpr_spill"] <= 2 and r["waves"] == 2, (n, r)
+        # (held to two waves per SIMD -- amdgpu_waves_per_eu(2, 2): the capacity rule counts on two resident workgroups per CU.  Under that
+        # budget the one-workgroup-per-bus variants -- the reference's 12 x 8 -- keep everything in registers; the one-workgroup-per-voice
+        # variants of wide buses park two to four registers in 12-20 bytes of scratch)
+        wide = "ELb1E" in n
+        assert r["vgpr_spill"] <= (4 if wide else 0) and r["waves"] == 2, (n, r)
 
 
 def test_render_kernels_do_not_spill_where_the_design_says_so(built):

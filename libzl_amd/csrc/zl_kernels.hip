@@ -167,10 +167,13 @@ __global__ void __launch_bounds__(64) zl_k1c_assemble(const ZlBatch A, int block
 // final coalesced store.
 static __device__ __forceinline__ int zl_sample_to_peak_int(float x)
 {
-    const float v = fabsf(131072.0f * x);                          // AudioLevels.cpp:356,367
-    if (!(v == v)) return 0;
-    if (v >= 2147483648.0f) return 0x7fffffff;
-    return (int)v;
+    // (int)fabsf(131072.f * x), AudioLevels.cpp:356,367, with the oracle's definition of the cases C leaves open: NaN -> 0, 2^31 and above
+    // (and infinity) -> INT_MAX.  That is what v_cvt_i32_f32 does by itself (truncation, saturation, NaN -> 0): one instruction with the
+    // |.| source modifier instead of two compares and three exec-masked branches per sample
+    const float v = 131072.0f * x;
+    int r;
+    asm("v_cvt_i32_f32_e64 %0, |%1|" : "=v"(r) : "v"(v));
+    return r;
 }
 
 // Wavefront reductions on the VALU (DPP row shifts / broadcasts, no LDS round trips): quad permutes, row_shr 4 and 8
@@ -201,12 +204,33 @@ static __device__ __forceinline__ float zl_wave_sum(float x)
     return __int_as_float(__builtin_amdgcn_readlane(v, 63));
 }
 
-static __device__ __forceinline__ float zl_wave_max(float x)
+// the four reductions of one bus's fused level scan (two integer peaks, two sums of squares) in ONE instruction sequence: the same
+// DPP trees as zl_wave_max_nonneg / zl_wave_sum -- same operands, same order, same bits -- one instruction per step and value (the row
+// broadcasts write their rows in place), the four chains interleaved so that no step waits out the DPP read-after-write hazard of its
+// own predecessor (2 wait states: three other instructions stand between).  What the compiler makes of the four separate calls is
+// ~50 VALU + ~20 s_nop per bus and wave; this is 24 + 4 v_readlane.  (s_nop 4 in front: 5 wait states cover every hazard a DPP
+// read can have with the code before the block, which the compiler's hazard recogniser does not look into.)  All 64 lanes active.
+#define ZL_DPP4(ctrl) "v_max_i32_dpp %0, %0, %0 " ctrl "\n\tv_max_i32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"
+static __device__ __forceinline__ void zl_wave_levels4(int &pkL, int &pkR, float &sqL, float &sqR)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
-    return x;
+    int a = pkL, b = pkR, ra, rb;
+    float c = sqL, d = sqR, rc, rd;
+    asm("s_nop 4\n\t"
+        ZL_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        ZL_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        ZL_DPP4("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        ZL_DPP4("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        ZL_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        ZL_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 0\n\t"
+        "v_readlane_b32 %4, %0, 63\n\tv_readlane_b32 %5, %1, 63\n\tv_readlane_b32 %6, %2, 63\n\tv_readlane_b32 %7, %3, 63"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=s"(ra), "=s"(rb), "=s"(rc), "=s"(rd));
+    pkL = ra; pkR = rb; sqL = rc; sqR = rd;
 }
+#undef ZL_DPP4
+
+// maximum of a wave's non-negative floats (they order like their bit patterns), wave-uniform
+static __device__ __forceinline__ float zl_wave_max(float x) { return __int_as_float(zl_wave_max_nonneg(__float_as_int(x))); }
 
 // 16-byte gather of the two interpolation taps of both channels (interleaved stereo), 8-byte aligned
 typedef float zl_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
@@ -915,10 +939,10 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
         // ---- fused AudioLevels block scan (AudioLevels.cpp:361-383) when this workgroup holds the final mix of its
         //      whole block(s) (no mix groups, one frame tile): saves the K3 launch and its re-read of the bus
         if (A.groups == 1 && (gdx == 1 || A.tile_accum) && A.levels) {
-            int pkL = written ? zl_sample_to_peak_int(accL) : 0, pkR = written ? zl_sample_to_peak_int(accR) : 0;
-            float sqL = written ? accL * accL : 0.0f, sqR = written ? accR * accR : 0.0f;
-            pkL = zl_wave_max_nonneg(pkL); pkR = zl_wave_max_nonneg(pkR);
-            sqL = zl_wave_sum(sqL); sqR = zl_wave_sum(sqR);
+            const float aL = written ? accL : 0.0f, aR = written ? accR : 0.0f;      // (a lane without a frame of its own scans a zero)
+            int pkL = zl_sample_to_peak_int(aL), pkR = zl_sample_to_peak_int(aR);
+            float sqL = aL * aL, sqR = aR * aR;
+            zl_wave_levels4(pkL, pkR, sqL, sqR);
             // each wave leaves its partial result of this bus; they are combined once, after the last bus (no barrier here)
             const int w = threadIdx.x >> 6, bi = bus - bus0;
             if ((threadIdx.x & 63) == 0) { s_pk[0][bi][w] = pkL; s_pk[1][bi][w] = pkR; s_sq[0][bi][w] = sqL; s_sq[1][bi][w] = sqR; }

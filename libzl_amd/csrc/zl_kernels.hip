@@ -250,6 +250,11 @@ typedef float zl_f2a4 __attribute__((ext_vector_type(2), aligned(4)));
 // 96 registers instead of 80 and the kernel gains 0.5 % (headline) to 2 % (64-voice engines) -- profiles/round3_k2_roll_ab.txt
 #define ZL_K2_WAVES_LINEAR 5
 #endif
+#ifndef ZL_K2_PREFETCH_BUS
+// narrow buses: issue the next bus's gathers before the finished bus's epilogue (1).  Measured and NOT shipped: 1-2 % slower than 0 on 64- / 96-voice
+// engines (profiles/round4_levels_epilogue_ab.txt) -- the epilogue's stores share vmcnt with the gathers, so the first mix waits for all of them
+#define ZL_K2_PREFETCH_BUS 0
+#endif
 #ifndef ZL_K2_MINWAVES
 #define ZL_K2_MINWAVES 1      // __launch_bounds__ minimum waves per SIMD (caps the VGPR budget)
 #endif
@@ -316,17 +321,18 @@ static __device__ __forceinline__ zl_f2 zl_mix_frame_pk(zl_f2 xm, zl_f2 x0, zl_f
 #define ZL_K2_PK_HERMITE 1
 #endif
 
+// the gathers of one simple chunk, in flight: issued by zl_k2_simple_issue, consumed by zl_k2_simple_mix
+template <bool HERM, int U> struct ZlSimpleTaps { zl_f4a4 d[U], e[HERM ? U : 1]; float alpha[U]; int widem; };
+
+// first half of a simple chunk: the U positions and the U gathers, issued back to back.
 // INT ("interior"): every frame of the block lies inside the source for every voice of the chunk (checked per voice at
 // staging from the block's first and last position) -- no bounds guard, no tap selects, no read of the duration.
 template <uint32_t MODE, bool SEG2, bool UNIT, bool INT, int U>
-static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
-                                                           int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
+static __device__ __forceinline__ void zl_k2_simple_issue(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
+                                                           int c0, int f, double fd, ZlSimpleTaps<(MODE & ZL_MODE_HERMITE) != 0, U> &T)
 {
     constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
-    constexpr bool PK = HERM ? (ZL_K2_PK_HERMITE != 0) : (ZL_K2_PK_LINEAR != 0);
-    zl_f4a4 d[U], e[HERM ? U : 1];
-    float alpha[U];
-    int   widem = 0;
+    T.widem = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
@@ -342,10 +348,10 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
         if (UNIT) {
             // step == 1 inside an exact run: every frame has the fractional part of P0 and the integer part moves by f
             pos = s_unit[i].ipos + f;
-            alpha[u] = s_unit[i].alpha;
+            T.alpha[u] = s_unit[i].alpha;
         } else {
             pos = (int)P;
-            alpha[u] = (float)__builtin_amdgcn_fract(P);
+            T.alpha[u] = (float)__builtin_amdgcn_fract(P);
         }
         const int dur = INT ? 0 : s_vc[i].sample_duration;
         const bool inb = INT || dur > pos;                        // :204 guard (Q5)
@@ -362,23 +368,33 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
             p -= wide ? 1 : 0;
             // (uniform 64-bit base + 32-bit byte offset: the scalar-base form of global_load, no 64-bit VALU address)
             const uint32_t ob = (uint32_t)p << 3;
-            d[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ob);
-            e[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ob + 16u);   // inside the arena padding at the end
-            widem |= wide ? (1 << u) : 0;
+            T.d[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ob);
+            T.e[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ob + 16u);   // inside the arena padding at the end
+            T.widem |= wide ? (1 << u) : 0;
         } else {
-            d[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ((uint32_t)p << 3));
+            T.d[u] = *reinterpret_cast<const zl_f4a4 *>(reinterpret_cast<const char *>(src) + ((uint32_t)p << 3));
         }
     }
+}
+
+// second half: the voices mixed and accumulated in voice order
+template <uint32_t MODE, bool INT, int U>
+static __device__ __forceinline__ void zl_k2_simple_mix(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
+                                                         int c0, int vfirst, bool wantPeak, const ZlSimpleTaps<(MODE & ZL_MODE_HERMITE) != 0, U> &T,
+                                                         float &accL, float &accR)
+{
+    constexpr bool HERM = (MODE & ZL_MODE_HERMITE) != 0;
+    constexpr bool PK = HERM ? (ZL_K2_PK_HERMITE != 0) : (ZL_K2_PK_LINEAR != 0);
     zl_f2 acc = {accL, accR};
     // every lane of the wave has all four Hermite taps inside its source (true except in the blocks at a loop's ends):
     // the wave-uniform fast form needs no tap selects and no linear alternative
-    const bool allWide = HERM && PK && (INT || __all(widem == (1 << U) - 1));
+    const bool allWide = HERM && PK && (INT || __all(T.widem == (1 << U) - 1));
     if (allWide) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = c0 + u;
-            const zl_f2 o = zl_mix_frame_pk<MODE>((zl_f2){d[u].x, d[u].y}, (zl_f2){d[u].z, d[u].w}, (zl_f2){e[HERM ? u : 0].x, e[HERM ? u : 0].y},
-                                                  (zl_f2){e[HERM ? u : 0].z, e[HERM ? u : 0].w}, alpha[u], true, true,
+            const zl_f2 o = zl_mix_frame_pk<MODE>((zl_f2){T.d[u].x, T.d[u].y}, (zl_f2){T.d[u].z, T.d[u].w}, (zl_f2){T.e[HERM ? u : 0].x, T.e[HERM ? u : 0].y},
+                                                  (zl_f2){T.e[HERM ? u : 0].z, T.e[HERM ? u : 0].w}, T.alpha[u], true, true,
                                                   (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
                                                   (zl_f2){s_vc[i].lpan, s_vc[i].rpan}, (zl_f2){s_unit[i].gpl, s_unit[i].gpr});
             acc += o;
@@ -395,20 +411,20 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = c0 + u;
-        const bool wide = INT || ((widem >> u) & 1);
+        const bool wide = INT || ((T.widem >> u) & 1);
         float l, r;
         if (PK) {
             zl_f2 xm, x0, x1, x2;
             if (HERM) {
-                xm = (zl_f2){d[u].x, d[u].y};
-                x0 = wide ? (zl_f2){d[u].z, d[u].w} : (zl_f2){d[u].x, d[u].y};
-                x1 = wide ? (zl_f2){e[u].x, e[u].y} : (zl_f2){d[u].z, d[u].w};
-                x2 = (zl_f2){e[u].z, e[u].w};
+                xm = (zl_f2){T.d[u].x, T.d[u].y};
+                x0 = wide ? (zl_f2){T.d[u].z, T.d[u].w} : (zl_f2){T.d[u].x, T.d[u].y};
+                x1 = wide ? (zl_f2){T.e[u].x, T.e[u].y} : (zl_f2){T.d[u].z, T.d[u].w};
+                x2 = (zl_f2){T.e[u].z, T.e[u].w};
             } else {
-                x0 = (zl_f2){d[u].x, d[u].y}; x1 = (zl_f2){d[u].z, d[u].w};
+                x0 = (zl_f2){T.d[u].x, T.d[u].y}; x1 = (zl_f2){T.d[u].z, T.d[u].w};
                 xm = x0; x2 = x1;
             }
-            const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, alpha[u], true, wide,
+            const zl_f2 o = zl_mix_frame_pk<MODE>(xm, x0, x1, x2, T.alpha[u], true, wide,
                                                   (zl_f2){s_vc[i].lgain, s_vc[i].rgain}, s_plan[i].env, s_vc[i].clip_volume,
                                                   (zl_f2){s_vc[i].lpan, s_vc[i].rpan}, (zl_f2){s_unit[i].gpl, s_unit[i].gpr});
             acc += o;                                             // :218-221 (index shift applied at the store)
@@ -416,15 +432,15 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
         } else {
             ZlTaps t;
             if (HERM) {
-                t.xml = d[u].x; t.xmr = d[u].y;
-                t.x0l = wide ? d[u].z : d[u].x; t.x0r = wide ? d[u].w : d[u].y;
-                t.x1l = wide ? e[u].x : d[u].z; t.x1r = wide ? e[u].y : d[u].w;
-                t.x2l = e[u].z; t.x2r = e[u].w;
+                t.xml = T.d[u].x; t.xmr = T.d[u].y;
+                t.x0l = wide ? T.d[u].z : T.d[u].x; t.x0r = wide ? T.d[u].w : T.d[u].y;
+                t.x1l = wide ? T.e[u].x : T.d[u].z; t.x1r = wide ? T.e[u].y : T.d[u].w;
+                t.x2l = T.e[u].z; t.x2r = T.e[u].w;
             } else {
-                t.x0l = d[u].x; t.x0r = d[u].y; t.x1l = d[u].z; t.x1r = d[u].w;
+                t.x0l = T.d[u].x; t.x0r = T.d[u].y; t.x1l = T.d[u].z; t.x1r = T.d[u].w;
                 t.xml = t.xmr = t.x2l = t.x2r = 0.0f;
             }
-            zl_mix_frame<MODE>(t, alpha[u], true, wide, true, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env,
+            zl_mix_frame<MODE>(t, T.alpha[u], true, wide, true, s_vc[i].lgain, s_vc[i].rgain, s_plan[i].env,
                                s_vc[i].clip_volume, s_vc[i].lpan, s_vc[i].rpan, l, r);
             accL += l; accR += r;                                 // :218-221 (index shift applied at the store)
         }
@@ -436,6 +452,15 @@ static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, cons
         }
     }
     if (PK) { accL = acc.x; accR = acc.y; }
+}
+
+template <uint32_t MODE, bool SEG2, bool UNIT, bool INT, int U>
+static __device__ __forceinline__ void zl_k2_chunk_simple(const ZlBatch &A, const ZlBlockPlan *s_plan, const ZlVoiceConst *s_vc, const ZlUnit *s_unit,
+                                                           int c0, int vfirst, int f, double fd, bool wantPeak, float &accL, float &accR)
+{
+    ZlSimpleTaps<(MODE & ZL_MODE_HERMITE) != 0, U> T;
+    zl_k2_simple_issue<MODE, SEG2, UNIT, INT, U>(A, s_plan, s_vc, s_unit, c0, f, fd, T);
+    zl_k2_simple_mix<MODE, INT, U>(A, s_plan, s_vc, s_unit, c0, vfirst, wantPeak, T, accL, accR);
 }
 
 // UNIT + INT chunks with SHARED taps (ZL_K2_UNIT_SHARE=1): at the playback rate inside an exact run, lane f + 1's first tap IS lane
@@ -979,6 +1004,8 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
     };
 
     int vbase = v0;                                               // first voice of the staging pass under way
+    // gathers issued ahead of a bus's epilogue (linear modes; with four taps they would be 64 registers)
+    constexpr bool PF = !ST && !(MODE & ZL_MODE_HERMITE) && ZL_K2_PREFETCH_BUS;
     // after a chunk of U voices: if it held the last voice of a narrow bus (VPB is a multiple of the chunk size there), write that
     // bus and start the next one
     auto chunk_end = [&](int c) {
@@ -1191,6 +1218,21 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
                     if (cc & 2) zl_k2_chunk<MODE, true, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, fc, wantPeak, accL, accR);
                     else        zl_k2_chunk<MODE, false, H>(A, s_plan, s_vc, s_cls, c0 + h, pbase, vb, fc, wantPeak, accL, accR);
                 }
+            }
+            // narrow buses: the chunk that ends a bus is followed by that bus's epilogue (store, level scan: ~100 instructions in a
+            // dependent chain).  The NEXT bus's gathers go out first -- they travel while the epilogue runs -- when its first chunk is
+            // of the steady-state kind (stereo, interior, one segment); with the reference's 8 voices per bus this inner loop walks
+            // all the workgroup's buses.  (The taps in flight live only inside this loop: no register is held for them elsewhere.)
+            while (PF && NB > 1 && vbase + c0 + U == busEnd && c0 + U < nv) {
+                const int nc = __builtin_amdgcn_readfirstlane(s_chunk[c0 / U + 1]);
+                const bool unit = (nc & 124) == 100;
+                if (!unit && (nc & 92) != 68) break;
+                ZlSimpleTaps<(MODE & ZL_MODE_HERMITE) != 0, U> pf;
+                if (unit) zl_k2_simple_issue<MODE, false, true, true, U>(A, s_plan, s_vc, s_unit, c0 + U, fc, fd, pf);
+                else      zl_k2_simple_issue<MODE, false, false, true, U>(A, s_plan, s_vc, s_unit, c0 + U, fc, fd, pf);
+                chunk_end(c0);
+                c0 += U;
+                zl_k2_simple_mix<MODE, true, U>(A, s_plan, s_vc, s_unit, c0, vb, wantPeak, pf, accL, accR);
             }
             chunk_end(c0);
             c0 += U;

@@ -1032,7 +1032,35 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
             vc.lgain = vc.rgain = vc.clip_volume = vc.lpan = vc.rpan = vc.env = 0.0f; vc.pad[0] = vc.pad[1] = 0;
             if (i < nv) {
                 vc = A.vconst[vb + i];                             // K1 leaves a neutral record for voices that do not play
-                if (kk < A.K) pl = zl_plan_lookup(A, kk, vb + i, vc.env);   // implied by a run, explicit, or idle
+                if (kk < A.K) {
+                    // zl_plan_lookup (implied by a run, explicit, or idle) with the run list AND the explicit record's header and first segment
+                    // fetched together: ONE memory round trip per prologue where "look at the runs, then fetch the record" is two in a row (most
+                    // blocks of a long window are explicit: a voice has ZL_MAXRUNS inline runs, a 2 s loop in a 43 s window restarts twenty times).
+                    // The record of a block that a run covers is never written: its bits lose every select below.
+                    const ZlRunList *rl = &A.runs[vb + i];
+                    const size_t pidx = (size_t)kk * V + (size_t)(vb + i);
+                    const ZlPlanHdr ph = A.plan_hdr[pidx];
+                    const ZlPlanSeg0 ps = A.plan_seg0[pidx];
+                    const int rn = rl->n, dead = rl->dead_from;
+                    bool cov = false; double rP = 0.0, rstep = 0.0; int rk0 = 0;
+#pragma unroll
+                    for (int j = 0; j < ZL_MAXRUNS; ++j) {
+                        const ZlRun r = rl->r[j];
+                        const bool hit = !cov && j < rn && kk >= r.k0 && kk < r.k1;
+                        rP = hit ? r.P : rP; rstep = hit ? r.step : rstep; rk0 = hit ? r.k0 : rk0;
+                        cov = cov || hit;
+                    }
+                    if (kk < dead) {
+                        pl.flags = cov ? (int32_t)ZL_PLAN_ACTIVE : ph.flags; pl.n_active = cov ? N : ph.n_active; pl.nseg = cov ? 1 : ph.nseg;
+                        pl.env = cov ? vc.env : ph.env;
+                        pl.P0 = cov ? fma((double)((kk - rk0) * N), rstep, rP) : ps.P0;   // exact: inside the linear run
+                        pl.step = cov ? rstep : ps.step;
+                        if (!cov && ((((ph.nseg >= 2 || (ph.flags & ZL_PLAN_ENV)) && !(ph.flags & ZL_PLAN_SLOW)) || (ph.flags & (ZL_PLAN_NOSLOT_SIM | ZL_PLAN_NOSLOT_EXPAND))))) {
+                            const ZlPlanSeg1 s1 = A.plan_seg1[pidx];
+                            pl.P1 = s1.P1; pl.step1 = s1.step1; pl.n1 = s1.n1; pl.estep0 = s1.estep0; pl.E1 = s1.E1; pl.estep1 = s1.estep1;
+                        }
+                    }
+                }
             }
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
             // 4 = "simple": whole block, sustain (and no debug trace); 8 = it has a second position segment; 16 = mono source

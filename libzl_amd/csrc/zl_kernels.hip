@@ -1022,6 +1022,10 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
         //      need at once (voice constants, run list; plan header + first segment when no run covers the block), so
         //      the prologue is one memory round trip (two for blocks with a second segment) and one barrier
         __syncthreads();
+#ifdef ZL_STAMPS
+        const unsigned long long zl_ta = __builtin_amdgcn_s_memrealtime();
+        unsigned long long zl_tb = zl_ta;
+#endif
         for (int idx = threadIdx.x; idx < BPW * CH; idx += blockDim.x) {   // whole waves: blockDim.x is a multiple of 64
             const int b = idx / CH, i = idx - b * CH;
             const int kk = yb * BPW + b;
@@ -1062,6 +1066,10 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
                     }
                 }
             }
+#ifdef ZL_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            zl_tb = __builtin_amdgcn_s_memrealtime();
+#endif
             int cls = (pl.flags & ZL_PLAN_ACTIVE) ? (1 | ((pl.flags & ZL_PLAN_SLOW) ? 2 : 0)) : 0;
             // 4 = "simple": whole block, sustain (and no debug trace); 8 = it has a second position segment; 16 = mono source
             const float gprod = vc.lgain * vc.rgain * vc.clip_volume * pl.env;     // finite iff every factor is (or one is 0 * inf = NaN)
@@ -1121,6 +1129,7 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
         __syncthreads();
 #ifdef ZL_STAMPS
         zl_t1 = __builtin_amdgcn_s_memrealtime();
+        zl_paths = ((zl_ta - zl_t0) & 0xffffull) | (((zl_tb - zl_t0) & 0xffffull) << 16);   // prologue break-down: first barrier, loads landed (10 ns ticks)
 #endif
         const size_t pbase = (size_t)k * V + vb;
         if (ST) {
@@ -1221,9 +1230,6 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
         } else
         for (int c0 = 0; c0 < nv; ) {
             const int cc = __builtin_amdgcn_readfirstlane(s_chunk[c0 / U]);
-#ifdef ZL_STAMPS
-            if (cc) zl_paths += ((cc & 12) == 4) ? 1ull : (cc & 4) ? (1ull << 16) : (cc & 2) ? (1ull << 48) : (1ull << 32);
-#endif
             if (cc == 0) {                                        // nobody in this chunk plays (SamplerSynth.cpp:137)
             } else if ((cc & 124) == 100) {
                 // (the shared-tap form needs a wave's lanes to be consecutive frames of one block: true for every launch shape --

@@ -39,10 +39,12 @@ st = tr[: nwg * 8].view(np.uint64).reshape(nwg, 4)
 ok = st[:, 0] != np.uint64(0xffffffffffffffff)
 st = st[ok]
 t0, t1, t2 = st[:, 0].astype(np.float64), st[:, 1].astype(np.float64), st[:, 2].astype(np.float64)
+ta, tb = (st[:, 3] & np.uint64(0xffff)).astype(np.float64) * 10e-3, ((st[:, 3] >> np.uint64(16)) & np.uint64(0xffff)).astype(np.float64) * 10e-3
 base = t0.min()
 dur, stage = (t2 - t0) * 10e-3, (t1 - t0) * 10e-3          # 100 MHz ticks -> us
 print(f"V={V} B={B} blocks={KB} source rate {SR or fs:.0f} notes {NOTES}: K2 {t.render_ms * 1e3:.1f} us by its events, {(t2.max() - base) * 10e-3:.1f} us by the stamps; {len(st)} of {nwg} workgroups stamped")
 print(f"workgroup lifetime us: mean {dur.mean():.2f} p50 {np.percentile(dur, 50):.2f} p90 {np.percentile(dur, 90):.2f} p99 {np.percentile(dur, 99):.2f}")
 print(f"staging prologue us:   mean {stage.mean():.2f} p50 {np.percentile(stage, 50):.2f} p99 {np.percentile(stage, 99):.2f}  = {100 * stage.sum() / dur.sum():.1f} % of the lifetimes")
+print(f"  of it: up to the first barrier {ta.mean():.2f} us, loads landed at {tb.mean():.2f} us (p99 {np.percentile(tb, 99):.2f}), classification + LDS + second barrier end at {stage.mean():.2f} us")
 edges = np.linspace(0, (t2.max() - base), 17)
 print("resident workgroups at 16 instants:", [int(((t0 <= (a + b) / 2 + base) & (t2 > (a + b) / 2 + base)).sum()) for a, b in zip(edges[:-1], edges[1:])])

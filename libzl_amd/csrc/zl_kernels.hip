@@ -1021,7 +1021,10 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
         // ---- stage the per-voice records of this pass in LDS: one lane per (block, voice) issues every load it may
         //      need at once (voice constants, run list; plan header + first segment when no run covers the block), so
         //      the prologue is one memory round trip (two for blocks with a second segment) and one barrier
-        __syncthreads();
+        // (the barrier keeps a pass from overwriting records that another wave still reads: nothing to wait for before the FIRST pass of a
+        // batch workgroup -- its first wave issues the staging loads while the others are still being launched; the resident kernel runs
+        // this body once per cycle and keeps the barrier)
+        if (!REPORTS || vb != v0) __syncthreads();
 #ifdef ZL_STAMPS
         const unsigned long long zl_ta = __builtin_amdgcn_s_memrealtime();
         unsigned long long zl_tb = zl_ta;

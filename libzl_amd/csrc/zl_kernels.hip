@@ -869,8 +869,15 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
     // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin in launch order, so launch slot y runs on XCD
     // y % 8; giving XCD x the contiguous blocks [x * KY / 8, (x + 1) * KY / 8) lets neighbouring blocks (which share the
     // cache line at their common edge of every source) meet in the same L2
-    const int ky = (int)gdy, xq = ky >> 3, xr = ky & 7, xx = (int)(by & 7u);
-    const int yb = xx * xq + (xx < xr ? xx : xr) + (int)(by >> 3);      // a bijection of [0, ky) for every ky
+    // Split tail (narrow buses, set by zl_launch_render): a launch ends when its last workgroups do, and those start one workgroup lifetime before
+    // the end whatever the machine does meanwhile -- the launch's last blocks are therefore rendered by tail_split workgroups each, a few buses per
+    // workgroup: a quarter of the lifetime, a quarter of the time the machine drains.  Slots [0, tail_from) are the blocks in front of them.
+    const bool tailed = BPW == 1 && !ST && REPORTS && A.tail_from > 0;
+    const bool inTail = tailed && (int)by >= A.tail_from;
+    const int tj = inTail ? (int)by - A.tail_from : 0;
+    const int ky = tailed ? A.tail_from : (int)gdy, xq = ky >> 3, xr = ky & 7, xx = (int)(by & 7u);
+    const int yb = inTail ? A.tail_from + tj / A.tail_split
+                          : xx * xq + (xx < xr ? xx : xr) + (int)(by >> 3);      // a bijection of [0, ky) for every ky
     const int k = yb * BPW + blk;
     const bool live = k < A.K;                                     // the last workgroup may hold fewer than BPW blocks
     const ZlBlockPlan *s_plan = s_plan_[blk];
@@ -880,9 +887,10 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
     // Narrow buses (the reference's 8 voices per channel): one workgroup renders A.NB whole buses, one after the other,
     // from ONE staging pass over their NB * VPB <= 128 voices -- the gathers of consecutive buses keep flowing and the
     // fixed costs per workgroup are shared.  NB == 1: one (bus, mix group) per workgroup.
-    const int NB = A.NB;
-    const int bus0 = (NB > 1) ? (int)bz * NB : (int)bz / A.groups;
-    const int g    = (NB > 1) ? 0 : (int)bz - bus0 * A.groups;
+    const int NB = inTail ? A.tail_nb : A.NB;
+    const int zz = inTail ? tj % A.tail_split : (int)bz;          // (a split tail exists only where one workgroup holds all the buses: bz == 0)
+    const int bus0 = (NB > 1) ? zz * NB : zz / A.groups;
+    const int g    = (NB > 1) ? 0 : zz - bus0 * A.groups;
     const int v0 = bus0 * A.VPB + g * A.G;
     const int vlim = (NB > 1) ? ((bus0 + NB) * A.VPB < V ? (bus0 + NB) * A.VPB : V) : (bus0 + 1) * A.VPB;
     const int v1 = (NB > 1) ? vlim : ((v0 + A.G < vlim) ? v0 + A.G : vlim);
@@ -1302,7 +1310,7 @@ static __device__ __forceinline__ void zl_k2_body(const ZlBatch &A, const unsign
                 A.rep_gain[v] = gn;
                 if (A.rep_host) { uint4 *dst = reinterpret_cast<uint4 *>(&A.rep_host[v]); dst[0] = a; dst[1] = b; A.rep_host_gain[v] = gn; }
             }
-            if (bz == 0 && threadIdx.x == 0 && A.rep_host_stats) {
+            if (bus0 == 0 && g == 0 && threadIdx.x == 0 && A.rep_host_stats) {
                 const unsigned long long sb = A.stats->source_bytes, sl = A.stats->slow_blocks, af = A.stats->active_frames;
                 A.rep_host_stats->source_bytes = sb; A.rep_host_stats->slow_blocks = sl; A.rep_host_stats->active_frames = af;
                 A.stats->source_bytes = 0; A.stats->slow_blocks = 0; A.stats->active_frames = 0;   // cleared for the call that reuses this slot
@@ -1866,7 +1874,21 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEv
     const int bpw = ((A.N == 64 || A.N == 128) && A.K > 1) ? 256 / A.N : 1;
     // (whole waves: a block of 100 frames runs on 128 lanes, one of 300 on two workgroups of 256)
     const int tpb = bpw > 1 ? 256 : (A.N < 256 ? ((A.N + 63) & ~63) : 256);
-    const dim3 grid(bpw > 1 ? 1 : (A.N + tpb - 1) / tpb, (A.K + bpw - 1) / bpw, A.NB > 1 ? (A.B + A.NB - 1) / A.NB : A.B * A.groups), block(tpb);
+    dim3 grid(bpw > 1 ? 1 : (A.N + tpb - 1) / tpb, (A.K + bpw - 1) / bpw, A.NB > 1 ? (A.B + A.NB - 1) / A.NB : A.B * A.groups);
+    const dim3 block(tpb);
+    // split tail (see zl_k2_body): one workgroup per block holding ALL the buses, a window long enough to have a tail worth splitting
+    static const int tail_env = [] { const char *e = getenv("ZL_K2_TAIL"); return e ? atoi(e) : 1; }();
+    static const int tail_min = [] { const char *e = getenv("ZL_K2_TAIL_MIN_BLOCKS"); return e ? std::max(8, atoi(e)) : 2048; }();   // (the test tier lowers it)
+    ZlBatch At = A;
+    At.tail_from = 0; At.tail_split = 1; At.tail_nb = A.NB;
+    if (tail_env && bpw == 1 && A.NB > 1 && A.NB == A.B && grid.z == 1 && grid.x == 1 && !(A.staged && A.K > 1 && tpb == 256) && A.K >= tail_min) {
+        const int split = (A.NB % 4 == 0) ? 4 : (A.NB % 2 == 0) ? 2 : 1;
+        if (split > 1) {
+            const int T = std::min(A.K / 4, 640);                  // half a generation of workgroups (5 per CU x 256 CUs)
+            At.tail_from = A.K - T; At.tail_split = split; At.tail_nb = A.NB / split;
+            grid.y = (unsigned)(At.tail_from + T * split);
+        }
+    }
     // One-block-per-workgroup kernels fill every SIMD's register file (6 waves x 80 VGPRs; 5 x 96 with 4 taps) and
     // leave no room for a planning wave (88 VGPRs): a K1 launch that arrives after K2 has filled the machine then
     // crawls (measured 550 instead of 130 us).  Unused dynamic LDS caps K2 at 5 workgroups per CU (27 KB each of
@@ -1884,12 +1906,12 @@ int zl_launch_render(const ZlBatch &A, hipStream_t s, hipEvent_t ev_start, hipEv
     const int ring = 4 * ZL_ST_D * ZL_ST_SLOT;
     switch (A.mode & 7u) {
 #define ZL_CASE(M) case M: \
-        if (st && bpw == 4)      hipExtLaunchKernelGGL((zl_k2_render<M, 4, true>), grid, block, ring, s, ev_start, ev_stop, 0, A); \
-        else if (st && bpw == 2) hipExtLaunchKernelGGL((zl_k2_render<M, 2, true>), grid, block, ring, s, ev_start, ev_stop, 0, A); \
-        else if (st)             hipExtLaunchKernelGGL((zl_k2_render<M, 1, true>), grid, block, ring, s, ev_start, ev_stop, 0, A); \
-        else if (bpw == 4)       hipExtLaunchKernelGGL((zl_k2_render<M, 4, false>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
-        else if (bpw == 2)       hipExtLaunchKernelGGL((zl_k2_render<M, 2, false>), grid, block, 0, s, ev_start, ev_stop, 0, A); \
-        else                     hipExtLaunchKernelGGL((zl_k2_render<M, 1, false>), grid, block, pad, s, ev_start, ev_stop, 0, A); \
+        if (st && bpw == 4)      hipExtLaunchKernelGGL((zl_k2_render<M, 4, true>), grid, block, ring, s, ev_start, ev_stop, 0, At); \
+        else if (st && bpw == 2) hipExtLaunchKernelGGL((zl_k2_render<M, 2, true>), grid, block, ring, s, ev_start, ev_stop, 0, At); \
+        else if (st)             hipExtLaunchKernelGGL((zl_k2_render<M, 1, true>), grid, block, ring, s, ev_start, ev_stop, 0, At); \
+        else if (bpw == 4)       hipExtLaunchKernelGGL((zl_k2_render<M, 4, false>), grid, block, 0, s, ev_start, ev_stop, 0, At); \
+        else if (bpw == 2)       hipExtLaunchKernelGGL((zl_k2_render<M, 2, false>), grid, block, 0, s, ev_start, ev_stop, 0, At); \
+        else                     hipExtLaunchKernelGGL((zl_k2_render<M, 1, false>), grid, block, pad, s, ev_start, ev_stop, 0, At); \
         break;
         ZL_CASE(0) ZL_CASE(1) ZL_CASE(2) ZL_CASE(3) ZL_CASE(4) ZL_CASE(5) ZL_CASE(6) ZL_CASE(7)
 #undef ZL_CASE

@@ -258,6 +258,8 @@ struct ZlBatch {
     int32_t G;                    // voices per render task (mix group); groups per bus = ceil(VPB / G)
     int32_t groups;
     int32_t NB;                   // buses rendered by one K2 workgroup (narrow buses in batches), else 1
+    int32_t tail_from, tail_split, tail_nb;   // narrow buses, one workgroup per block: launch slots from tail_from on render the window's LAST blocks with
+                                  // tail_nb buses per workgroup, tail_split workgroups per block (zl_launch_render; 0 = no split tail)
     int32_t host_fmt;             // offline bounce, direct delivery: K2 also stores the finished bus into the caller's page-locked HOST buffer
                                   // (0 = fp32 planar [B][2][host_total], 1 = 16-bit stereo [B][host_total][2]) -- no conversion pass, no copy
     void   *host_out;             // device view of that buffer, or nullptr

@@ -34,7 +34,7 @@ t = syn.last_timings()
 tr = syn.read_trace().reshape(-1)
 nb = max(1, min(16, 128 // (V // B))) if V // B <= 64 else 1      # narrow buses per workgroup (zl_engine.cpp)
 nwg_z = (B + nb - 1) // nb
-nwg = KB * nwg_z
+nwg = 2 * KB * nwg_z          # (a split tail adds workgroups: every stamped record in this range is one)
 st = tr[: nwg * 8].view(np.uint64).reshape(nwg, 4)
 ok = st[:, 0] != np.uint64(0xffffffffffffffff)
 st = st[ok]
@@ -42,7 +42,10 @@ t0, t1, t2 = st[:, 0].astype(np.float64), st[:, 1].astype(np.float64), st[:, 2].
 ta, tb = (st[:, 3] & np.uint64(0xffff)).astype(np.float64) * 10e-3, ((st[:, 3] >> np.uint64(16)) & np.uint64(0xffff)).astype(np.float64) * 10e-3
 base = t0.min()
 dur, stage = (t2 - t0) * 10e-3, (t1 - t0) * 10e-3          # 100 MHz ticks -> us
-print(f"V={V} B={B} blocks={KB} source rate {SR or fs:.0f} notes {NOTES}: K2 {t.render_ms * 1e3:.1f} us by its events, {(t2.max() - base) * 10e-3:.1f} us by the stamps; {len(st)} of {nwg} workgroups stamped")
+print(f"V={V} B={B} blocks={KB} source rate {SR or fs:.0f} notes {NOTES}: K2 {t.render_ms * 1e3:.1f} us by its events, {(t2.max() - base) * 10e-3:.1f} us by the stamps; {len(st)} workgroups stamped")
+order = np.argsort(t0)
+late = dur[order][-len(dur) // 16:]
+print(f"lifetime of the last sixteenth of the workgroups to start: mean {late.mean():.2f} us")
 print(f"workgroup lifetime us: mean {dur.mean():.2f} p50 {np.percentile(dur, 50):.2f} p90 {np.percentile(dur, 90):.2f} p99 {np.percentile(dur, 99):.2f}")
 print(f"staging prologue us:   mean {stage.mean():.2f} p50 {np.percentile(stage, 50):.2f} p99 {np.percentile(stage, 99):.2f}  = {100 * stage.sum() / dur.sum():.1f} % of the lifetimes")
 print(f"  of it: up to the first barrier {ta.mean():.2f} us, loads landed at {tb.mean():.2f} us (p99 {np.percentile(tb, 99):.2f}), classification + LDS + second barrier end at {stage.mean():.2f} us")

@@ -1117,6 +1117,7 @@ static int render_batch_impl(zlhip_engine *e, int32_t nblocks, int32_t nframes, 
     int W = e->windowBlocks > 0 ? e->windowBlocks : (int)std::max<size_t>(1, std::min<size_t>(mul * e->windowFrames / (size_t)nframes, (size_t)1 << 30));
     W = std::min(W, e->windowCap);
     W = std::min(W, (1 << 30) / nframes);                          // window time is a 32-bit frame index in K1 / K1c
+    W = std::min(W, 60000);                                        // a K2 launch has one y slot per block (+ 1920 for a split tail): gridDim.y stays below 65536
     std::vector<std::pair<int, int>> &wins = e->wins;              // (first block, blocks); member: no allocation per call
     wins.clear();
     // when the previous call is still in flight its rendering hides the planning of this call's first window: no

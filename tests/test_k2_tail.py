@@ -61,3 +61,14 @@ def test_split_tail_with_fanout_and_bounce(Engine):
     bus, rep, syn, _ = run_backend(sc, Engine, bounce=("f32", 50))
     compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 64)
     syn.close()
+
+
+@pytest.mark.gpu
+def test_very_long_call_stays_inside_the_grid_limit(Engine):
+    """66000 blocks of a 16-voice engine in ONE call: its plan windows would be 65536 blocks long (few voices: long windows) -- one launch slot per
+    block plus the split tail's extra workgroups must stay below the 65536 slots of a grid's y dimension (windows are capped at 60000 blocks)"""
+    sc = random_scene(0x7A20, nframes=256, nblocks=66000, nclips=4, min_len=20000, max_len=60000, events=False, mode=0, num_buses=2, voices_per_bus=8)
+    ref_bus, ref_rep, ref_syn = run_oracle(sc)
+    bus, rep, syn, _ = run_backend(sc, Engine, batch=1 << 30)
+    compare_runs(ref_bus, ref_rep, ref_syn, bus, rep, 16)
+    syn.close()
